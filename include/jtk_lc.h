@@ -1,0 +1,206 @@
+/* jtk_lc.h -- C ABI of the MI355X-native local-clustering stage (drop-in for the rayon loop of
+ * ban-m/jtk haplotyper/src/local_clustering/mod.rs:64-72).
+ *
+ * Everything here is plain C: pointers, sizes and POD structs; no torch / HIP types.  All buffers are
+ * caller-owned HOST memory unless a function name ends in `_dev`; the library never keeps a pointer
+ * after returning, never throws/unwinds across the boundary, and returns 0 or a negative jtk_status.
+ * The reference has no FFI layer (it is one Rust process); each entry point below cites the Rust item
+ * it replaces, and INTEGRATION.md shows the `extern "C"` block + shim a jtk maintainer would add.
+ *
+ * Sequence encoding at the boundary: ASCII upper-case ACGT (the reference rejects anything else at
+ * entry, haplotyper/src/entry.rs:40-45).  Alignment ops are one byte per column, values of
+ * `kiley::Op` in the order the reference uses them (haplotyper/src/misc.rs:167-172):
+ *   0 = Match, 1 = Mismatch, 2 = Ins (read base, no template base), 3 = Del (template base, no read base).
+ */
+#ifndef JTK_LC_H
+#define JTK_LC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JTK_LC_ABI_VERSION 1
+
+/* kiley::hmm::NUM_ROW = 8 + COPY_SIZE + DEL_SIZE (pseudo_mcmc.rs:7,172,447): rows 0-3 substitute to
+ * ACGT, 4-7 insert ACGT before the position, 8-10 copy 1-3 bp, 11-13 delete 1-3 bp. */
+#define JTK_NUM_ROW 14
+#define JTK_COPY_SIZE 3
+#define JTK_DEL_SIZE 3
+#define JTK_GAINS_MAX_HOMOP 8
+
+enum jtk_op { JTK_OP_MATCH = 0, JTK_OP_MISMATCH = 1, JTK_OP_INS = 2, JTK_OP_DEL = 3 };
+
+/* likelihood_gains.rs:194-199 (declaration order). */
+enum jtk_diff_type { JTK_DIFF_SUBST = 0, JTK_DIFF_DEL = 1, JTK_DIFF_INS = 2 };
+
+typedef enum jtk_status {
+    JTK_OK = 0,
+    JTK_ERR_INVALID_ARG = -1,     /* null pointer, inconsistent offsets, non-ACGT base, bad op code    */
+    JTK_ERR_NO_DEVICE = -2,       /* no usable MI355X / HIP runtime failure (message via last_error)   */
+    JTK_ERR_UNSUPPORTED = -3,     /* band radius > 31 (one wavefront per anti-diagonal), copy_num >= 8 */
+    JTK_ERR_ALLOC = -4,           /* hipMalloc / host allocation failed                                */
+    JTK_ERR_OPS_MISMATCH = -5,    /* ops do not consume exactly the template and the read              */
+    JTK_ERR_CHUNK_FAILED = -6,    /* >=1 chunk hit a condition on which the reference panics; see      */
+                                  /* chunk_status[] (e.g. WeightedError::AllWeightsZero, misc.rs:335)  */
+    JTK_ERR_INTERNAL = -7
+} jtk_status;
+
+/* definitions/src/lib.rs:101-126 (same field order; model_tune.rs:36-63 maps it 1:1 onto
+ * kiley::hmm::PairHiddenMarkovModel).  mat_emit[4*ref + read]; ins_emit[4*prev_read_base + read] with
+ * prev = 4 for the first read base (own reading of kiley's 20-entry table). */
+typedef struct jtk_hmm {
+    double mat_mat, mat_ins, mat_del;
+    double ins_mat, ins_ins, ins_del;
+    double del_mat, del_ins, del_del;
+    double mat_emit[16];
+    double ins_emit[20];
+} jtk_hmm_t;
+
+/* likelihood_gains.rs:41-47 / :55-61. */
+typedef struct jtk_gain_profile {
+    double gain;
+    double prob;
+} jtk_gain_profile_t;
+
+typedef struct jtk_gains {
+    uint32_t max_homopolymer_len; /* 3 for estimate_gain_default (likelihood_gains.rs:189) */
+    uint32_t reserved;
+    jtk_gain_profile_t subst[JTK_GAINS_MAX_HOMOP];
+    jtk_gain_profile_t deletions[JTK_GAINS_MAX_HOMOP];
+    jtk_gain_profile_t insertions[JTK_GAINS_MAX_HOMOP];
+} jtk_gains_t;
+
+/* What local_clustering_selected computes once per call and passes by reference into every
+ * clustering_on_pileup (mod.rs:57-62): the model on both strands, the calibrated gains, the haploid
+ * coverage and the read type (only its band fraction matters here, definitions/src/lib.rs:173-175). */
+typedef struct jtk_lc_params {
+    jtk_hmm_t forward;
+    jtk_hmm_t reverse;
+    jtk_gains_t gains;
+    double haploid_coverage;
+    double band_frac; /* 0.03 ONT, 0.01 CCS, 0.05 CLR/None; band_width = ceil(len*frac), radius = band_width/2 */
+} jtk_lc_params_t;
+
+/* One pile-up = one call of clustering_on_pileup (mod.rs:86-123). Reads are already in the order fixed
+ * by pileup_nodes (mod.rs:45-51); jtk_lc_pileup_sort_keys below gives the sort key. */
+typedef struct jtk_lc_chunk {
+    uint64_t chunk_id;   /* seeds the per-chunk RNG: Xoshiro256StarStar::seed_from_u64(id * 3490) (mod.rs:97) */
+    uint32_t copy_num;   /* Chunk.copy_num (definitions/src/lib.rs:403-415) */
+    uint32_t n_reads;
+    uint64_t tmpl_off;   /* into tmpl_bases */
+    uint64_t tmpl_len;
+    uint64_t read_first; /* index of this chunk's first read in read_off / ops_off / strand */
+} jtk_lc_chunk_t;
+
+/* Per-chunk result record. */
+typedef struct jtk_lc_result {
+    double score;         /* Chunk.score (mod.rs:78)        */
+    uint32_t cluster_num; /* Chunk.cluster_num (mod.rs:79)   */
+    int32_t status;       /* 0, or the jtk_status this chunk failed with */
+    uint32_t polish_rounds;
+    uint32_t n_variants;  /* D: number of selected variant columns (filter_profiles) */
+} jtk_lc_result_t;
+
+/* ---- the drop-in entry point ------------------------------------------------------------------
+ * Replaces `pileups.into_par_iter()...map(clustering_on_pileup)` (mod.rs:64-72) for a batch of chunks:
+ * consensus polishing (mod.rs:105-106), variant search (pseudo_mcmc.rs:109-138), clustering
+ * (pseudo_mcmc.rs:213-274, 77-107) and the per-node write-back data of update_by_clusterings
+ * (mod.rs:244-260).  copy_num >= 8 (clustering_recursive's split branch, mod.rs:138-189) is not yet on
+ * the device: such chunks get status JTK_ERR_UNSUPPORTED.
+ *
+ * label[r]        : Node.cluster of read r (before normalize_local_clustering).
+ * log_post        : row r has post_stride doubles; the first result[c].cluster_num are Node.posterior
+ *                   (log posterior, rows logsumexp to 0), the rest are written as 0.
+ * cons_out        : polished consensus of chunk c at cons_off[c] .. cons_off[c+1]; the caller provides
+ *                   capacity cons_cap bytes in total (>= sum(tmpl_len) + 64*n_chunks is always enough:
+ *                   the library fails the chunk rather than overrun).
+ * ops_out         : re-threaded per-base ops of read r at ops_out_off[r] .. ops_out_off[r+1], capacity
+ *                   ops_cap bytes (sum(ops_len) + 8*polish edits; same overrun rule).
+ * device          : HIP device ordinal (one process drives one GPU; multi-GPU = one process per GPU).
+ */
+int jtk_lc_cluster_chunks(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                          const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                          const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
+                          uint32_t *label, double *log_post, uint32_t post_stride, jtk_lc_result_t *result,
+                          uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out,
+                          uint64_t *ops_out_off, uint64_t ops_cap, int device);
+
+/* Same, but the template is an already polished consensus and ops are already re-threaded: skips
+ * polish_until_converge_antidiagonal.  This is `pseudo_mcmc::clustering` (pseudo_mcmc.rs:77-107) batched;
+ * a Rust host that keeps real kiley polishing calls this one and inherits exactness downstream.
+ * cons_out/ops_out are not produced. */
+int jtk_lc_cluster_polished(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                            const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                            const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
+                            uint32_t *label, double *log_post, uint32_t post_stride,
+                            jtk_lc_result_t *result, int device);
+
+/* ---- stage pieces, exported because the reference exposes them too ------------------------------ */
+
+/* `pseudo_mcmc::modification_table` (pseudo_mcmc.rs:45-68) for one pile-up: for read r, table[r] has
+ * JTK_NUM_ROW*(tmpl_len+1) doubles = kiley modification_table_antidiagonal(...) MINUS lk[r]
+ * (pseudo_mcmc.rs:62-64); lk[r] is the read's log-likelihood under the unedited template. */
+int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl, uint64_t tmpl_len,
+                              uint32_t n_reads, const uint8_t *read_bases, const uint64_t *read_off,
+                              const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
+                              double *table, double *lk, int device);
+
+/* `pseudo_mcmc::cluster_filtered_variants` + the re-assignment / posterior tail of `clustering`
+ * (pseudo_mcmc.rs:213-274, 98-105) on caller-supplied feature matrices (the entry the reference's
+ * sandbox/src/bin/benchmark_mcmc.rs:111-114 drives).  Chunk c: variants[var_off[c] ..] is n_reads x dim
+ * row-major, variant_type[vt_off..] is dim x (homop_len, jtk_diff_type) pairs of uint32. */
+typedef struct jtk_lc_feature_chunk {
+    uint64_t chunk_id;
+    uint32_t copy_num;
+    uint32_t n_reads;
+    uint32_t dim;
+    uint32_t reserved;
+    uint64_t var_off;  /* in doubles */
+    uint64_t vt_off;   /* in (uint32,uint32) pairs */
+    uint64_t read_first;
+    double local_coverage; /* ClusteringConfig.local_coverage (mod.rs:108-112) */
+} jtk_lc_feature_chunk_t;
+
+int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks,
+                            const jtk_lc_feature_chunk_t *chunks, const double *variants,
+                            const uint32_t *variant_type, uint32_t *label, double *log_post,
+                            uint32_t post_stride, jtk_lc_result_t *result, int device);
+
+/* ---- host-side helpers (no GPU needed) ------------------------------------------------------------ */
+
+/* Sort key of pileup_nodes (mod.rs:47-50): number of alignment columns that are not '|' in
+ * Node::recover (definitions/src/lib.rs:773-813) for run-length cigar ops given per base. */
+int jtk_lc_pileup_sort_key(const uint8_t *tmpl, uint64_t tmpl_len, const uint8_t *read, uint64_t read_len,
+                           const uint8_t *ops, uint64_t ops_len, uint64_t *key_out);
+
+/* normalize_local_clustering for one pile-up (normalize.rs:21-50): relabels by descending cluster size
+ * (ties: larger old index first) and permutes each posterior row in place. */
+int jtk_lc_normalize_pileup(uint32_t n_reads, uint32_t cluster_num, uint32_t *label, double *log_post,
+                            uint32_t post_stride);
+
+const char *jtk_lc_strerror(int status);
+/* Thread-local text of the last failure on this thread (HIP error strings etc.); "" if none. */
+const char *jtk_lc_last_error(void);
+int jtk_lc_version(void);
+/* 1 if a gfx950 device `device` is present and the kernels for it are loaded. */
+int jtk_lc_device_ok(int device);
+
+/* Timing of the last jtk_lc_cluster_* call on this thread, measured with HIP events on the library's
+ * own stream: total device milliseconds and the milliseconds + launch count of each kernel family
+ * (index = enum jtk_kernel_id).  Used by bench.py for the live roofline number. */
+enum jtk_kernel_id { JTK_K_PHMM = 0, JTK_K_POLISH = 1, JTK_K_FILTER = 2, JTK_K_MCMC = 3, JTK_K_COUNT = 4 };
+typedef struct jtk_lc_timing {
+    double total_ms;
+    double h2d_ms, d2h_ms;
+    double kernel_ms[JTK_K_COUNT];
+    uint32_t kernel_launches[JTK_K_COUNT];
+} jtk_lc_timing_t;
+int jtk_lc_last_timing(jtk_lc_timing_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JTK_LC_H */
