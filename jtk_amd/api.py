@@ -1,0 +1,149 @@
+"""Thin numpy wrappers over the C-ABI (include/jtk_lc.h).  Every compute function runs on the GPU through
+libjtk_lc.so; there is no fallback path."""
+import ctypes as C
+
+import numpy as np
+
+from . import ffi
+from .ffi import check, f64p, u8p, u32p, u64p
+
+
+def _outputs(batch):
+    n_chunks, n_reads, stride = batch.n_chunks, batch.n_reads, batch.post_stride
+    label = np.zeros(n_reads, dtype=np.uint32)
+    post = np.zeros((n_reads, stride), dtype=np.float64)
+    result = np.zeros(n_chunks, dtype=ffi.RESULT_DT)
+    cons_cap = int(batch.chunks["tmpl_len"].sum()) * 2 + 64 * n_chunks + 64
+    ops_cap = int(len(batch.ops)) * 2 + 64 * n_reads + 64
+    cons = np.zeros(cons_cap, dtype=np.uint8)
+    cons_off = np.zeros(n_chunks + 1, dtype=np.uint64)
+    ops_out = np.zeros(ops_cap, dtype=np.uint8)
+    ops_out_off = np.zeros(n_reads + 1, dtype=np.uint64)
+    return dict(label=label, log_post=post, result=result, cons=cons, cons_off=cons_off, ops_out=ops_out,
+                ops_out_off=ops_out_off)
+
+
+def cluster_chunks(params, batch, device=0, raise_on_chunk_failure=True):
+    """jtk_lc_cluster_chunks: polish + variant search + clustering for every chunk of `batch`."""
+    L = ffi.lib()
+    o = _outputs(batch)
+    rc = L.jtk_lc_cluster_chunks(C.byref(params), batch.n_chunks, batch.chunks.ctypes.data, u8p(batch.tmpl_bases),
+                                 u8p(batch.read_bases), u64p(batch.read_off), u8p(batch.ops), u64p(batch.ops_off),
+                                 u8p(batch.strand), u32p(o["label"]), f64p(o["log_post"]), batch.post_stride,
+                                 o["result"].ctypes.data, u8p(o["cons"]), u64p(o["cons_off"]), len(o["cons"]),
+                                 u8p(o["ops_out"]), u64p(o["ops_out_off"]), len(o["ops_out"]), device)
+    if rc != 0 and (raise_on_chunk_failure or rc != -6):
+        check(rc)
+    o["rc"] = rc
+    return o
+
+
+def cluster_polished(params, batch, device=0, raise_on_chunk_failure=True):
+    """jtk_lc_cluster_polished: the template is already the polished consensus (pseudo_mcmc::clustering)."""
+    L = ffi.lib()
+    o = _outputs(batch)
+    rc = L.jtk_lc_cluster_polished(C.byref(params), batch.n_chunks, batch.chunks.ctypes.data,
+                                   u8p(batch.tmpl_bases), u8p(batch.read_bases), u64p(batch.read_off), u8p(batch.ops),
+                                   u64p(batch.ops_off), u8p(batch.strand), u32p(o["label"]), f64p(o["log_post"]),
+                                   batch.post_stride, o["result"].ctypes.data, device)
+    if rc != 0 and (raise_on_chunk_failure or rc != -6):
+        check(rc)
+    o["rc"] = rc
+    return o
+
+
+def modification_table(params, tmpl, reads, ops, strands, device=0):
+    """jtk_lc_modification_table for one pile-up -> (table [n, 14*(L+1)] minus lk, lk [n])."""
+    L = ffi.lib()
+    n = len(reads)
+    rb = np.concatenate(reads).astype(np.uint8) if n else np.zeros(0, np.uint8)
+    ob = np.concatenate(ops).astype(np.uint8) if n else np.zeros(0, np.uint8)
+    ro = np.zeros(n + 1, dtype=np.uint64)
+    oo = np.zeros(n + 1, dtype=np.uint64)
+    ro[1:] = np.cumsum([len(r) for r in reads])
+    oo[1:] = np.cumsum([len(o) for o in ops])
+    st = np.array([1 if s else 0 for s in strands], dtype=np.uint8)
+    tmpl = np.ascontiguousarray(tmpl, dtype=np.uint8)
+    table = np.zeros((n, ffi.NUM_ROW * (len(tmpl) + 1)), dtype=np.float64)
+    lk = np.zeros(n, dtype=np.float64)
+    check(L.jtk_lc_modification_table(C.byref(params), u8p(tmpl), len(tmpl), n, u8p(rb), u64p(ro), u8p(ob), u64p(oo),
+                                      u8p(st), f64p(table), f64p(lk), device))
+    return table, lk
+
+
+def cluster_features(params, feature_chunks, variants, variant_type, post_stride, device=0,
+                     raise_on_chunk_failure=True):
+    """jtk_lc_cluster_features: cluster_filtered_variants + posterior on caller-supplied feature matrices."""
+    L = ffi.lib()
+    n_reads = int(feature_chunks["n_reads"].sum())
+    label = np.zeros(n_reads, dtype=np.uint32)
+    post = np.zeros((n_reads, post_stride), dtype=np.float64)
+    result = np.zeros(len(feature_chunks), dtype=ffi.RESULT_DT)
+    variants = np.ascontiguousarray(variants, dtype=np.float64)
+    variant_type = np.ascontiguousarray(variant_type, dtype=np.uint32)
+    rc = L.jtk_lc_cluster_features(C.byref(params), len(feature_chunks), feature_chunks.ctypes.data, f64p(variants),
+                                   u32p(variant_type), u32p(label), f64p(post), post_stride, result.ctypes.data, device)
+    if rc != 0 and (raise_on_chunk_failure or rc != -6):
+        check(rc)
+    return dict(rc=rc, label=label, log_post=post, result=result)
+
+
+def last_timing():
+    t = ffi.Timing()
+    check(ffi.lib().jtk_lc_last_timing(C.byref(t)))
+    return dict(total_ms=t.total_ms, h2d_ms=t.h2d_ms, d2h_ms=t.d2h_ms,
+                kernel_ms={n: t.kernel_ms[i] for i, n in enumerate(ffi.KERNEL_NAMES)},
+                kernel_launches={n: int(t.kernel_launches[i]) for i, n in enumerate(ffi.KERNEL_NAMES)})
+
+
+class Session:
+    """Resident-batch session: inputs uploaded once, `run()` = one pass of the hot path on the device."""
+
+    def __init__(self, params, batch, device=0):
+        self._lib = ffi.lib()
+        self._h = C.c_void_p()
+        self.batch = batch
+        self.params = params
+        check(self._lib.jtk_lc_session_create(C.byref(params), batch.n_chunks, batch.chunks.ctypes.data,
+                                              u8p(batch.tmpl_bases), u8p(batch.read_bases), u64p(batch.read_off),
+                                              u8p(batch.ops), u64p(batch.ops_off), u8p(batch.strand),
+                                              batch.post_stride, device, C.byref(self._h)))
+
+    def run(self, skip_polish=False):
+        check(self._lib.jtk_lc_session_run(self._h, int(skip_polish)))
+
+    def fetch(self, raise_on_chunk_failure=True):
+        o = _outputs(self.batch)
+        rc = self._lib.jtk_lc_session_fetch(self._h, u32p(o["label"]), f64p(o["log_post"]), o["result"].ctypes.data,
+                                            u8p(o["cons"]), u64p(o["cons_off"]), len(o["cons"]), u8p(o["ops_out"]),
+                                            u64p(o["ops_out_off"]), len(o["ops_out"]))
+        if rc != 0 and (raise_on_chunk_failure or rc != -6):
+            check(rc)
+        o["rc"] = rc
+        return o
+
+    def close(self):
+        if self._h:
+            self._lib.jtk_lc_session_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def normalize_pileup(label, log_post, cluster_num):
+    """normalize_local_clustering for one pile-up (normalize.rs:21-50), in place."""
+    label = np.ascontiguousarray(label, dtype=np.uint32)
+    log_post = np.ascontiguousarray(log_post, dtype=np.float64)
+    check(ffi.lib().jtk_lc_normalize_pileup(len(label), int(cluster_num), u32p(label), f64p(log_post),
+                                            log_post.shape[1]))
+    return label, log_post

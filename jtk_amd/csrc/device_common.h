@@ -1,0 +1,102 @@
+// device_common.h -- shared declarations of the HIP kernels (gfx950 only) and the session that drives them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jtk_lc.h"
+#include "jtk_math.h"
+
+#define JTK_WAVE 64
+#define JTK_MAX_RADIUS 30        // 2r+1 <= 61 lanes: 3 spare lanes make the lane ring unambiguous
+#define JTK_SCALE_BLOCK 64       // one power-of-two exponent per 64 anti-diagonals (oracle/phmm.c)
+#define JTK_ACC_N 16             // accumulators per template row (see phmm_kernels.hip)
+#define JTK_LOG_ZERO (-1.0e300)
+#define JTK_LN2 0.6931471805599453094
+#define JTK_POS_THR 0.00001      // pseudo_mcmc.rs:5
+#define JTK_MASK_LENGTH 7        // pseudo_mcmc.rs:3
+#define JTK_MAX_HOMOP_LENGTH 2   // pseudo_mcmc.rs:4
+#define JTK_MAX_COPY 7           // copy_num < 8 on the device (clustering_recursive's split is host-side work)
+#define JTK_MAX_DIM (3 * JTK_MAX_COPY)  // ROUND * max(copy_num, 2) picked columns (pseudo_mcmc.rs:421,527,532)
+#define JTK_POLISH_MIN_GAIN 0.1
+#define JTK_POLISH_MAX_ROUNDS 20
+
+// One read of the resident batch.
+struct ReadMeta {
+    uint32_t chunk;      // index into ChunkMeta
+    uint32_t read_len;   // n
+    uint64_t ey_off;     // into d_ey: ey[j] = y[j-1] | ctx(j)<<2 for j = 1..n (ey[0] unused)
+    uint64_t ops_off;    // into d_ops[cur] (capacity slot)
+    uint32_t ops_cap;
+    uint32_t strand;     // 1 = forward model
+    uint64_t delta_off;  // into d_delta (u64 words)
+    uint64_t table_off;  // into d_table (doubles): JTK_NUM_ROW * (tmpl_cap + 1) per read
+    uint64_t raw_off;    // into d_raw (doubles): JTK_ACC_N * (tmpl_cap + 1) per read
+    uint64_t row_off;    // into d_rawG (ints): tmpl_cap + 1 per read
+};
+
+// One chunk (pile-up) of the resident batch.
+struct ChunkMeta {
+    uint64_t chunk_id;
+    uint32_t copy_num;
+    uint32_t n_reads;
+    uint32_t read_first;
+    uint32_t tmpl_cap;   // capacity of each template buffer
+    uint64_t tmpl_off;   // into d_tmpl[cur]
+    uint64_t total_off;  // into d_total (doubles): JTK_NUM_ROW * (tmpl_cap + 1)
+    uint32_t radius;     // band radius for this chunk: ceil(len0 * band_frac) / 2 (mod.rs:96,105)
+    uint32_t edit_cap;   // capacity of this chunk's edit list
+    uint64_t edit_off;   // into d_edits
+    uint64_t feat_off;   // into d_feat (doubles): n_reads * JTK_MAX_DIM
+    uint64_t cand_off;   // into d_cand (doubles): JTK_NUM_ROW * (tmpl_cap + 1) candidate scores
+    double local_coverage;  // ClusteringConfig.local_coverage (mod.rs:108-112)
+};
+
+// Mutable per-chunk state (device resident).
+struct ChunkState {
+    uint32_t tmpl_len;   // current template length
+    uint32_t buf;        // which of the two template / ops buffers is current
+    uint32_t active;     // 1 while polishing has not converged
+    uint32_t rounds;     // polish rounds executed
+    int32_t status;      // jtk_status of this chunk
+    uint32_t n_edits;    // edits selected in the current round
+    uint32_t dim;        // D selected variant columns
+    uint32_t k;          // cluster_num
+    double score;
+};
+
+struct HmmDev {
+    double a[9];      // mat_mat, mat_ins, mat_del, ins_mat, ins_ins, ins_del, del_mat, del_ins, del_del
+    double eM[16];
+    double eI[20];
+};
+
+struct Edit {
+    uint32_t pos;
+    uint32_t row;
+};
+
+// The two ping-pong buffer sets (template codes, per-base ops and their lengths); ChunkState.buf selects
+// the current one.  Passed to kernels by value.
+struct DevBufs {
+    uint8_t *tmpl[2];
+    uint8_t *ops[2];
+    uint32_t *ops_len[2];
+};
+
+// ---- kernel launchers (definitions in the .hip files) ----
+size_t phmm_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
+void launch_band_prep(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
+                      ChunkState *state, DevBufs bufs, uint64_t *delta, int only_active);
+void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
+                 const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta,
+                 const HmmDev *hmm2, double *scratch, uint64_t scratch_stride, uint32_t n_waves,
+                 uint32_t *work_counter, double *raw, int *rawG, double *lk, uint32_t max_tmpl,
+                 uint32_t max_read, int only_active);
+void launch_finalize(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
+                     const ChunkState *state, const HmmDev *hmm2, const double *raw, const int *rawG,
+                     const double *lk, double *table, uint32_t max_tmpl, int only_active);
+// polish_kernels.hip
+void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, const ReadMeta *reads,
+                         const ChunkMeta *chunks, ChunkState *state, DevBufs bufs, const uint8_t *ey,
+                         const double *table, double *total, Edit *edits, uint32_t *new_len, uint32_t max_tmpl,
+                         uint32_t ignore_edge, int final_pass, uint32_t *n_active_out);

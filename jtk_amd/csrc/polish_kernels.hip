@@ -1,0 +1,225 @@
+// polish_kernels.hip -- one round of consensus polishing on the device (own specification of kiley
+// `polish_until_converge_antidiagonal`, local_clustering/mod.rs:105-106; see DESIGN.md and oracle/phmm.c).
+//
+//   total[p][row] = sum over the reads of the pile-up, IN READ ORDER, of (table_r - lk_r)      (sum_tables)
+//   scan p = ignore_edge .. L-ignore_edge-1 left to right: first best row; apply if > MIN_GAIN, then skip
+//   the touched bases + inactive(round) positions; build the edited template                    (select_edits)
+//   re-thread every read's ops around the edits and recompute the Match/Mismatch tags           (rethread)
+//   flip the ping-pong buffers                                                                  (commit)
+#include "device_common.h"
+
+namespace {
+
+__global__ void sum_tables_kernel(const ReadMeta *reads, const ChunkMeta *chunks, const ChunkState *state,
+                                  const double *table_all, double *total_all) {
+    const uint32_t ci = blockIdx.y;
+    const ChunkState st = state[ci];
+    if (st.status != 0 || !st.active) return;
+    const ChunkMeta cm = chunks[ci];
+    const uint32_t cols = JTK_NUM_ROW * (st.tmpl_len + 1);
+    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols) return;
+    double s = 0.0;
+    for (uint32_t r = 0; r < cm.n_reads; r++) s += table_all[reads[cm.read_first + r].table_off + col];
+    total_all[cm.total_off + col] = s;
+}
+
+__device__ __forceinline__ uint32_t edit_inserted(uint32_t row, uint32_t pos, uint32_t L) {
+    if (row >= 4 && row < 8) return 1;
+    if (row >= 8 && row < 11) {
+        const uint32_t c = row - 7;
+        return pos + c <= L ? c : L - pos;
+    }
+    return 0;
+}
+
+// one wave per chunk: lanes reduce the 14 rows of each position in parallel; lane 0 does the (inherently
+// sequential) left-to-right scan and writes the edited template.
+__global__ __launch_bounds__(64) void select_edits_kernel(const ChunkMeta *chunks, ChunkState *state, DevBufs bufs,
+                                                          const double *total_all, Edit *edits_all,
+                                                          uint32_t *new_len, uint32_t ignore_edge, int final_pass) {
+    extern __shared__ unsigned char s_best[];  // per position: best row | 0x80 if its total > MIN_GAIN
+    const uint32_t ci = blockIdx.x;
+    ChunkState *st = &state[ci];
+    if (st->status != 0 || !st->active) return;
+    const ChunkMeta cm = chunks[ci];
+    const uint32_t L = st->tmpl_len;
+    if (final_pass) {  // table of the final template is ready; nothing more to select
+        if (threadIdx.x == 0) {
+            st->active = 0;
+            st->n_edits = 0;
+        }
+        return;
+    }
+    const double *total = total_all + cm.total_off;
+    for (uint32_t p = threadIdx.x; p < L; p += 64) {
+        uint32_t best = 0;
+        double g = total[p * JTK_NUM_ROW];
+        for (uint32_t row = 1; row < JTK_NUM_ROW; row++) {
+            const double v = total[p * JTK_NUM_ROW + row];
+            if (v > g) {
+                g = v;
+                best = row;
+            }
+        }
+        s_best[p] = (unsigned char)(best | (g > JTK_POLISH_MIN_GAIN ? 0x80u : 0u));
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const uint32_t round = st->rounds;
+    const uint32_t inactive = 5 + (5 * round) % 21;
+    Edit *edits = edits_all + cm.edit_off;
+    uint32_t ne = 0, pos = ignore_edge, grow = 0;
+    while (pos + ignore_edge < L) {
+        const unsigned char b = s_best[pos];
+        if ((b & 0x80u) && ne < cm.edit_cap) {
+            const uint32_t row = b & 0x7fu;
+            edits[ne].pos = pos;
+            edits[ne].row = row;
+            ne++;
+            grow += edit_inserted(row, pos, L);
+            pos += (row >= 11 ? row - 10 : 1) + inactive;
+        } else {
+            pos++;
+        }
+    }
+    st->rounds = round + 1;
+    st->n_edits = ne;
+    if (ne == 0) {
+        st->active = 0;
+        return;
+    }
+    if (L + grow > cm.tmpl_cap) {
+        st->status = JTK_ERR_CHUNK_FAILED;
+        return;
+    }
+    // edited template into the other buffer
+    const uint8_t *src = bufs.tmpl[st->buf] + cm.tmpl_off;
+    uint8_t *dst = bufs.tmpl[st->buf ^ 1] + cm.tmpl_off;
+    uint32_t w = 0, e = 0, p = 0;
+    while (p < L) {
+        if (e < ne && edits[e].pos == p) {
+            const uint32_t row = edits[e].row;
+            e++;
+            if (row < 4) {
+                dst[w++] = (uint8_t)row;
+                p++;
+            } else if (row < 8) {
+                dst[w++] = (uint8_t)(row - 4);
+                dst[w++] = src[p++];
+            } else if (row < 11) {
+                const uint32_t c = row - 7;
+                for (uint32_t q = 0; q < c && p + q < L; q++) dst[w++] = src[p + q];
+                dst[w++] = src[p++];
+            } else {
+                p += row - 10;
+            }
+        } else {
+            dst[w++] = src[p++];
+        }
+    }
+    new_len[ci] = w;
+}
+
+// one thread per read: local surgery of the ops around the edits, then Match/Mismatch re-tagging.
+__global__ void rethread_kernel(uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
+                                ChunkState *state, DevBufs bufs, const uint8_t *ey_all, const Edit *edits_all) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const ReadMeta rm = reads[r];
+    ChunkState *st = &state[rm.chunk];
+    if (st->status != 0 || !st->active || st->n_edits == 0) return;
+    const ChunkMeta cm = chunks[rm.chunk];
+    const uint32_t L = st->tmpl_len, ne = st->n_edits, b = st->buf;
+    const Edit *edits = edits_all + cm.edit_off;
+    const uint8_t *ops = bufs.ops[b] + rm.ops_off;
+    uint8_t *out = bufs.ops[b ^ 1] + rm.ops_off;
+    const uint32_t n_ops = bufs.ops_len[b][r];
+    const uint8_t *tmpl = bufs.tmpl[b ^ 1] + cm.tmpl_off;  // the edited template
+    const uint8_t *ey = ey_all + rm.ey_off;                // read base j is ey[j+1] & 3
+    uint32_t w = 0, e = 0, ti = 0;
+    uint32_t ni = 0, nj = 0;  // positions in the NEW template / the read, for re-tagging
+    bool overflow = false;
+    auto emit = [&](uint8_t op) {
+        if (w >= rm.ops_cap) {
+            overflow = true;
+            return;
+        }
+        if (op == JTK_OP_INS) {
+            nj++;
+        } else if (op == JTK_OP_DEL) {
+            ni++;
+        } else {
+            op = tmpl[ni] == (ey[nj + 1] & 3) ? JTK_OP_MATCH : JTK_OP_MISMATCH;
+            ni++;
+            nj++;
+        }
+        out[w++] = op;
+    };
+    auto pending_inserts = [&]() {
+        while (e < ne && edits[e].pos == ti && edits[e].row >= 4 && edits[e].row < 11) {
+            const uint32_t k = edit_inserted(edits[e].row, edits[e].pos, L);
+            for (uint32_t q = 0; q < k; q++) emit(JTK_OP_DEL);
+            e++;
+        }
+    };
+    pending_inserts();
+    for (uint32_t k = 0; k < n_ops; k++) {
+        const uint8_t op = ops[k];
+        if (op == JTK_OP_INS) {
+            emit(op);
+            continue;
+        }
+        if (e < ne && edits[e].row >= 11 && edits[e].pos <= ti && ti < edits[e].pos + (edits[e].row - 10)) {
+            if (op != JTK_OP_DEL) emit(JTK_OP_INS);
+            ti++;
+            if (ti == edits[e].pos + (edits[e].row - 10)) e++;
+        } else {
+            emit(op);
+            if (e < ne && edits[e].row < 4 && edits[e].pos == ti) e++;
+            ti++;
+        }
+        pending_inserts();
+    }
+    bufs.ops_len[b ^ 1][r] = w;
+    if (overflow) atomicMin(&st->status, (int)JTK_ERR_CHUNK_FAILED);
+}
+
+// reads of chunks WITHOUT edits keep their ops: copy them so both buffers stay valid is unnecessary --
+// only chunks with edits flip.
+__global__ void commit_kernel(uint32_t n_chunks, ChunkState *state, const uint32_t *new_len, uint32_t max_rounds,
+                              uint32_t *n_active) {
+    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= n_chunks) return;
+    ChunkState *st = &state[ci];
+    if (st->status != 0 || !st->active) return;
+    if (st->n_edits > 0) {
+        st->buf ^= 1;
+        st->tmpl_len = new_len[ci];
+        st->n_edits = 0;
+    }
+    atomicAdd(n_active, 1u);
+    (void)max_rounds;
+}
+
+}  // namespace
+
+void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, const ReadMeta *reads,
+                         const ChunkMeta *chunks, ChunkState *state, DevBufs bufs, const uint8_t *ey,
+                         const double *table, double *total, Edit *edits, uint32_t *new_len, uint32_t max_tmpl,
+                         uint32_t ignore_edge, int final_pass, uint32_t *n_active_out) {
+    if (n_chunks == 0) return;
+    hipMemsetAsync(n_active_out, 0, sizeof(uint32_t), s);
+    if (!final_pass) {
+        const uint32_t cols = JTK_NUM_ROW * (max_tmpl + 1);
+        dim3 grid((cols + 255) / 256, n_chunks);
+        sum_tables_kernel<<<grid, 256, 0, s>>>(reads, chunks, state, table, total);
+    }
+    select_edits_kernel<<<n_chunks, 64, max_tmpl + 64, s>>>(chunks, state, bufs, total, edits, new_len,
+                                                            ignore_edge, final_pass);
+    if (!final_pass) {
+        rethread_kernel<<<(n_reads + 63) / 64, 64, 0, s>>>(n_reads, reads, chunks, state, bufs, ey, edits);
+        commit_kernel<<<(n_chunks + 63) / 64, 64, 0, s>>>(n_chunks, state, new_len, JTK_POLISH_MAX_ROUNDS,
+                                                          n_active_out);
+    }
+}

@@ -1,0 +1,718 @@
+// session.hip -- resident-batch session and the C-ABI entry points of include/jtk_lc.h.
+//
+// One process drives one GPU.  A session validates and encodes the flat host batch, uploads it once, allocates
+// every workspace up front (sized for 288 GB of HBM: the full N x 14(L+1) tables of all chunks stay
+// resident), and then runs the stage as a short sequence of kernel launches on its own stream:
+//
+//   band_prep -> [ phmm -> finalize -> polish_round ]* until no chunk is active -> filter -> mcmc
+//
+// (mod.rs:86-123 per chunk).  The last polishing pass that finds no edit has produced exactly the
+// modification table `clustering` would recompute (same consensus, same ops, same radius: mod.rs:105 vs
+// :112, pseudo_mcmc.rs:117), so it is reused instead of recomputed.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "device_common.h"
+
+// launchers defined in the other translation units
+void launch_filter(hipStream_t s, uint32_t n_chunks, const ReadMeta *reads, const ChunkMeta *chunks,
+                   ChunkState *state, DevBufs bufs, const jtk_lc_params_t *params, const double *table,
+                   uint16_t *homop, const uint64_t *homop_off, double *aux, const uint64_t *aux_off, double *cand,
+                   uint32_t *list, uint8_t *sel, double *feat, uint32_t *vtype, uint32_t *pos, uint32_t max_tmpl);
+size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d);
+void launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
+                 const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
+                 uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
+                 const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d);
+
+namespace {
+
+thread_local std::string g_last_error;
+thread_local jtk_lc_timing_t g_timing;
+
+int fail(int status, const std::string &msg) {
+    g_last_error = msg;
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(_e == hipErrorOutOfMemory ? JTK_ERR_ALLOC : JTK_ERR_NO_DEVICE,         \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+    } while (0)
+
+inline int base_code(uint8_t c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return -1;
+    }
+}
+
+HmmDev to_dev(const jtk_hmm_t &h) {
+    HmmDev d;
+    const double a[9] = {h.mat_mat, h.mat_ins, h.mat_del, h.ins_mat, h.ins_ins, h.ins_del, h.del_mat, h.del_ins, h.del_del};
+    memcpy(d.a, a, sizeof a);
+    memcpy(d.eM, h.mat_emit, sizeof d.eM);
+    memcpy(d.eI, h.ins_emit, sizeof d.eI);
+    return d;
+}
+
+struct DevPtr {
+    void *p = nullptr;
+    ~DevPtr() {
+        if (p) (void)hipFree(p);
+    }
+    template <typename T>
+    T *as() const {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
+struct KernelTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind = 0;
+};
+
+}  // namespace
+
+struct jtk_lc_session {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    jtk_lc_params_t params;
+    uint32_t n_chunks = 0, n_reads = 0, post_stride = 1;
+    uint32_t max_tmpl = 0, max_read = 0, max_n = 0, n_waves = 0;
+    uint64_t scratch_stride = 0;
+    bool features_only = false;
+    std::vector<ChunkMeta> h_chunks;
+    std::vector<ReadMeta> h_reads;
+    std::vector<ChunkState> h_state0;  // initial state (re-uploaded at every run)
+    std::vector<uint64_t> h_in_tmpl_off;
+    // device memory
+    DevPtr d_params, d_hmm2, d_chunks, d_reads, d_state, d_tmpl0, d_tmpl1, d_ops0, d_ops1, d_opslen0, d_opslen1,
+        d_ey, d_delta, d_scratch, d_raw, d_rawG, d_lk, d_table, d_total, d_edits, d_newlen, d_counter, d_nactive,
+        d_homop, d_homop_off, d_aux, d_aux_off, d_cand, d_list, d_sel, d_feat, d_vtype, d_pos, d_label, d_post,
+        d_lg, d_lg_off, d_vt_off, d_tmpl_init, d_ops_init, d_opslen_init;
+    size_t tmpl_bytes = 0, ops_bytes = 0;
+    DevBufs bufs;
+    std::vector<KernelTimer> timers;
+    ~jtk_lc_session() {
+        for (auto &t : timers) {
+            if (t.a) (void)hipEventDestroy(t.a);
+            if (t.b) (void)hipEventDestroy(t.b);
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(DevPtr &d, size_t count) {
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&d.p, bytes));
+    return 0;
+}
+template <typename T>
+int dev_upload(jtk_lc_session *s, DevPtr &d, const std::vector<T> &v) {
+    int rc = dev_alloc<T>(d, v.size());
+    if (rc) return rc;
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s->stream));
+    return 0;
+}
+
+int pick_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(JTK_ERR_NO_DEVICE, "no HIP device visible (jtk_lc has no CPU fallback)");
+    if (device < 0 || device >= count) return fail(JTK_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(JTK_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    return 0;
+}
+
+void tstart(jtk_lc_session *s, int kind) {
+    KernelTimer t;
+    t.kind = kind;
+    (void)hipEventCreate(&t.a);
+    (void)hipEventCreate(&t.b);
+    (void)hipEventRecord(t.a, s->stream);
+    s->timers.push_back(t);
+}
+void tstop(jtk_lc_session *s) { (void)hipEventRecord(s->timers.back().b, s->stream); }
+
+}  // namespace
+
+extern "C" {
+
+int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                          const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                          const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
+                          uint32_t post_stride, int device, jtk_lc_session_t **out) {
+    g_last_error.clear();
+    if (!params || !out || (n_chunks && (!chunks || !tmpl_bases || !read_bases || !read_off || !ops || !ops_off || !strand)))
+        return fail(JTK_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (post_stride == 0) return fail(JTK_ERR_INVALID_ARG, "post_stride must be >= 1");
+    if (params->gains.max_homopolymer_len == 0 || params->gains.max_homopolymer_len > JTK_GAINS_MAX_HOMOP)
+        return fail(JTK_ERR_INVALID_ARG, "gains.max_homopolymer_len out of range");
+    int rc = pick_device(device);
+    if (rc) return rc;
+    jtk_lc_session *s = new jtk_lc_session();
+    std::unique_ptr<jtk_lc_session> guard(s);
+    s->device = device;
+    s->params = *params;
+    s->post_stride = post_stride;
+    s->n_chunks = (uint32_t)n_chunks;
+    HIP_TRY(hipStreamCreate(&s->stream));
+
+    // ---- host-side layout + validation + encoding
+    uint64_t n_reads = 0;
+    for (size_t c = 0; c < n_chunks; c++) n_reads += chunks[c].n_reads;
+    s->n_reads = (uint32_t)n_reads;
+    s->h_chunks.resize(n_chunks);
+    s->h_reads.resize(n_reads);
+    s->h_state0.resize(n_chunks);
+    std::vector<uint8_t> h_tmpl, h_ops, h_ey;
+    std::vector<uint32_t> h_opslen(n_reads);
+    std::vector<uint64_t> h_homop_off(n_chunks), h_aux_off(n_chunks), h_lg_off(n_chunks);
+    uint64_t tmpl_off = 0, ops_cap_off = 0, ey_off = 0, delta_off = 0, table_off = 0, raw_off = 0, row_off = 0,
+             total_off = 0, edit_off = 0, feat_off = 0, cand_off = 0, aux_off = 0, lg_off = 0;
+    const uint32_t H = params->gains.max_homopolymer_len;
+    uint32_t rcount = 0;
+    for (size_t c = 0; c < n_chunks; c++) {
+        const jtk_lc_chunk_t &ch = chunks[c];
+        const uint32_t tl = (uint32_t)ch.tmpl_len;
+        if (ch.read_first != rcount) return fail(JTK_ERR_INVALID_ARG, "chunks must list their reads contiguously in order");
+        const uint32_t cap = tl + tl / 8 + 64;
+        ChunkMeta &cm = s->h_chunks[c];
+        memset(&cm, 0, sizeof cm);
+        cm.chunk_id = ch.chunk_id;
+        cm.copy_num = ch.copy_num;
+        cm.n_reads = ch.n_reads;
+        cm.read_first = rcount;
+        cm.tmpl_cap = cap;
+        cm.tmpl_off = tmpl_off;
+        cm.total_off = total_off;
+        const uint32_t band_width = (uint32_t)std::ceil((double)tl * params->band_frac);
+        cm.radius = band_width / 2;
+        cm.edit_cap = cap / 2 + 2;
+        cm.edit_off = edit_off;
+        cm.feat_off = feat_off;
+        cm.cand_off = cand_off;
+        // per_cluster_cov (mod.rs:108-111)
+        const double pcc = (double)ch.n_reads / (double)ch.copy_num;
+        cm.local_coverage = ch.copy_num <= 2 ? pcc : (pcc > params->haploid_coverage ? pcc : params->haploid_coverage);
+        ChunkState &st = s->h_state0[c];
+        memset(&st, 0, sizeof st);
+        st.tmpl_len = tl;
+        st.active = 1;
+        st.k = 1;
+        if (cm.radius > JTK_MAX_RADIUS || ch.copy_num > JTK_MAX_COPY) st.status = JTK_ERR_UNSUPPORTED;
+        h_tmpl.resize(tmpl_off + cap, 0);
+        for (uint32_t p = 0; p < tl; p++) {
+            const int code = base_code(tmpl_bases[ch.tmpl_off + p]);
+            if (code < 0) return fail(JTK_ERR_INVALID_ARG, "non-ACGT base in a template");
+            h_tmpl[tmpl_off + p] = (uint8_t)code;
+        }
+        h_homop_off[c] = tmpl_off;
+        h_aux_off[c] = aux_off;
+        h_lg_off[c] = lg_off;
+        for (uint32_t r = 0; r < ch.n_reads; r++) {
+            const uint64_t g = rcount + r;
+            const uint64_t rl = read_off[g + 1] - read_off[g], ol = ops_off[g + 1] - ops_off[g];
+            ReadMeta &rm = s->h_reads[g];
+            memset(&rm, 0, sizeof rm);
+            rm.chunk = (uint32_t)c;
+            rm.read_len = (uint32_t)rl;
+            rm.ey_off = ey_off;
+            rm.ops_off = ops_cap_off;
+            rm.ops_cap = (uint32_t)ol + tl / 8 + 64;
+            rm.strand = strand[g] ? 1 : 0;
+            rm.delta_off = delta_off;
+            rm.table_off = table_off;
+            rm.raw_off = raw_off;
+            rm.row_off = row_off;
+            h_ey.resize(ey_off + rl + 1, 0);
+            int prev = 4;
+            for (uint64_t j = 0; j < rl; j++) {
+                const int code = base_code(read_bases[read_off[g] + j]);
+                if (code < 0) return fail(JTK_ERR_INVALID_ARG, "non-ACGT base in a read");
+                h_ey[ey_off + j + 1] = (uint8_t)(code | (prev << 2));
+                prev = code;
+            }
+            h_ops.resize(ops_cap_off + rm.ops_cap, 0);
+            for (uint64_t k = 0; k < ol; k++) {
+                const uint8_t op = ops[ops_off[g] + k];
+                if (op > JTK_OP_DEL) return fail(JTK_ERR_INVALID_ARG, "bad op code");
+                h_ops[ops_cap_off + k] = op;
+            }
+            h_opslen[g] = (uint32_t)ol;
+            if (rl > s->max_read) s->max_read = (uint32_t)rl;
+            ey_off += rl + 1;
+            ops_cap_off += rm.ops_cap;
+            delta_off += ((uint64_t)(cap + rl) >> 6) + 3;
+            table_off += (uint64_t)JTK_NUM_ROW * (cap + 1);
+            raw_off += (uint64_t)JTK_ACC_N * (cap + 1);
+            row_off += cap + 1;
+        }
+        if (cap > s->max_tmpl) s->max_tmpl = cap;
+        if (ch.n_reads > s->max_n) s->max_n = ch.n_reads;
+        rcount += ch.n_reads;
+        tmpl_off += cap;
+        total_off += (uint64_t)JTK_NUM_ROW * (cap + 1);
+        cand_off += (uint64_t)JTK_NUM_ROW * (cap + 1);
+        edit_off += cm.edit_cap;
+        feat_off += (uint64_t)ch.n_reads * JTK_MAX_DIM;
+        aux_off += (uint64_t)3 * H * (ch.n_reads + 1) + (ch.n_reads + 1) + (JTK_MAX_COPY + 2);
+        lg_off += (uint64_t)ch.n_reads * (JTK_MAX_COPY + 1);
+    }
+    s->tmpl_bytes = h_tmpl.size();
+    s->ops_bytes = h_ops.size();
+
+    // ---- device allocation + upload
+    tstart(s, -1);
+    std::vector<jtk_lc_params_t> pv(1, *params);
+    std::vector<HmmDev> hv = {to_dev(params->forward), to_dev(params->reverse)};
+    if ((rc = dev_upload(s, s->d_params, pv))) return rc;
+    if ((rc = dev_upload(s, s->d_hmm2, hv))) return rc;
+    if ((rc = dev_upload(s, s->d_chunks, s->h_chunks))) return rc;
+    if ((rc = dev_upload(s, s->d_reads, s->h_reads))) return rc;
+    if ((rc = dev_alloc<ChunkState>(s->d_state, n_chunks))) return rc;
+    if ((rc = dev_upload(s, s->d_tmpl_init, h_tmpl))) return rc;
+    if ((rc = dev_upload(s, s->d_ops_init, h_ops))) return rc;
+    if ((rc = dev_upload(s, s->d_opslen_init, h_opslen))) return rc;
+    if ((rc = dev_alloc<uint8_t>(s->d_tmpl0, h_tmpl.size()))) return rc;
+    if ((rc = dev_alloc<uint8_t>(s->d_tmpl1, h_tmpl.size()))) return rc;
+    if ((rc = dev_alloc<uint8_t>(s->d_ops0, h_ops.size()))) return rc;
+    if ((rc = dev_alloc<uint8_t>(s->d_ops1, h_ops.size()))) return rc;
+    if ((rc = dev_alloc<uint32_t>(s->d_opslen0, n_reads))) return rc;
+    if ((rc = dev_alloc<uint32_t>(s->d_opslen1, n_reads))) return rc;
+    if ((rc = dev_upload(s, s->d_ey, h_ey))) return rc;
+    if ((rc = dev_alloc<uint64_t>(s->d_delta, delta_off))) return rc;
+    if ((rc = dev_alloc<double>(s->d_raw, raw_off))) return rc;
+    if ((rc = dev_alloc<int>(s->d_rawG, row_off))) return rc;
+    if ((rc = dev_alloc<double>(s->d_lk, n_reads))) return rc;
+    if ((rc = dev_alloc<double>(s->d_table, table_off))) return rc;
+    if ((rc = dev_alloc<double>(s->d_total, total_off))) return rc;
+    if ((rc = dev_alloc<Edit>(s->d_edits, edit_off))) return rc;
+    if ((rc = dev_alloc<uint32_t>(s->d_newlen, n_chunks))) return rc;
+    if ((rc = dev_alloc<uint32_t>(s->d_counter, 4))) return rc;
+    if ((rc = dev_alloc<uint32_t>(s->d_nactive, 4))) return rc;
+    if ((rc = dev_alloc<uint16_t>(s->d_homop, tmpl_off))) return rc;
+    if ((rc = dev_upload(s, s->d_homop_off, h_homop_off))) return rc;
+    if ((rc = dev_alloc<double>(s->d_aux, aux_off))) return rc;
+    if ((rc = dev_upload(s, s->d_aux_off, h_aux_off))) return rc;
+    if ((rc = dev_alloc<double>(s->d_cand, cand_off))) return rc;
+    if ((rc = dev_alloc<uint32_t>(s->d_list, cand_off))) return rc;
+    if ((rc = dev_alloc<uint8_t>(s->d_sel, cand_off))) return rc;
+    if ((rc = dev_alloc<double>(s->d_feat, feat_off))) return rc;
+    if ((rc = dev_alloc<uint32_t>(s->d_vtype, (uint64_t)2 * n_chunks * JTK_MAX_DIM))) return rc;
+    if ((rc = dev_alloc<uint32_t>(s->d_pos, (uint64_t)n_chunks * JTK_MAX_DIM))) return rc;
+    if ((rc = dev_alloc<uint32_t>(s->d_label, n_reads))) return rc;
+    if ((rc = dev_alloc<double>(s->d_post, (uint64_t)n_reads * post_stride))) return rc;
+    if ((rc = dev_alloc<double>(s->d_lg, lg_off))) return rc;
+    if ((rc = dev_upload(s, s->d_lg_off, h_lg_off))) return rc;
+    // forward scratch: one stripe per resident wave
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        const uint32_t want = (uint32_t)prop.multiProcessorCount * 8;
+        s->n_waves = n_reads < want ? (uint32_t)n_reads : want;
+        if (s->n_waves == 0) s->n_waves = 1;
+        s->scratch_stride = (uint64_t)(s->max_tmpl + s->max_read + 8) * 64 * 2;  // doubles
+        if ((rc = dev_alloc<double>(s->d_scratch, s->scratch_stride * s->n_waves))) return rc;
+    }
+    s->bufs.tmpl[0] = s->d_tmpl0.as<uint8_t>();
+    s->bufs.tmpl[1] = s->d_tmpl1.as<uint8_t>();
+    s->bufs.ops[0] = s->d_ops0.as<uint8_t>();
+    s->bufs.ops[1] = s->d_ops1.as<uint8_t>();
+    s->bufs.ops_len[0] = s->d_opslen0.as<uint32_t>();
+    s->bufs.ops_len[1] = s->d_opslen1.as<uint32_t>();
+    tstop(s);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, s->timers.back().a, s->timers.back().b);
+        memset(&g_timing, 0, sizeof g_timing);
+        g_timing.h2d_ms = ms;
+    }
+    const size_t lds = phmm_lds_bytes(s->max_tmpl, s->max_read);
+    if (lds > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "template + read too long for the LDS staging of phmm_kernel");
+    *out = guard.release();
+    return 0;
+}
+
+int jtk_lc_session_run(jtk_lc_session_t *s, int skip_polish) {
+    g_last_error.clear();
+    if (!s) return fail(JTK_ERR_INVALID_ARG, "null session");
+    HIP_TRY(hipSetDevice(s->device));
+    const double h2d = g_timing.h2d_ms;
+    memset(&g_timing, 0, sizeof g_timing);
+    g_timing.h2d_ms = h2d;
+    for (auto &t : s->timers) {
+        if (t.a) (void)hipEventDestroy(t.a);
+        if (t.b) (void)hipEventDestroy(t.b);
+    }
+    s->timers.clear();
+    hipStream_t st = s->stream;
+    const ReadMeta *reads = s->d_reads.as<ReadMeta>();
+    const ChunkMeta *chunks = s->d_chunks.as<ChunkMeta>();
+    ChunkState *state = s->d_state.as<ChunkState>();
+    const HmmDev *hmm2 = s->d_hmm2.as<HmmDev>();
+    hipEvent_t ev0, ev1;
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, st));
+    // reset the mutable state from the pristine copies (device-to-device; inputs stay resident)
+    HIP_TRY(hipMemcpyAsync(state, s->h_state0.data(), s->h_state0.size() * sizeof(ChunkState), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_tmpl0.p, s->d_tmpl_init.p, s->tmpl_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_ops0.p, s->d_ops_init.p, s->ops_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_opslen0.p, s->d_opslen_init.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToDevice, st));
+
+    tstart(s, JTK_K_POLISH);
+    launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 0);
+    tstop(s);
+    uint32_t n_active = s->n_chunks;
+    const int max_rounds = skip_polish ? 1 : JTK_POLISH_MAX_ROUNDS + 1;
+    for (int round = 0; round < max_rounds && n_active > 0; round++) {
+        const int only_active = round > 0;
+        const int final_pass = skip_polish || round == JTK_POLISH_MAX_ROUNDS;
+        tstart(s, JTK_K_PHMM);
+        launch_phmm(st, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(),
+                    hmm2, s->d_scratch.as<double>(), s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(),
+                    s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read,
+                    only_active);
+        launch_finalize(st, s->n_reads, reads, chunks, state, hmm2, s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                        s->d_lk.as<double>(), s->d_table.as<double>(), s->max_tmpl, only_active);
+        tstop(s);
+        tstart(s, JTK_K_POLISH);
+        launch_polish_round(st, s->n_chunks, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(),
+                            s->d_table.as<double>(), s->d_total.as<double>(), s->d_edits.as<Edit>(),
+                            s->d_newlen.as<uint32_t>(), s->max_tmpl, 3 /* HMMPolishConfig ignore_edge, mod.rs:105 */,
+                            final_pass, s->d_nactive.as<uint32_t>());
+        if (!final_pass)
+            launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 1);
+        tstop(s);
+        if (final_pass) break;
+        HIP_TRY(hipMemcpyAsync(&n_active, s->d_nactive.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    tstart(s, JTK_K_FILTER);
+    launch_filter(st, s->n_chunks, reads, chunks, state, s->bufs, s->d_params.as<jtk_lc_params_t>(),
+                  s->d_table.as<double>(), s->d_homop.as<uint16_t>(), s->d_homop_off.as<uint64_t>(),
+                  s->d_aux.as<double>(), s->d_aux_off.as<uint64_t>(), s->d_cand.as<double>(), s->d_list.as<uint32_t>(),
+                  s->d_sel.as<uint8_t>(), s->d_feat.as<double>(), s->d_vtype.as<uint32_t>(), s->d_pos.as<uint32_t>(),
+                  s->max_tmpl);
+    tstop(s);
+    tstart(s, JTK_K_MCMC);
+    launch_mcmc(st, s->n_chunks, chunks, state, s->d_params.as<jtk_lc_params_t>(), s->d_feat.as<double>(),
+                s->d_vtype.as<uint32_t>(), nullptr, 0, s->d_label.as<uint32_t>(), s->d_post.as<double>(),
+                s->post_stride, s->d_lg.as<double>(), s->d_lg_off.as<uint64_t>(), s->max_n, JTK_MAX_DIM);
+    tstop(s);
+    HIP_TRY(hipEventRecord(ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    g_timing.total_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    for (auto &t : s->timers) {
+        if (t.kind < 0 || t.kind >= JTK_K_COUNT) continue;
+        float k = 0;
+        (void)hipEventElapsedTime(&k, t.a, t.b);
+        g_timing.kernel_ms[t.kind] += k;
+        g_timing.kernel_launches[t.kind] += 1;
+    }
+    return 0;
+}
+
+int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post, jtk_lc_result_t *result,
+                         uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out,
+                         uint64_t *ops_out_off, uint64_t ops_cap) {
+    g_last_error.clear();
+    if (!s) return fail(JTK_ERR_INVALID_ARG, "null session");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = s->stream;
+    hipEvent_t ev0, ev1;
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, st));
+    std::vector<ChunkState> state(s->n_chunks);
+    HIP_TRY(hipMemcpyAsync(state.data(), s->d_state.p, state.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
+    if (label) HIP_TRY(hipMemcpyAsync(label, s->d_label.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToHost, st));
+    if (log_post)
+        HIP_TRY(hipMemcpyAsync(log_post, s->d_post.p, (size_t)s->n_reads * s->post_stride * 8, hipMemcpyDeviceToHost, st));
+    std::vector<uint8_t> t0, t1, o0, o1;
+    std::vector<uint32_t> l0, l1;
+    const bool want_cons = cons_out && cons_off, want_ops = ops_out && ops_out_off;
+    if (want_cons) {
+        t0.resize(s->tmpl_bytes);
+        t1.resize(s->tmpl_bytes);
+        HIP_TRY(hipMemcpyAsync(t0.data(), s->d_tmpl0.p, s->tmpl_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(t1.data(), s->d_tmpl1.p, s->tmpl_bytes, hipMemcpyDeviceToHost, st));
+    }
+    if (want_ops) {
+        o0.resize(s->ops_bytes);
+        o1.resize(s->ops_bytes);
+        l0.resize(s->n_reads);
+        l1.resize(s->n_reads);
+        HIP_TRY(hipMemcpyAsync(o0.data(), s->d_ops0.p, s->ops_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(o1.data(), s->d_ops1.p, s->ops_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(l0.data(), s->d_opslen0.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(l1.data(), s->d_opslen1.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipEventRecord(ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    g_timing.d2h_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    int any_fail = 0;
+    static const char BASES[] = "ACGT";
+    uint64_t co = 0, oo = 0;
+    for (uint32_t c = 0; c < s->n_chunks; c++) {
+        const ChunkState &cs = state[c];
+        const ChunkMeta &cm = s->h_chunks[c];
+        if (cs.status != 0) any_fail = 1;
+        if (result) {
+            result[c].score = cs.status == 0 ? cs.score : 0.0;
+            result[c].cluster_num = cs.status == 0 ? cs.k : 1;
+            result[c].status = cs.status;
+            result[c].polish_rounds = cs.rounds;
+            result[c].n_variants = cs.dim;
+        }
+        if (want_cons) {
+            cons_off[c] = co;
+            if (cs.status == 0) {
+                if (co + cs.tmpl_len > cons_cap) return fail(JTK_ERR_INVALID_ARG, "cons_cap too small");
+                const uint8_t *src = (cs.buf ? t1.data() : t0.data()) + cm.tmpl_off;
+                for (uint32_t p = 0; p < cs.tmpl_len; p++) cons_out[co + p] = (uint8_t)BASES[src[p] & 3];
+                co += cs.tmpl_len;
+            }
+        }
+        if (want_ops) {
+            for (uint32_t r = 0; r < cm.n_reads; r++) {
+                const uint32_t g = cm.read_first + r;
+                ops_out_off[g] = oo;
+                if (cs.status == 0) {
+                    const uint32_t len = cs.buf ? l1[g] : l0[g];
+                    if (oo + len > ops_cap) return fail(JTK_ERR_INVALID_ARG, "ops_cap too small");
+                    memcpy(ops_out + oo, (cs.buf ? o1.data() : o0.data()) + s->h_reads[g].ops_off, len);
+                    oo += len;
+                }
+                ops_out_off[g + 1] = oo;
+            }
+        }
+    }
+    if (want_cons) cons_off[s->n_chunks] = co;
+    return any_fail ? fail(JTK_ERR_CHUNK_FAILED, "at least one chunk failed; see result[].status") : 0;
+}
+
+int jtk_lc_session_destroy(jtk_lc_session_t *s) {
+    if (!s) return 0;
+    (void)hipSetDevice(s->device);
+    delete s;
+    return 0;
+}
+
+static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                    const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off, const uint8_t *ops,
+                    const uint64_t *ops_off, const uint8_t *strand, int skip_polish, uint32_t *label, double *log_post,
+                    uint32_t post_stride, jtk_lc_result_t *result, uint8_t *cons_out, uint64_t *cons_off,
+                    uint64_t cons_cap, uint8_t *ops_out, uint64_t *ops_out_off, uint64_t ops_cap, int device) {
+    jtk_lc_session_t *s = nullptr;
+    int rc = jtk_lc_session_create(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand,
+                                   post_stride, device, &s);
+    if (rc) return rc;
+    rc = jtk_lc_session_run(s, skip_polish);
+    if (rc == 0)
+        rc = jtk_lc_session_fetch(s, label, log_post, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap);
+    const std::string keep = g_last_error;
+    jtk_lc_session_destroy(s);
+    g_last_error = keep;
+    return rc;
+}
+
+int jtk_lc_cluster_chunks(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                          const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                          const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t *label,
+                          double *log_post, uint32_t post_stride, jtk_lc_result_t *result, uint8_t *cons_out,
+                          uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out, uint64_t *ops_out_off,
+                          uint64_t ops_cap, int device) {
+    return run_once(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, 0, label,
+                    log_post, post_stride, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap, device);
+}
+
+int jtk_lc_cluster_polished(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                            const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                            const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t *label,
+                            double *log_post, uint32_t post_stride, jtk_lc_result_t *result, int device) {
+    return run_once(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, 1, label,
+                    log_post, post_stride, result, nullptr, nullptr, 0, nullptr, nullptr, 0, device);
+}
+
+int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl, uint64_t tmpl_len,
+                              uint32_t n_reads, const uint8_t *read_bases, const uint64_t *read_off,
+                              const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, double *table,
+                              double *lk, int device) {
+    g_last_error.clear();
+    if (!table || !lk) return fail(JTK_ERR_INVALID_ARG, "null output");
+    jtk_lc_chunk_t ch;
+    memset(&ch, 0, sizeof ch);
+    ch.chunk_id = 0;
+    ch.copy_num = 2;
+    ch.n_reads = n_reads;
+    ch.tmpl_off = 0;
+    ch.tmpl_len = tmpl_len;
+    ch.read_first = 0;
+    jtk_lc_session_t *s = nullptr;
+    int rc = jtk_lc_session_create(params, 1, &ch, tmpl, read_bases, read_off, ops, ops_off, strand, 2, device, &s);
+    if (rc) return rc;
+    std::unique_ptr<jtk_lc_session> guard(s);
+    hipStream_t st = s->stream;
+    ChunkState *state = s->d_state.as<ChunkState>();
+    HIP_TRY(hipMemcpyAsync(state, s->h_state0.data(), sizeof(ChunkState), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_tmpl0.p, s->d_tmpl_init.p, s->tmpl_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_ops0.p, s->d_ops_init.p, s->ops_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_opslen0.p, s->d_opslen_init.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToDevice, st));
+    launch_band_prep(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
+                     s->d_delta.as<uint64_t>(), 0);
+    launch_phmm(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
+                s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(), s->d_scratch.as<double>(),
+                s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(), s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
+    launch_finalize(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state,
+                    s->d_hmm2.as<HmmDev>(), s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(),
+                    s->d_table.as<double>(), s->max_tmpl, 0);
+    ChunkState cs;
+    HIP_TRY(hipMemcpyAsync(&cs, state, sizeof cs, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(lk, s->d_lk.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, st));
+    const size_t cols = (size_t)JTK_NUM_ROW * (tmpl_len + 1);
+    for (uint32_t r = 0; r < n_reads; r++)
+        HIP_TRY(hipMemcpyAsync(table + (size_t)r * cols, s->d_table.as<double>() + s->h_reads[r].table_off, cols * 8,
+                               hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if (cs.status != 0) return fail(cs.status, "modification table failed (ops mismatch or unsupported band)");
+    return 0;
+}
+
+int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_feature_chunk_t *chunks,
+                            const double *variants, const uint32_t *variant_type, uint32_t *label, double *log_post,
+                            uint32_t post_stride, jtk_lc_result_t *result, int device) {
+    g_last_error.clear();
+    if (!params || (n_chunks && (!chunks || !variants || !variant_type || !label || !log_post || !result)))
+        return fail(JTK_ERR_INVALID_ARG, "null argument");
+    int rc = pick_device(device);
+    if (rc) return rc;
+    jtk_lc_session sess;
+    jtk_lc_session *s = &sess;
+    s->device = device;
+    HIP_TRY(hipStreamCreate(&s->stream));
+    std::vector<ChunkMeta> cms(n_chunks);
+    std::vector<ChunkState> sts(n_chunks);
+    std::vector<uint64_t> vt_off(n_chunks), lg_off(n_chunks);
+    uint64_t n_reads = 0, n_var = 0, n_vt = 0, lgo = 0;
+    uint32_t max_n = 1, max_d = 1;
+    for (size_t c = 0; c < n_chunks; c++) {
+        const jtk_lc_feature_chunk_t &fc = chunks[c];
+        if (fc.read_first != n_reads) return fail(JTK_ERR_INVALID_ARG, "chunks must list their reads contiguously in order");
+        memset(&cms[c], 0, sizeof(ChunkMeta));
+        memset(&sts[c], 0, sizeof(ChunkState));
+        cms[c].chunk_id = fc.chunk_id;
+        cms[c].copy_num = fc.copy_num;
+        cms[c].n_reads = fc.n_reads;
+        cms[c].read_first = (uint32_t)n_reads;
+        cms[c].feat_off = fc.var_off;
+        cms[c].local_coverage = fc.local_coverage;
+        sts[c].dim = fc.dim;
+        sts[c].k = 1;
+        if (fc.dim > JTK_MAX_DIM || fc.copy_num > JTK_MAX_COPY) sts[c].status = JTK_ERR_UNSUPPORTED;
+        vt_off[c] = fc.vt_off;
+        lg_off[c] = lgo;
+        lgo += (uint64_t)fc.n_reads * (JTK_MAX_COPY + 1);
+        n_reads += fc.n_reads;
+        if (fc.var_off + (uint64_t)fc.n_reads * fc.dim > n_var) n_var = fc.var_off + (uint64_t)fc.n_reads * fc.dim;
+        if (fc.vt_off + fc.dim > n_vt) n_vt = fc.vt_off + fc.dim;
+        if (fc.n_reads > max_n) max_n = fc.n_reads;
+        if (fc.dim > max_d) max_d = fc.dim;
+    }
+    std::vector<jtk_lc_params_t> pv(1, *params);
+    std::vector<double> varv(variants, variants + n_var);
+    std::vector<uint32_t> vtv(variant_type, variant_type + 2 * n_vt);
+    DevPtr d_params, d_chunks, d_state, d_var, d_vt, d_vtoff, d_label, d_post, d_lg, d_lgoff;
+    if ((rc = dev_upload(s, d_params, pv))) return rc;
+    if ((rc = dev_upload(s, d_chunks, cms))) return rc;
+    if ((rc = dev_upload(s, d_state, sts))) return rc;
+    if ((rc = dev_upload(s, d_var, varv))) return rc;
+    if ((rc = dev_upload(s, d_vt, vtv))) return rc;
+    if ((rc = dev_upload(s, d_vtoff, vt_off))) return rc;
+    if ((rc = dev_upload(s, d_lgoff, lg_off))) return rc;
+    if ((rc = dev_alloc<uint32_t>(d_label, n_reads))) return rc;
+    if ((rc = dev_alloc<double>(d_post, n_reads * post_stride))) return rc;
+    if ((rc = dev_alloc<double>(d_lg, lgo))) return rc;
+    if (mcmc_lds_bytes(max_n, max_d) > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "feature matrix too large for LDS");
+    hipEvent_t ev0, ev1;
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, s->stream));
+    launch_mcmc(s->stream, (uint32_t)n_chunks, d_chunks.as<ChunkMeta>(), d_state.as<ChunkState>(),
+                d_params.as<jtk_lc_params_t>(), d_var.as<double>(), d_vt.as<uint32_t>(), d_vtoff.as<uint64_t>(), 1,
+                d_label.as<uint32_t>(), d_post.as<double>(), post_stride, d_lg.as<double>(), d_lgoff.as<uint64_t>(),
+                max_n, max_d);
+    HIP_TRY(hipEventRecord(ev1, s->stream));
+    HIP_TRY(hipMemcpyAsync(sts.data(), d_state.p, sts.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(label, d_label.p, n_reads * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(log_post, d_post.p, n_reads * post_stride * 8, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    memset(&g_timing, 0, sizeof g_timing);
+    g_timing.total_ms = ms;
+    g_timing.kernel_ms[JTK_K_MCMC] = ms;
+    g_timing.kernel_launches[JTK_K_MCMC] = 1;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    int any_fail = 0;
+    for (size_t c = 0; c < n_chunks; c++) {
+        result[c].score = sts[c].status == 0 ? sts[c].score : 0.0;
+        result[c].cluster_num = sts[c].status == 0 ? sts[c].k : 1;
+        result[c].status = sts[c].status;
+        result[c].polish_rounds = 0;
+        result[c].n_variants = sts[c].dim;
+        if (sts[c].status != 0) any_fail = 1;
+    }
+    return any_fail ? fail(JTK_ERR_CHUNK_FAILED, "at least one chunk failed; see result[].status") : 0;
+}
+
+const char *jtk_lc_last_error(void) { return g_last_error.c_str(); }
+
+int jtk_lc_last_timing(jtk_lc_timing_t *out) {
+    if (!out) return JTK_ERR_INVALID_ARG;
+    *out = g_timing;
+    return 0;
+}
+
+int jtk_lc_device_ok(int device) {
+    const std::string keep = g_last_error;
+    const int rc = pick_device(device);
+    g_last_error = keep;
+    return rc == 0 ? 1 : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,201 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+Bar (BASELINE.json north_star): integer cluster assignments bit-exact, per-read log-posteriors within 1e-4;
+this build additionally expects the f64 results to be bit-identical because both sides share the
+arithmetic specification."""
+import numpy as np
+import pytest
+
+import helpers
+import oracle_ffi as O
+from jtk_amd import api, batch as jb, ffi, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4   # north_star tolerance for log-likelihoods / log-posteriors
+
+
+@pytest.fixture(scope="module")
+def lib(jtk_lib):
+    assert jtk_lib.jtk_lc_device_ok(0) == 1, "needs a gfx950 device"
+    return jtk_lib
+
+
+def oracle_table(p, b, c):
+    po = helpers.oracle_params(p)
+    Lo = O.lib()
+    reads = list(b.chunk_reads(c))
+    t = b.template(c)
+    n = len(reads)
+    cols = ffi.NUM_ROW * (len(t) + 1)
+    rb = np.concatenate([b.read(r) for r in reads])
+    ob = np.concatenate([b.read_ops(r) for r in reads])
+    ro = np.zeros(n + 1, np.uint64)
+    oo = np.zeros(n + 1, np.uint64)
+    ro[1:] = np.cumsum([len(b.read(r)) for r in reads])
+    oo[1:] = np.cumsum([len(b.read_ops(r)) for r in reads])
+    st = b.strand[reads[0]:reads[-1] + 1].copy()
+    table = np.zeros((n, cols))
+    lk = np.zeros(n)
+    import ctypes as C
+    Lo.jo_modification_table(C.byref(po), O.u8p(t), len(t), n, O.u8p(rb), O.u64p(ro), O.u8p(ob), O.u64p(oo),
+                             O.u8p(st), O.f64p(table), O.f64p(lk))
+    return table, lk
+
+
+@pytest.mark.parametrize("tmpl_len,config", [(300, "ont_diploid"), (2000, "ont_diploid"), (700, "ont_noisy"),
+                                             (2000, "hifi_diploid")])
+def test_modification_table_matches_oracle(lib, tmpl_len, config):
+    b, cfg, p = helpers.small_batch(config=config, n_chunks=1, tmpl_len=tmpl_len, reads_per_hap=4)
+    reads = list(b.chunk_reads(0))
+    tab, lk = api.modification_table(p, b.template(0), [b.read(r) for r in reads], [b.read_ops(r) for r in reads],
+                                     [b.strand[r] for r in reads])
+    otab, olk = oracle_table(p, b, 0)
+    assert np.abs(lk - olk).max() < TOL
+    finite = otab > -1e299
+    assert np.array_equal(finite, tab > -1e299)
+    assert np.abs(tab[finite] - otab[finite]).max() < TOL
+    # this build's stronger property: identical bits
+    assert np.array_equal(helpers.bits(lk), helpers.bits(olk))
+    assert np.array_equal(helpers.bits(tab), helpers.bits(otab))
+
+
+def test_modification_table_rejects_inconsistent_ops(lib):
+    b, cfg, p = helpers.small_batch(n_chunks=1, tmpl_len=200, reads_per_hap=2)
+    reads = list(b.chunk_reads(0))
+    ops = [b.read_ops(r).copy() for r in reads]
+    ops[1] = ops[1][:-3]
+    with pytest.raises(ffi.JtkError) as e:
+        api.modification_table(p, b.template(0), [b.read(r) for r in reads], ops, [1, 1, 1, 1])
+    assert e.value.status == -5
+
+
+def random_feature_problem(rng, n, dim, k_true, cid, copy_num):
+    """feature matrix shaped like search_variants output: +gain for carriers, -gain otherwise, some zeros"""
+    lab = rng.integers(0, k_true, n)
+    owner = rng.integers(0, k_true, dim)
+    x = np.where(lab[:, None] == owner[None, :], rng.normal(4.5, 0.8, (n, dim)), rng.normal(-4.5, 0.8, (n, dim)))
+    x[rng.random((n, dim)) < 0.08] = 0.0
+    x[rng.random((n, dim)) < 0.03] *= -1
+    vt = np.stack([rng.integers(1, 4, dim), rng.integers(0, 3, dim)], axis=1).astype(np.uint32)
+    return x, vt, lab
+
+
+def run_features_both(p, specs, seed):
+    rng = np.random.default_rng(seed)
+    chunks = np.zeros(len(specs), dtype=ffi.FEATURE_CHUNK_DT)
+    var, vts, truth = [], [], []
+    voff = vtoff = rfirst = 0
+    for i, (n, dim, k_true, copy_num) in enumerate(specs):
+        x, vt, lab = random_feature_problem(rng, n, dim, k_true, i, copy_num)
+        chunks[i] = (1000 + 17 * i, copy_num, n, dim, 0, voff, vtoff, rfirst, n / copy_num)
+        var.append(x.ravel())
+        vts.append(vt.ravel())
+        truth.append(lab)
+        voff += n * dim
+        vtoff += dim
+        rfirst += n
+    var = np.concatenate(var)
+    vts = np.concatenate(vts).astype(np.uint32)
+    stride = max(s[3] for s in specs)
+    dev = api.cluster_features(p, chunks, var, vts, stride)
+    import ctypes as C
+    po = helpers.oracle_params(p)
+    lab = np.zeros(rfirst, np.uint32)
+    post = np.zeros((rfirst, stride))
+    res = np.zeros(len(specs), dtype=ffi.RESULT_DT)
+    rc = O.lib().jo_cluster_features(C.byref(po), len(specs), chunks.ctypes.data, O.f64p(var), O.u32p(vts),
+                                     O.u32p(lab), O.f64p(post), stride, res.ctypes.data, 0)
+    assert rc == 0
+    return dev, dict(label=lab, log_post=post, result=res), truth
+
+
+def test_cluster_features_matches_oracle(lib):
+    p = jb.default_params(haploid_coverage=12.0)
+    specs = [(24, 3, 2, 2), (24, 6, 2, 2), (30, 1, 2, 2), (36, 5, 3, 3), (40, 6, 3, 4), (20, 4, 1, 2),
+             (6, 3, 2, 2), (2, 2, 2, 2), (25, 0, 2, 2), (20, 3, 2, 1)]
+    dev, ora, truth = run_features_both(p, specs, seed=1)
+    assert np.array_equal(dev["label"], ora["label"])
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert np.abs(dev["log_post"] - ora["log_post"]).max() < TOL
+    assert np.abs(dev["result"]["score"] - ora["result"]["score"]).max() < TOL
+    assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(ora["log_post"]))
+    assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(ora["result"]["score"]))
+    # rows of the posterior logsumexp to 0 (mod.rs:184-185 invariant)
+    off = 0
+    for (n, dim, kt, cn), k in zip(specs, dev["result"]["cluster_num"]):
+        rows = dev["log_post"][off:off + n, :k]
+        assert np.abs(np.log(np.exp(rows).sum(axis=1))).max() < 1e-9
+        off += n
+    # sanity: the clean 2-cluster problems are recovered
+    assert helpers.same_partition(dev["label"][:24], truth[0]) or (dev["label"][:24] == truth[0]).mean() > 0.9
+
+
+def test_cluster_polished_matches_oracle(lib):
+    b, cfg, p = helpers.small_batch(n_chunks=4, tmpl_len=500, reads_per_hap=10)
+    dev = api.cluster_polished(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=True)
+    assert ora["rc"] == 0
+    assert np.array_equal(dev["result"]["n_variants"], ora["result"]["n_variants"])
+    assert np.array_equal(dev["label"], ora["label"])
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert np.abs(dev["log_post"] - ora["log_post"]).max() < TOL
+    assert np.abs(dev["result"]["score"] - ora["result"]["score"]).max() < TOL
+
+
+@pytest.mark.parametrize("config,tmpl_len,rph,nch", [("ont_diploid", 500, 10, 4), ("ont_diploid", 2000, 30, 2),
+                                                     ("ont_4copy", 600, 8, 2), ("hifi_diploid", 800, 10, 2)])
+def test_cluster_chunks_matches_oracle(lib, config, tmpl_len, rph, nch):
+    b, cfg, p = helpers.small_batch(config=config, n_chunks=nch, tmpl_len=tmpl_len, reads_per_hap=rph)
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
+    assert ora["rc"] == 0
+    assert np.array_equal(dev["result"]["polish_rounds"], ora["result"]["polish_rounds"])
+    assert np.array_equal(dev["cons_off"], ora["cons_off"])
+    n = int(dev["cons_off"][-1])
+    assert bytes(dev["cons"][:n]) == bytes(ora["cons"][:n])
+    assert np.array_equal(dev["ops_out_off"], ora["ops_out_off"])
+    m = int(dev["ops_out_off"][-1])
+    assert np.array_equal(dev["ops_out"][:m], ora["ops_out"][:m])
+    assert np.array_equal(dev["result"]["n_variants"], ora["result"]["n_variants"])
+    assert np.array_equal(dev["label"], ora["label"])                       # bit-exact integer labels
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert np.abs(dev["log_post"] - ora["log_post"]).max() < TOL            # north_star tolerance
+    assert np.abs(dev["result"]["score"] - ora["result"]["score"]).max() < TOL
+    for c in range(b.n_chunks):
+        k = int(dev["result"][c]["cluster_num"])
+        rows = dev["log_post"][list(b.chunk_reads(c))][:, :k]
+        assert np.abs(np.log(np.exp(rows).sum(axis=1))).max() < 1e-4       # mod.rs:184-185
+
+
+def test_edge_cases(lib):
+    """empty batch, empty pile-up, copy_num 0/1, a pile-up smaller than its copy number"""
+    p = jb.default_params(haploid_coverage=5.0)
+    empty = jb.pack([])
+    out = api.cluster_chunks(p, empty)
+    assert len(out["label"]) == 0
+    b, cfg, _ = helpers.small_batch(n_chunks=3, tmpl_len=300, reads_per_hap=3)
+    b.chunks["copy_num"][0] = 1
+    b.chunks["copy_num"][1] = 6       # n = 6 <= copy_num -> trivial (pseudo_mcmc.rs:221)
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b)
+    assert np.array_equal(dev["label"], ora["label"])
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert dev["result"]["cluster_num"][0] == 1 and dev["result"]["cluster_num"][1] == 1
+    assert np.abs(dev["log_post"] - ora["log_post"]).max() < TOL
+    # copy_num >= 8 is reported, not silently mis-handled
+    b.chunks["copy_num"][2] = 8
+    out = api.cluster_chunks(p, b, raise_on_chunk_failure=False)
+    assert out["rc"] == -6 and out["result"]["status"][2] == -3
+
+
+def test_session_is_repeatable_and_matches_one_shot(lib):
+    b, cfg, p = helpers.small_batch(n_chunks=3, tmpl_len=400, reads_per_hap=8)
+    one = api.cluster_chunks(p, b)
+    with api.Session(p, b) as s:
+        s.run()
+        a = s.fetch()
+        s.run()
+        c = s.fetch()
+    for k in ("label", "log_post", "cons", "ops_out"):
+        assert np.array_equal(a[k], c[k]) and np.array_equal(a[k], one[k])
+    t = api.last_timing()
+    assert t["kernel_launches"]["phmm"] >= 1
