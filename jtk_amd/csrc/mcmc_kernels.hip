@@ -9,12 +9,23 @@
 // with the rand 0.8.5 / rand_xoshiro 0.6.0 sampling restated exactly as in oracle/rng.c.
 //
 // The chain is strictly sequential per chunk (one RNG stream threads through k-means, 20 restarts and every
-// candidate k, local_clustering/mod.rs:97), so the parallelism is: chunks across wavefronts, and inside a
-// step the D variant columns across lanes.  Lane d keeps LKCount[c][d] for every cluster c in registers
-// (K is a template parameter so the cluster index is a static register index); the RNG state and the
-// cluster sizes are wave-uniform.  Sums that the reference evaluates left to right are evaluated left to
-// right here (serial chains over LDS broadcast reads) -- integer labels only match if every f64 rounding
-// matches.
+// candidate k, local_clustering/mod.rs:97).  A lone wavefront on CDNA4 issues roughly one dependent
+// instruction every 5-7 cycles, so the chain is bound by the instruction count of a step, not by bandwidth.
+// Two things buy speed without changing a single bit of the result:
+//  * PIPELINE: a workgroup is two wavefronts.  Wave 1 ("producer") parses the xoshiro stream into
+//    proposals -- read index, position of the chosen candidate cluster, the u64 the Bernoulli test will
+//    compare, and a snapshot of the generator state -- and hands them to wave 0 ("consumer") through an LDS
+//    ring.  Which draws a proposal consumes does not depend on the chain state, except that an improving
+//    proposal skips the Bernoulli draw (pseudo_mcmc.rs:736); that happens in <2% of the steps, and the
+//    consumer then re-synchronises the producer from the snapshot.
+//  * A SLIM STEP: lane d keeps LKCount[c][d] of every cluster c in registers (K is a template parameter, so
+//    the cluster index is a static register index); counts are kept as integers (num_pos and 3*num_pos -
+//    7*num_neg, which decides is_informative exactly); a proposal is evaluated on tentative values and then
+//    committed or undone with the reference's own arithmetic ((tg - x) + x, not a restore); labels, cluster
+//    sizes and the >0 masks are wave-uniform scalars; the left-to-right sum of get_lk visits only the non-zero
+//    terms (ballot + v_readlane).
+// Sums that the reference evaluates left to right are evaluated left to right here -- integer labels only
+// match if every f64 rounding matches.
 #include "device_common.h"
 
 namespace {
@@ -31,7 +42,8 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t &x) {
     return z ^ (z >> 31);
 }
 __device__ __forceinline__ uint64_t next_u64(Rng &r) {
-    const uint64_t result = rotl64(r.s1 * 5, 7) * 9;
+    const uint64_t m5 = (r.s1 << 2) + r.s1, rr = rotl64(m5, 7);
+    const uint64_t result = (rr << 3) + rr;  // rotl(s1 * 5, 7) * 9
     const uint64_t t = r.s1 << 17;
     r.s2 ^= r.s0;
     r.s3 ^= r.s1;
@@ -77,10 +89,43 @@ __device__ __forceinline__ uint32_t choose_other(Rng &r, uint32_t k, uint32_t ol
     return result;
 }
 
+// Only wave 0 runs the non-chain phases, so LDS hand-offs between its lanes need a wave-level fence, not a
+// workgroup barrier (the producer wave is parked at a real barrier meanwhile).
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
+__device__ __forceinline__ double unif64(double v) { return jtk_bits_f64(uni64(jtk_f64_bits(v))); }
+// a wave-uniform condition as a scalar: branches on it are s_cbranch, not exec-mask regions
+__device__ __forceinline__ bool ubool(bool c) { return uni(c ? 1u : 0u) != 0u; }
 
 // LDS work area of one chunk
+struct Elem {  // one (read, column) cell as the chain needs it
+    double x;  // the likelihood gain
+    int dp;    // 1 if x >  POS_THR (counts towards num_pos)
+    int pw;    // 3*[x > POS_THR] - 7*[x < -POS_THR]: increment of 3*num_pos - 7*num_neg
+};
+#define QN 64
+struct QEntry {  // 64 B
+    uint32_t gen, seq;  // tag, written last
+    uint32_t idx, j;    // proposed read; position of the chosen cluster among the K-1 candidates
+    uint64_t v;         // the u64 a Bernoulli draw of this step compares
+    uint64_t pad;
+    uint64_t s[4];      // generator state after the proposal draws, before v
+};
+struct QCtl {  // 64 B
+    uint32_t gen, stop, consumed, quit;
+    uint32_t restart_seq, n, k, pad;
+    uint64_t restart_state[4];
+};
 struct Lds {
+    QCtl *ctl;
+    QEntry *queue;
+    Elem *elem;          // n x D
     double *data;        // n x D
     double *size_to_lk;  // n + 1
     double *lfact;       // n + 1
@@ -88,7 +133,6 @@ struct Lds {
     double *centers;     // K x D
     double *fbuf;        // n (dists / weights / per-read gains)
     double *cum;         // n
-    uint8_t *thr;        // n + 1 : min num_pos that makes a column informative at num_pos+num_neg = s
     uint8_t *assign;     // n   current labels
     uint8_t *argmax;     // n   best labels seen in this chain
     uint8_t *best;       // n   best over restarts for this k
@@ -100,7 +144,7 @@ struct Lds {
 };
 
 // slice.choose_weighted over weights w[0..n) in LDS; cum is scratch. Returns -1 on WeightedError.
-__device__ int choose_weighted(Rng &r, const double *w, uint32_t n, double *cum, uint32_t lane) {
+__device__ __forceinline__ int choose_weighted(Rng &r, const double *w, uint32_t n, double *cum, uint32_t lane) {
     double total = w[0];
     if (!(total >= 0.0)) return -1;
     bool bad = false;
@@ -116,12 +160,12 @@ __device__ int choose_weighted(Rng &r, const double *w, uint32_t n, double *cum,
     while (scale * max_rand + 0.0 >= total) scale = jtk_bits_f64(jtk_f64_bits(scale) - 1);
     const double v12 = jtk_bits_f64((next_u64(r) >> 12) | 0x3ff0000000000000ULL);
     const double chosen = (v12 - 1.0) * scale + 0.0;
-    __syncthreads();
+    wsync();
     // partition point of `cum[i] <= chosen` (cum is non-decreasing): count the entries <= chosen
     uint32_t cnt = 0;
     for (uint32_t i = lane; i + 1 < n; i += 64) cnt += cum[i] <= chosen ? 1u : 0u;
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    __syncthreads();
+    wsync();
     return (int)cnt;
 }
 
@@ -135,7 +179,7 @@ __device__ __forceinline__ double dist_row(const double *a, const double *b, uin
 }
 
 // misc.rs:261-276 with centres given as K rows of D doubles in LDS (first minimum wins)
-__device__ void update_assignments(const Lds &m, uint32_t n, uint32_t D, uint32_t k, const double *centers,
+__device__ __forceinline__ void update_assignments(const Lds &m, uint32_t n, uint32_t D, uint32_t k, const double *centers,
                                    uint8_t *assign, uint32_t lane) {
     for (uint32_t i = lane; i < n; i += 64) {
         uint32_t best = 0;
@@ -149,28 +193,28 @@ __device__ void update_assignments(const Lds &m, uint32_t n, uint32_t D, uint32_
         }
         assign[i] = (uint8_t)best;
     }
-    __syncthreads();
+    wsync();
 }
 
 // misc.rs:298-307: sum over reads, in read order, of dist(read, its centre)
-__device__ double get_dist(const Lds &m, uint32_t n, uint32_t D, const uint8_t *assign, uint32_t lane) {
+__device__ __forceinline__ double get_dist(const Lds &m, uint32_t n, uint32_t D, const uint8_t *assign, uint32_t lane) {
     for (uint32_t i = lane; i < n; i += 64) m.fbuf[i] = dist_row(m.data + i * D, m.centers + assign[i] * D, D);
-    __syncthreads();
+    wsync();
     double s = 0.0;
     for (uint32_t i = 0; i < n; i++) s += m.fbuf[i];
-    __syncthreads();
+    wsync();
     return s;
 }
 
 // misc.rs:229-259; returns false where the reference would panic
-__device__ bool kmeans(const Lds &m, uint32_t n, uint32_t D, uint32_t k, Rng &rng, uint32_t lane) {
+__device__ __forceinline__ bool kmeans(const Lds &m, uint32_t n, uint32_t D, uint32_t k, Rng &rng, uint32_t lane) {
     const double UPDATE_THR = 0.00000001;
     if (gen_bool(rng, 0.5)) {
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t c = (uint32_t)gen_range_usize(rng, k);
             if (lane == 0) m.assign[i] = (uint8_t)c;
         }
-        __syncthreads();
+        wsync();
     } else {
         // suggest_first (misc.rs:315-341): centre rows are borrowed data rows; keep their indices in cum's tail
         uint32_t centre_idx[JTK_MAX_COPY];
@@ -185,19 +229,19 @@ __device__ bool kmeans(const Lds &m, uint32_t n, uint32_t D, uint32_t k, Rng &rn
                 }
                 m.fbuf[i] = mn;
             }
-            __syncthreads();
+            wsync();
             const int idx = choose_weighted(rng, m.fbuf, n, m.cum, lane);
             if (idx < 0) return false;
             centre_idx[nc++] = (uint32_t)idx;
         }
         for (uint32_t c = 0; c < k; c++)
             for (uint32_t d = lane; d < D; d += 64) m.centers[c * D + d] = m.data[centre_idx[c] * D + d];
-        __syncthreads();
+        wsync();
         update_assignments(m, n, D, k, m.centers, m.assign, lane);
     }
     // Lloyd iterations; `dist` is first evaluated against all-zero centres
     for (uint32_t e = lane; e < k * D; e += 64) m.centers[e] = 0.0;
-    __syncthreads();
+    wsync();
     double dist = get_dist(m, n, D, m.assign, lane);
     for (;;) {
         // update_centers (misc.rs:277-297): per (cluster, column) slot, sum in read order
@@ -212,7 +256,7 @@ __device__ bool kmeans(const Lds &m, uint32_t n, uint32_t D, uint32_t k, Rng &rn
                 }
             m.centers[e] = cnt > 0 ? s / (double)cnt : s;
         }
-        __syncthreads();
+        wsync();
         update_assignments(m, n, D, k, m.centers, m.assign, lane);
         const double nd = get_dist(m, n, D, m.assign, lane);
         if (!(nd < dist + UPDATE_THR)) return false;  // assert!(new_dist < dist + UPDATE_THR)
@@ -254,16 +298,18 @@ __device__ __forceinline__ void lk_sub(Counts<K> &q, uint32_t c, double x) {
         }
 }
 
-// get_used_columns (:847-869) for this lane's column
+// get_used_columns (:847-869) for this lane's column.
+// LKCount::is_informative (:818-822) is `0 < total_gain && 0.70 < num_pos / (num_pos + num_neg + 1e-7)`; for
+// integer counts the f64 quotient test is exactly `3*num_pos > 7*num_neg` (no count pair comes within 1e-10 of
+// the threshold; tests/test_host_and_abi.py checks every pair up to 2000 against the f64 expression).
 template <int K>
-__device__ __forceinline__ bool column_used(const Counts<K> &q, const uint8_t *thr) {
+__device__ __forceinline__ bool column_used(const Counts<K> &q) {
     bool any = false;
     int in_use = 0, in_neg = 0;
 #pragma unroll
     for (int c = 0; c < K; c++) {
         const bool pos = 0.0 < q.tg[c];
-        // is_informative: 0 < total_gain && 0.70 < num_pos / (num_pos + num_neg + 1e-7)
-        any |= pos && q.np[c] >= (int)thr[q.np[c] + q.nn[c]];
+        any |= pos && 3 * q.np[c] > 7 * q.nn[c];
         in_use += pos ? q.np[c] : 0;
         in_neg += pos ? 0 : q.np[c];
     }
@@ -290,96 +336,572 @@ __device__ __forceinline__ void fill_counts(const Lds &m, uint32_t n, uint32_t D
     }
 }
 
-// get_lk (:785-795): size terms first, then clusters outer / columns inner, left to right
-template <int K>
-__device__ __forceinline__ double get_lk(const Lds &m, const Counts<K> &q, const int *clusters, uint32_t D,
-                                         uint32_t lane) {
-    const bool used = lane < D && column_used<K>(q, m.thr);
-#pragma unroll
-    for (int c = 0; c < K; c++)
-        if (lane < D) m.val[c * D + lane] = used ? jtk_fmax(q.tg[c], 0.0) : 0.0;
-    __syncthreads();
-    double lk = 0.0;
-#pragma unroll
-    for (int c = 0; c < K; c++) lk += m.size_to_lk[clusters[c]];
-    const uint32_t tot = K * D;
-    for (uint32_t s = 0; s < tot; s++) lk += m.val[s];
-    __syncthreads();
-    return lk;
+__device__ __forceinline__ double readlane_f64(double v, uint32_t l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), (int)l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), (int)l);
+    return __hiloint2double(hi, lo);
 }
 
-template <int K>
-__device__ __forceinline__ void flip(const Lds &m, Counts<K> &q, int *clusters, uint32_t D, uint32_t idx,
-                                     uint32_t from, uint32_t to, uint32_t lane) {
-    const double x = lane < D ? m.data[idx * D + lane] : 0.0;
-    lk_sub<K>(q, from, x);
-    lk_add<K>(q, to, x);
-#pragma unroll
-    for (int cc = 0; cc < K; cc++) {
-        if ((uint32_t)cc == from) clusters[cc]--;
-        if ((uint32_t)cc == to) clusters[cc]++;
+// Per-read values spread over lanes: element i lives in lane i & 63 of register i >> 6 (n <= 255).
+// SMALL (n <= 63): everything sits in register 0 and the lookups are branch-free.
+struct LaneTab {
+    double v[4];
+};
+template <bool SMALL>
+__device__ __forceinline__ double tab_get(const LaneTab &t, uint32_t i) {
+    if (SMALL) return readlane_f64(t.v[0], i);
+    const uint32_t l = i & 63;
+    switch (i >> 6) {
+        case 0: return readlane_f64(t.v[0], l);
+        case 1: return readlane_f64(t.v[1], l);
+        case 2: return readlane_f64(t.v[2], l);
+        default: return readlane_f64(t.v[3], l);
     }
-    if (lane == 0) m.assign[idx] = (uint8_t)to;
+}
+struct LaneLabels {
+    int v[4];
+};
+template <bool SMALL>
+__device__ __forceinline__ uint32_t lab_get(const LaneLabels &a, uint32_t i) {
+    if (SMALL) return (uint32_t)__builtin_amdgcn_readlane(a.v[0], (int)i);
+    const int l = (int)(i & 63);
+    switch (i >> 6) {
+        case 0: return (uint32_t)__builtin_amdgcn_readlane(a.v[0], l);
+        case 1: return (uint32_t)__builtin_amdgcn_readlane(a.v[1], l);
+        case 2: return (uint32_t)__builtin_amdgcn_readlane(a.v[2], l);
+        default: return (uint32_t)__builtin_amdgcn_readlane(a.v[3], l);
+    }
+}
+template <bool SMALL>
+__device__ __forceinline__ void lab_set(LaneLabels &a, uint32_t i, uint32_t val, uint32_t lane) {
+    const bool mine = lane == (i & 63);
+    if (SMALL) {
+        a.v[0] = mine ? (int)val : a.v[0];
+        return;
+    }
+    switch (i >> 6) {
+        case 0: a.v[0] = mine ? (int)val : a.v[0]; break;
+        case 1: a.v[1] = mine ? (int)val : a.v[1]; break;
+        case 2: a.v[2] = mine ? (int)val : a.v[2]; break;
+        default: a.v[3] = mine ? (int)val : a.v[3]; break;
+    }
+}
+
+// ---- LDS accessors for the producer/consumer hand-off.  The pointers reach us as generic pointers (members of
+// struct Lds); casting them back to the LDS address space makes these ds_read/ds_write instead of waited flat
+// accesses.  volatile: re-read every time, in program order (LDS operations of one wave execute in order).
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+typedef __attribute__((address_space(3))) volatile uint64_t lds_vu64;
+__device__ __forceinline__ uint32_t lds_ld32(const uint32_t *p) { return *(lds_vu32 *)p; }
+__device__ __forceinline__ void lds_st32(uint32_t *p, uint32_t v) { *(lds_vu32 *)p = v; }
+__device__ __forceinline__ uint64_t lds_ld64(const uint64_t *p) { return *(lds_vu64 *)p; }
+__device__ __forceinline__ void lds_st64(uint64_t *p, uint64_t v) { *(lds_vu64 *)p = v; }
+
+// Position (0-based among the K-1 candidates) that `(0..K).filter(|c| c != old).choose(rng)` selects
+// (pseudo_mcmc.rs:732): the i-th yielded candidate replaces the pick iff gen_index(i) == 0, whatever `old` is.
+__device__ __forceinline__ uint32_t choose_pos(Rng &r, uint32_t k) {
+    uint32_t pos = 0;
+    for (uint32_t i = 1; i < k; i++)
+        if (gen_index(r, i) == 0) pos = i - 1;
+    return pos;
+}
+
+// The producer wave: turns the generator stream into proposals, assuming every step draws its Bernoulli
+// value; re-synchronised by the consumer (ctl->gen) whenever a step did not.  A lone wave issues about one
+// instruction per 4-5 cycles, so this loop is written for instruction count: the control block is read with
+// one 128-bit LDS load per iteration (issued before the draws, looked at after them), an entry is four
+// 128-bit stores, the tag-carrying one last (LDS operations of a wave complete in order).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) volatile u32x4 lds_vu128;
+__device__ __forceinline__ void producer_main(QCtl *ctl, QEntry *queue, uint32_t lane) {
+    for (;;) {
+        __syncthreads();  // A: a chain has been armed (or the kernel is done)
+        if (uni(lds_ld32(&ctl->quit))) return;
+        const uint32_t n = uni(lds_ld32(&ctl->n)), k = uni(lds_ld32(&ctl->k));
+        Rng r;
+        r.s0 = r.s1 = r.s2 = r.s3 = 0;
+        uint32_t seq = 0, gen_seen = 0xffffffffu;
+        for (;;) {
+            const u32x4 c = *(lds_vu128 *)ctl;  // gen, stop, consumed, quit
+            const uint32_t g = uni(c.x);
+            if (uni(c.y)) break;
+            if (g != gen_seen) {
+                r.s0 = uni64(lds_ld64(&ctl->restart_state[0]));
+                r.s1 = uni64(lds_ld64(&ctl->restart_state[1]));
+                r.s2 = uni64(lds_ld64(&ctl->restart_state[2]));
+                r.s3 = uni64(lds_ld64(&ctl->restart_state[3]));
+                seq = uni(lds_ld32(&ctl->restart_seq));
+                // the restart record is only stable if gen did not move while we read it
+                if (uni(lds_ld32(&ctl->gen)) != g) continue;
+                gen_seen = g;
+            }
+            if ((int32_t)(seq - uni(c.z)) >= QN) {
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            const uint32_t idx = (uint32_t)gen_range_usize(r, n);
+            const uint32_t pos = choose_pos(r, k);
+            const Rng snap = r;
+            const uint64_t v = next_u64(r);
+            lds_vu128 *e = (lds_vu128 *)&queue[seq & (QN - 1)];
+            if (lane == 0) {
+                e[2] = u32x4{(uint32_t)snap.s0, (uint32_t)(snap.s0 >> 32), (uint32_t)snap.s1, (uint32_t)(snap.s1 >> 32)};
+                e[3] = u32x4{(uint32_t)snap.s2, (uint32_t)(snap.s2 >> 32), (uint32_t)snap.s3, (uint32_t)(snap.s3 >> 32)};
+                e[1] = u32x4{(uint32_t)v, (uint32_t)(v >> 32), 0u, 0u};
+                e[0] = u32x4{g, seq, idx, pos};  // tag last
+            }
+            seq++;
+        }
+        __syncthreads();  // B: chain finished
+    }
+}
+
+// The Bernoulli test of `0f64 < diff || rng.gen_bool(diff.exp())` (:736) for a step that does draw:
+// gen_bool compares the u64 draw v with p_int = floor(exp(diff) * 2^64).  The exact exp is only evaluated
+// when an f32 estimate with a guard band cannot decide, so the decision is always the exact one.
+__device__ __forceinline__ bool bernoulli_exact(uint64_t v, double diff) {
+    if (ubool(diff <= -44.4)) return false;  // exp(diff) * 2^64 < 1  =>  p_int == 0
+    if (ubool(diff < -1e-3)) {
+        const float u = (float)(uint32_t)(v >> 40) * 0x1p-24f;  // v / 2^64 within 2^-24
+        const float pe = __expf((float)diff);
+        if (ubool(u < pe * 0.999f - 3e-7f)) return true;
+        if (ubool(u > pe * 1.001f + 3e-7f)) return false;
+    }
+    const double scaled = unif64(jtk_exp(diff)) * 18446744073709551616.0;
+    return v < uni64(__double2ull_rz(scaled));
 }
 
 // mcmc_with_filter (:704-762). m.assign holds the k-means labels on entry, the best-seen labels on exit.
-template <int K>
-__device__ double mcmc_with_filter(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
+// Runs on the consumer wave; the producer wave feeds it proposals.
+template <int K, bool SMALL>
+__device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
     // size_to_lk[x] = max_{c=1..K} poisson_lk(x, cov*c)
-    for (uint32_t x = lane; x <= n; x += 64) {
+    LaneTab size_to_lk;
+#pragma unroll
+    for (int r = 0; r < (SMALL ? 1 : 4); r++) {
+        const uint32_t x = lane + 64 * r;
         double mx = -__builtin_inf();
-        for (int c = 1; c <= K; c++) {
-            const double lam = cov * (double)c;
-            mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
-        }
-        m.size_to_lk[x] = mx;
+        if (x <= n)
+            for (int c = 1; c <= K; c++) {
+                const double lam = cov * (double)c;
+                mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
+            }
+        size_to_lk.v[r] = mx;
     }
-    __syncthreads();
-    Counts<K> q;
-    int clusters[K];
-    fill_counts<K>(m, n, D, m.assign, q, clusters, lane);
-    double lk = get_lk<K>(m, q, clusters, D, lane);
+    // ---- arm the producer
+    if (lane == 0) {
+        lds_st64(&m.ctl->restart_state[0], rng.s0);
+        lds_st64(&m.ctl->restart_state[1], rng.s1);
+        lds_st64(&m.ctl->restart_state[2], rng.s2);
+        lds_st64(&m.ctl->restart_state[3], rng.s3);
+        lds_st32(&m.ctl->restart_seq, 0);
+        lds_st32(&m.ctl->n, n);
+        lds_st32(&m.ctl->k, K);
+        lds_st32(&m.ctl->consumed, 0);
+        lds_st32(&m.ctl->stop, 0);
+        lds_st32(&m.ctl->gen, 0);
+    }
+    for (uint32_t e = lane; e < QN; e += 64) lds_st64((uint64_t *)&m.queue[e].gen, ~0ull);  // no valid tag
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();  // A
+    // ---- initial LKCounts in the reference's order (reads outer)
+    double tg[K];
+    int np[K], w[K], cl[K];
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        tg[c] = 0.0;
+        np[c] = 0;
+        w[c] = 0;
+        cl[c] = 0;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t c = uni(m.assign[i]);
+        Elem el = {0.0, 0, 0};
+        if (lane < D) el = m.elem[i * D + lane];
+#pragma unroll
+        for (int cc = 0; cc < K; cc++)
+            if ((uint32_t)cc == c) {
+                tg[cc] += el.x;
+                np[cc] += el.dp;
+                w[cc] += el.pw;
+                cl[cc]++;
+            }
+    }
+    int totp = 0;  // reads with a positive value in this column: sum_c num_pos[c], constant along the chain
+    unsigned long long posm[K], infm[K];
+    const unsigned long long colm = D >= 64 ? ~0ull : ((1ull << D) - 1ull);
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        totp += np[c];
+        posm[c] = __ballot(0.0 < tg[c]) & colm;
+        infm[c] = __ballot(w[c] > 0);
+    }
+    LaneLabels assign, argmax;
+#pragma unroll
+    for (int r = 0; r < (SMALL ? 1 : 4); r++) {
+        const uint32_t i = lane + 64 * r;
+        assign.v[r] = i < n ? (int)m.assign[i] : 0;
+        argmax.v[r] = assign.v[r];
+    }
+    // get_lk (:785-795) on a tentative state: size terms first, then clusters outer / columns inner, left to
+    // right; exactly-zero terms (unused column or total_gain <= 0) leave the f64 sum unchanged and are skipped.
+    auto get_lk = [&](const double *T, const int *P, const int *cls, const unsigned long long *pm,
+                      const unsigned long long *im) -> double {
+        double S = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; c++) S += tab_get<SMALL>(size_to_lk, (uint32_t)cls[c]);
+        int in_use = 0;
+        unsigned long long anym = 0;
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            in_use += (0.0 < T[c]) ? P[c] : 0;
+            anym |= pm[c] & im[c];  // some cluster is_informative (:818-822) on this column
+        }
+        // get_used_columns (:847-869): informative somewhere, and 2 * pos_in_neg < pos_in_use
+        const unsigned long long usedm = __ballot(3 * in_use > 2 * totp) & anym;
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            unsigned long long mm = usedm & pm[c];
+            while (mm) {
+                const uint32_t d = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1;
+                S += readlane_f64(T[c], d);
+            }
+        }
+        return S;
+    };
+    double lk = get_lk(tg, np, cl, posm, infm);
     double max = lk;
-    for (uint32_t i = lane; i < n; i += 64) m.argmax[i] = m.assign[i];
-    __syncthreads();
     const uint32_t total = 2000u * n;
+    uint32_t gen = 0;
+    Rng after = rng;  // generator state after the last step
     for (uint32_t t = 0; t < total; t++) {
-        const uint32_t idx = (uint32_t)gen_range_usize(rng, n);
-        const uint32_t old = uni(m.assign[idx]);
-        const uint32_t nw = choose_other(rng, K, old);
-        flip<K>(m, q, clusters, D, idx, old, nw, lane);
-        const double proposed = get_lk<K>(m, q, clusters, D, lane);
-        const double diff = proposed - lk;
-        if (0.0 < diff || gen_bool(rng, jtk_exp(diff))) {
-            lk = proposed;
-            if (max < lk) {
-                max = proposed;
-                for (uint32_t i = lane; i < n; i += 64) m.argmax[i] = m.assign[i];
-                __syncthreads();
+        // ---- proposal t from the producer
+        const QEntry *e = &m.queue[t & (QN - 1)];
+        const uint64_t want = ((uint64_t)t << 32) | gen;
+        while (uni64(lds_ld64((const uint64_t *)&e->gen)) != want) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint64_t ij = uni64(lds_ld64((const uint64_t *)&e->idx));
+        const uint32_t idx = (uint32_t)ij, pos = (uint32_t)(ij >> 32);
+        const uint32_t old = lab_get<SMALL>(assign, idx);
+        const uint32_t nw = K == 2 ? 1u - old : (pos < old ? pos : pos + 1);
+        Elem el = {0.0, 0, 0};
+        if (lane < D) el = m.elem[idx * D + lane];
+        // ---- tentative flip (:764-783): only the two touched clusters change
+        double T[K];
+        int P[K], W[K], ncl[K];
+        unsigned long long npm[K], nim[K];
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            const bool o = (uint32_t)c == old, a = (uint32_t)c == nw;
+            T[c] = tg[c];
+            P[c] = np[c];
+            W[c] = w[c];
+            ncl[c] = cl[c];
+            npm[c] = posm[c];
+            nim[c] = infm[c];
+            if (o) {
+                T[c] = tg[c] - el.x;
+                P[c] = np[c] - el.dp;
+                W[c] = w[c] - el.pw;
+                ncl[c] = cl[c] - 1;
+            }
+            if (a) {
+                T[c] = tg[c] + el.x;
+                P[c] = np[c] + el.dp;
+                W[c] = w[c] + el.pw;
+                ncl[c] = cl[c] + 1;
+            }
+            if (o || a) {
+                npm[c] = __ballot(0.0 < T[c]) & colm;
+                nim[c] = __ballot(W[c] > 0);
+            }
+        }
+        const double proposed = get_lk(T, P, ncl, npm, nim);
+        const double diff = unif64(proposed - lk);
+        // gen_bool(1.0) draws nothing, and exp(diff) == 1.0 exactly when diff >= -2^-54
+        const bool no_draw = ubool(diff >= -0x1p-54);
+        bool accept = true;
+        if (no_draw) {
+            // the producer assumed a draw: re-synchronise it from the state before that draw
+            after.s0 = uni64(lds_ld64(&e->s[0]));
+            after.s1 = uni64(lds_ld64(&e->s[1]));
+            after.s2 = uni64(lds_ld64(&e->s[2]));
+            after.s3 = uni64(lds_ld64(&e->s[3]));
+            if (t + 1 < total) {
+                gen++;
+                if (lane == 0) {
+                    lds_st64(&m.ctl->restart_state[0], after.s0);
+                    lds_st64(&m.ctl->restart_state[1], after.s1);
+                    lds_st64(&m.ctl->restart_state[2], after.s2);
+                    lds_st64(&m.ctl->restart_state[3], after.s3);
+                    lds_st32(&m.ctl->restart_seq, t + 1);
+                    lds_st32(&m.ctl->consumed, t + 1);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    lds_st32(&m.ctl->gen, gen);
+                }
             }
         } else {
-            flip<K>(m, q, clusters, D, idx, nw, old, lane);
-            __syncthreads();
+            accept = bernoulli_exact(uni64(lds_ld64(&e->v)), diff);
+            if (t + 1 == total) {
+                after.s0 = uni64(lds_ld64(&e->s[0]));
+                after.s1 = uni64(lds_ld64(&e->s[1]));
+                after.s2 = uni64(lds_ld64(&e->s[2]));
+                after.s3 = uni64(lds_ld64(&e->s[3]));
+                (void)next_u64(after);
+            } else if ((t & 15) == 15 && lane == 0) {
+                lds_st32(&m.ctl->consumed, t + 1);
+            }
+        }
+        if (accept) {
+#pragma unroll
+            for (int c = 0; c < K; c++) {
+                tg[c] = T[c];
+                np[c] = P[c];
+                w[c] = W[c];
+                cl[c] = ncl[c];
+                posm[c] = npm[c];
+                infm[c] = nim[c];
+            }
+            lab_set<SMALL>(assign, idx, nw, lane);
+            lk = proposed;
+            if (ubool(max < lk)) {
+                max = proposed;
+                argmax = assign;
+            }
+        } else {
+            // flip back (:746): the reference re-adds / re-subtracts, which leaves rounding residue
+#pragma unroll
+            for (int c = 0; c < K; c++) {
+                if ((uint32_t)c == old) tg[c] = T[c] + el.x;
+                if ((uint32_t)c == nw) tg[c] = T[c] - el.x;
+            }
         }
     }
-    for (uint32_t i = lane; i < n; i += 64) m.assign[i] = m.argmax[i];
-    __syncthreads();
+    if (lane == 0) lds_st32(&m.ctl->stop, 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();  // B
+    rng = after;
+#pragma unroll
+    for (int r = 0; r < (SMALL ? 1 : 4); r++) {
+        const uint32_t i = lane + 64 * r;
+        if (i < n) m.assign[i] = (uint8_t)argmax.v[r];
+    }
+    wsync();
     return max;
+}
+
+// The same chain specialised for the diploid case (K == 2, n <= 63): labels are one scalar bitmask, the two
+// cluster sizes are (c0, n - c0) so the size term is one table entry, the flip is a sign change, and the next
+// proposal and its feature row are fetched from LDS one step ahead.  Same arithmetic, same order.
+__device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng,
+                                                uint32_t lane) {
+    // pair table: lane c0 holds (0.0 + size_to_lk[c0]) + size_to_lk[n - c0]   (get_lk :788, clusters in order)
+    double pair_lk;
+    {
+        auto size_lk = [&](uint32_t x) {
+            double mx = -__builtin_inf();
+            for (int c = 1; c <= 2; c++) {
+                const double lam = cov * (double)c;
+                mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
+            }
+            return mx;
+        };
+        const uint32_t c0 = lane <= n ? lane : n;
+        pair_lk = (0.0 + size_lk(c0)) + size_lk(n - c0);
+    }
+    if (lane == 0) {
+        lds_st64(&m.ctl->restart_state[0], rng.s0);
+        lds_st64(&m.ctl->restart_state[1], rng.s1);
+        lds_st64(&m.ctl->restart_state[2], rng.s2);
+        lds_st64(&m.ctl->restart_state[3], rng.s3);
+        lds_st32(&m.ctl->restart_seq, 0);
+        lds_st32(&m.ctl->n, n);
+        lds_st32(&m.ctl->k, 2);
+        lds_st32(&m.ctl->consumed, 0);
+        lds_st32(&m.ctl->stop, 0);
+        lds_st32(&m.ctl->gen, 0);
+    }
+    for (uint32_t e = lane; e < QN; e += 64) lds_st64((uint64_t *)&m.queue[e].gen, ~0ull);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();  // A
+    double tg0 = 0.0, tg1 = 0.0;
+    int np0 = 0, np1 = 0, w0 = 0, w1 = 0;
+    uint32_t c0 = 0;
+    unsigned long long lab = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t c = uni(m.assign[i]);
+        Elem el = {0.0, 0, 0};
+        if (lane < D) el = m.elem[i * D + lane];
+        if (c == 0) {
+            tg0 += el.x;
+            np0 += el.dp;
+            w0 += el.pw;
+            c0++;
+        } else {
+            tg1 += el.x;
+            np1 += el.dp;
+            w1 += el.pw;
+            lab |= 1ull << i;
+        }
+    }
+    const int totp2 = 2 * (np0 + np1);
+    const unsigned long long colm = (1ull << D) - 1ull;  // D <= JTK_MAX_DIM < 64
+    unsigned long long pm0 = __ballot(0.0 < tg0) & colm, pm1 = __ballot(0.0 < tg1) & colm;
+    unsigned long long im0 = __ballot(w0 > 0), im1 = __ballot(w1 > 0);
+    auto get_lk2 = [&](double T0, double T1, int P0, int P1, uint32_t cc0, unsigned long long a0, unsigned long long a1,
+                       unsigned long long b0, unsigned long long b1) -> double {
+        double S = readlane_f64(pair_lk, cc0);
+        const int in_use = ((0.0 < T0) ? P0 : 0) + ((0.0 < T1) ? P1 : 0);
+        const unsigned long long usedm = __ballot(3 * in_use > totp2) & ((a0 & b0) | (a1 & b1));
+        unsigned long long mm = usedm & a0;
+        while (mm) {
+            const uint32_t d = (uint32_t)__builtin_ctzll(mm);
+            mm &= mm - 1;
+            S += readlane_f64(T0, d);
+        }
+        mm = usedm & a1;
+        while (mm) {
+            const uint32_t d = (uint32_t)__builtin_ctzll(mm);
+            mm &= mm - 1;
+            S += readlane_f64(T1, d);
+        }
+        return S;
+    };
+    double lk = get_lk2(tg0, tg1, np0, np1, c0, pm0, pm1, im0, im1);
+    double max = lk;
+    unsigned long long argmax = lab;
+    const uint32_t total = 2000u * n;
+    uint32_t gen = 0;
+    Rng after = rng;
+    typedef __attribute__((address_space(3))) const volatile uint64_t *lds_cp64;
+    // fetch of proposal t: tag+idx words and v; validated (spinning if the producer is behind)
+    auto fetch = [&](uint32_t t, uint32_t &idx, uint64_t &v) {
+        const QEntry *e = &m.queue[t & (QN - 1)];
+        const uint64_t want = ((uint64_t)t << 32) | gen;
+        for (;;) {
+            const uint64_t tag = lds_ld64((const uint64_t *)&e->gen);
+            const uint64_t ij = lds_ld64((const uint64_t *)&e->idx);
+            const uint64_t vv = lds_ld64(&e->v);
+            if (uni64(tag) == want) {
+                idx = uni((uint32_t)ij);
+                v = uni64(vv);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    uint32_t idx;
+    uint64_t v;
+    fetch(0, idx, v);
+    Elem el = {0.0, 0, 0};
+    if (lane < D) el = m.elem[idx * D + lane];
+    for (uint32_t t = 0; t < total; t++) {
+        const uint32_t old = (uint32_t)(lab >> idx) & 1u;
+        // tentative flip: cluster `old` loses the read, the other one gains it
+        const double sx = old ? -el.x : el.x;
+        const int sdp = old ? -el.dp : el.dp, spw = old ? -el.pw : el.pw;
+        const double T0 = tg0 - sx, T1 = tg1 + sx;
+        const int P0 = np0 - sdp, P1 = np1 + sdp, W0 = w0 - spw, W1 = w1 + spw;
+        const uint32_t nc0 = old ? c0 + 1 : c0 - 1;
+        const unsigned long long a0 = __ballot(0.0 < T0) & colm, a1 = __ballot(0.0 < T1) & colm;
+        const unsigned long long b0 = __ballot(W0 > 0), b1 = __ballot(W1 > 0);
+        const double proposed = get_lk2(T0, T1, P0, P1, nc0, a0, a1, b0, b1);
+        const double diff = unif64(proposed - lk);
+        const bool no_draw = ubool(diff >= -0x1p-54);
+        const bool last = t + 1 == total;
+        bool accept = true;
+        const uint32_t cur_idx = idx;
+        const Elem cur = el;
+        if (no_draw || last) {
+            const QEntry *e = &m.queue[t & (QN - 1)];
+            after.s0 = uni64(lds_ld64(&e->s[0]));
+            after.s1 = uni64(lds_ld64(&e->s[1]));
+            after.s2 = uni64(lds_ld64(&e->s[2]));
+            after.s3 = uni64(lds_ld64(&e->s[3]));
+            if (!no_draw) {
+                accept = bernoulli_exact(v, diff);
+                (void)next_u64(after);
+            }
+            if (no_draw && !last) {
+                gen++;
+                if (lane == 0) {
+                    lds_st64(&m.ctl->restart_state[0], after.s0);
+                    lds_st64(&m.ctl->restart_state[1], after.s1);
+                    lds_st64(&m.ctl->restart_state[2], after.s2);
+                    lds_st64(&m.ctl->restart_state[3], after.s3);
+                    lds_st32(&m.ctl->restart_seq, t + 1);
+                    lds_st32(&m.ctl->consumed, t + 1);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    lds_st32(&m.ctl->gen, gen);
+                }
+            }
+        } else {
+            accept = bernoulli_exact(v, diff);
+            if ((t & 15) == 15 && lane == 0) lds_st32(&m.ctl->consumed, t + 1);
+        }
+        // next proposal and its feature row (LDS latency overlaps the commit/undo below)
+        if (!last) {
+            fetch(t + 1, idx, v);
+            el.x = 0.0;
+            el.dp = 0;
+            el.pw = 0;
+            if (lane < D) el = m.elem[idx * D + lane];
+        }
+        if (accept) {
+            tg0 = T0;
+            tg1 = T1;
+            np0 = P0;
+            np1 = P1;
+            w0 = W0;
+            w1 = W1;
+            c0 = nc0;
+            pm0 = a0;
+            pm1 = a1;
+            im0 = b0;
+            im1 = b1;
+            lab ^= 1ull << cur_idx;
+            lk = proposed;
+            if (ubool(max < lk)) {
+                max = proposed;
+                argmax = lab;
+            }
+        } else {
+            // flip back (:746): re-add / re-subtract, keeping the reference's rounding residue
+            const double ux = old ? -cur.x : cur.x;
+            tg0 = T0 + ux;
+            tg1 = T1 - ux;
+        }
+    }
+    if (lane == 0) lds_st32(&m.ctl->stop, 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();  // B
+    rng = after;
+    if (lane < n) m.assign[lane] = (uint8_t)((argmax >> lane) & 1ull);
+    wsync();
+    return max;
+}
+
+template <int K>
+__device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
+    if (K == 2 && n <= 63) return mcmc_chain_k2(m, n, D, cov, rng, lane);
+    if (n <= 63) return mcmc_chain<K, true>(m, n, D, cov, rng, lane);
+    return mcmc_chain<K, false>(m, n, D, cov, rng, lane);
 }
 
 // get_read_lk_gains (:381-408): used columns -> used[], per-read gain -> fbuf[]
 template <int K>
-__device__ void get_read_lk_gains(const Lds &m, uint32_t n, uint32_t D, const uint8_t *assign, uint8_t *used,
+__device__ __forceinline__ void get_read_lk_gains(const Lds &m, uint32_t n, uint32_t D, const uint8_t *assign, uint8_t *used,
                                   uint32_t lane) {
     Counts<K> q;
     int clusters[K];
     fill_counts<K>(m, n, D, assign, q, clusters, lane);
-    const bool u = lane < D && column_used<K>(q, m.thr);
+    const bool u = lane < D && column_used<K>(q);
     if (lane < D) used[lane] = u ? 1 : 0;
 #pragma unroll
     for (int c = 0; c < K; c++)
         if (lane < D) m.val[c * D + lane] = (u && JTK_POS_THR < q.tg[c]) ? 1.0 : 0.0;  // column counts for cluster c
-    __syncthreads();
+    wsync();
     for (uint32_t i = lane; i < n; i += 64) {
         const uint32_t a = assign[i];
         double s = 0.0;
@@ -387,21 +909,21 @@ __device__ void get_read_lk_gains(const Lds &m, uint32_t n, uint32_t D, const ui
             if (m.val[a * D + d] != 0.0) s += m.data[i * D + d];
         m.fbuf[i] = s;
     }
-    __syncthreads();
+    wsync();
 }
 
 // get_likelihood_gain (:353-379): out[i*K + c]
 template <int K>
-__device__ void get_likelihood_gain(const Lds &m, uint32_t n, uint32_t D, const uint8_t *assign, double *out,
+__device__ __forceinline__ void get_likelihood_gain(const Lds &m, uint32_t n, uint32_t D, const uint8_t *assign, double *out,
                                     uint32_t lane) {
     Counts<K> q;
     int clusters[K];
     fill_counts<K>(m, n, D, assign, q, clusters, lane);
-    const bool u = lane < D && column_used<K>(q, m.thr);
+    const bool u = lane < D && column_used<K>(q);
 #pragma unroll
     for (int c = 0; c < K; c++)
         if (lane < D) m.val[c * D + lane] = (u && JTK_POS_THR < q.tg[c]) ? 1.0 : 0.0;
-    __syncthreads();
+    wsync();
     for (uint32_t i = lane; i < n; i += 64)
         for (int c = 0; c < K; c++) {
             double s = 0.0;
@@ -409,12 +931,12 @@ __device__ void get_likelihood_gain(const Lds &m, uint32_t n, uint32_t D, const 
                 if (m.val[c * D + d] != 0.0) s += m.data[i * D + d];
             out[i * K + c] = s;
         }
-    __syncthreads();
+    wsync();
 }
 
 // mcmc_clustering (:649-670): labels -> m.best, per-read gains -> m.fbuf, used columns -> m.used
 template <int K>
-__device__ bool mcmc_clustering(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score,
+__device__ __forceinline__ bool mcmc_clustering(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score,
                                 uint32_t lane) {
     double best = 0.0;
     bool have = false;
@@ -425,7 +947,7 @@ __device__ bool mcmc_clustering(const Lds &m, uint32_t n, uint32_t D, double cov
             best = lk;
             have = true;
             for (uint32_t i = lane; i < n; i += 64) m.best[i] = m.assign[i];
-            __syncthreads();
+            wsync();
         }
     }
     get_read_lk_gains<K>(m, n, D, m.best, m.used, lane);
@@ -446,11 +968,11 @@ __device__ bool mcmc_clustering(const Lds &m, uint32_t n, uint32_t D, double cov
 }
 
 template <int K>
-__device__ bool run_k(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score, uint32_t lane) {
+__device__ __forceinline__ bool run_k(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score, uint32_t lane) {
     return mcmc_clustering<K>(m, n, D, cov, rng, score, lane);
 }
 
-__device__ bool run_k_dyn(uint32_t k, const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score,
+__device__ __forceinline__ bool run_k_dyn(uint32_t k, const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score,
                           uint32_t lane) {
     switch (k) {
         case 2: return run_k<2>(m, n, D, cov, rng, score, lane);
@@ -463,7 +985,7 @@ __device__ bool run_k_dyn(uint32_t k, const Lds &m, uint32_t n, uint32_t D, doub
     }
 }
 
-__device__ void likelihood_gain_dyn(uint32_t k, const Lds &m, uint32_t n, uint32_t D, const uint8_t *assign,
+__device__ __forceinline__ void likelihood_gain_dyn(uint32_t k, const Lds &m, uint32_t n, uint32_t D, const uint8_t *assign,
                                     double *out, uint32_t lane) {
     switch (k) {
         case 1: get_likelihood_gain<1>(m, n, D, assign, out, lane); break;
@@ -483,24 +1005,26 @@ __device__ __forceinline__ double gains_expected(const jtk_gains_t *g, uint32_t 
                                 : (dt == JTK_DIFF_DEL ? g->deletions[h - 1].gain : g->insertions[h - 1].gain);
 }
 
-// one wave per chunk
-__global__ __launch_bounds__(64) void mcmc_kernel(const ChunkMeta *chunks, ChunkState *state,
+// one workgroup of two waves per chunk: wave 0 runs the algorithm, wave 1 feeds it proposals
+__global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, ChunkState *state,
                                                   const jtk_lc_params_t *params, const double *feat_all,
                                                   const uint32_t *vtype_all, const uint64_t *vt_off_all,
                                                   uint32_t vt_stride_mode, uint32_t *label_all, double *post_all,
                                                   uint32_t post_stride, double *lg_all, const uint64_t *lg_off,
                                                   uint32_t lds_n, uint32_t lds_d) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t ci = blockIdx.x, lane = threadIdx.x;
+    const uint32_t ci = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     ChunkState *st = &state[ci];
     if (st->status != 0) return;
     const ChunkMeta cm = chunks[ci];
-    const uint32_t n = cm.n_reads, D = st->dim, copy_num = cm.copy_num;
-    const double coverage = params->haploid_coverage;
+    // everything that steers control flow is made provably wave-uniform (scalar registers, scalar branches)
+    const uint32_t n = uni(cm.n_reads), D = uni(st->dim), copy_num = uni(cm.copy_num);
+    const double coverage = unif64(params->haploid_coverage);
     uint32_t *label = label_all + cm.read_first;
     double *post = post_all + (uint64_t)cm.read_first * post_stride;
     // ---- trivial outcomes (pseudo_mcmc.rs:86-88, :221-225)
     if (copy_num < 2 || D == 0 || n <= copy_num) {
+        if (wave != 0) return;
         for (uint32_t i = lane; i < n; i += 64) {
             label[i] = 0;
             for (uint32_t c = 0; c < post_stride; c++) post[(uint64_t)i * post_stride + c] = 0.0;
@@ -512,7 +1036,7 @@ __global__ __launch_bounds__(64) void mcmc_kernel(const ChunkMeta *chunks, Chunk
         return;
     }
     if (copy_num > JTK_MAX_COPY || n > 255 || n > lds_n || D > lds_d) {
-        if (lane == 0) st->status = JTK_ERR_UNSUPPORTED;
+        if (threadIdx.x == 0) st->status = JTK_ERR_UNSUPPORTED;
         return;
     }
     // ---- LDS carve
@@ -524,6 +1048,9 @@ __global__ __launch_bounds__(64) void mcmc_kernel(const ChunkMeta *chunks, Chunk
             p += (bytes + 15) & ~(size_t)15;
             return q;
         };
+        m.ctl = (QCtl *)take(sizeof(QCtl));
+        m.queue = (QEntry *)take(sizeof(QEntry) * QN);
+        m.elem = (Elem *)take((size_t)lds_n * lds_d * sizeof(Elem));
         m.data = (double *)take((size_t)lds_n * lds_d * 8);
         m.size_to_lk = (double *)take((size_t)(lds_n + 1) * 8);
         m.lfact = (double *)take((size_t)(lds_n + 1) * 8);
@@ -531,7 +1058,6 @@ __global__ __launch_bounds__(64) void mcmc_kernel(const ChunkMeta *chunks, Chunk
         m.centers = (double *)take((size_t)JTK_MAX_COPY * lds_d * 8);
         m.fbuf = (double *)take((size_t)lds_n * 8);
         m.cum = (double *)take((size_t)lds_n * 8);
-        m.thr = (uint8_t *)take(lds_n + 1);
         m.assign = (uint8_t *)take(lds_n);
         m.argmax = (uint8_t *)take(lds_n);
         m.best = (uint8_t *)take(lds_n);
@@ -541,8 +1067,21 @@ __global__ __launch_bounds__(64) void mcmc_kernel(const ChunkMeta *chunks, Chunk
         m.prev_used = (uint8_t *)take(lds_d);
         m.tmp_used = (uint8_t *)take(lds_d);
     }
+    if (wave == 1) {
+        producer_main(m.ctl, m.queue, lane);
+        return;
+    }
+    if (lane == 0) lds_st32(&m.ctl->quit, 0);
     const double *feat = feat_all + cm.feat_off;
-    for (uint32_t e = lane; e < n * D; e += 64) m.data[e] = feat[e];
+    for (uint32_t e = lane; e < n * D; e += 64) {
+        const double x = feat[e];
+        m.data[e] = x;
+        Elem el;
+        el.x = x;
+        el.dp = JTK_POS_THR < x ? 1 : 0;
+        el.pw = 3 * el.dp - 7 * (x < -JTK_POS_THR ? 1 : 0);
+        m.elem[e] = el;
+    }
     // lfact[x] = sum_{c=1..x} ln c, summed left to right as poisson_lk does (:636-638)
     if (lane == 0) {
         double s = 0.0;
@@ -552,34 +1091,22 @@ __global__ __launch_bounds__(64) void mcmc_kernel(const ChunkMeta *chunks, Chunk
             m.lfact[c] = s;
         }
     }
-    // thr[s]: smallest num_pos with 0.70 < num_pos / (s + 1e-7)  (LKCount::is_informative, :818-822);
-    // the quotient is monotone in num_pos for fixed s, so the test is num_pos >= thr[s]
-    for (uint32_t s = lane; s <= n; s += 64) {
-        const double cov = (double)s + 0.0000001;
-        uint32_t t = s + 1;  // "never"
-        for (uint32_t p = 0; p <= s; p++)
-            if (0.70 < (double)p / cov) {
-                t = p;
-                break;
-            }
-        m.thr[s] = (uint8_t)(t > 255 ? 255 : t);
-    }
     for (uint32_t d = lane; d < D; d += 64) m.prev_used[d] = 0;
     for (uint32_t i = lane; i < n; i += 64) m.accepted[i] = 0;
-    __syncthreads();
+    wsync();
     const uint32_t *vt = vtype_all + 2 * ((uint64_t)ci * JTK_MAX_DIM);
     if (vt_stride_mode) vt = vtype_all + 2 * vt_off_all[ci];
     // ---- per-chunk RNG (local_clustering/mod.rs:97)
     Rng rng;
     {
-        uint64_t x = cm.chunk_id * 3490ULL;
+        uint64_t x = uni64(cm.chunk_id) * 3490ULL;
         rng.s0 = splitmix64(x);
         rng.s1 = splitmix64(x);
         rng.s2 = splitmix64(x);
         rng.s3 = splitmix64(x);
     }
     // ---- cluster_filtered_variants (:213-274)
-    const double per_cluster_cov = cm.local_coverage;
+    const double per_cluster_cov = unif64(cm.local_coverage);
     double max = 0.0;
     uint32_t max_k = 1;
     const uint32_t end = copy_num < 1 + 2 * D ? copy_num : 1 + 2 * D;
@@ -605,7 +1132,7 @@ __global__ __launch_bounds__(64) void mcmc_kernel(const ChunkMeta *chunks, Chunk
                 }
             }
             for (uint32_t i = lane; i < n; i += 64) m.tmp_asn[i] = 0.0 < m.data[i * D + max_idx] ? 1 : 0;
-            __syncthreads();
+            wsync();
             // keep the mcmc result aside: fbuf is overwritten by get_read_lk_gains
             get_read_lk_gains<2>(m, n, D, m.tmp_asn, m.tmp_used, lane);
             double hscore = 0.0;
@@ -614,7 +1141,7 @@ __global__ __launch_bounds__(64) void mcmc_kernel(const ChunkMeta *chunks, Chunk
                 score = hscore;
                 for (uint32_t i = lane; i < n; i += 64) m.best[i] = m.tmp_asn[i];
                 for (uint32_t d = lane; d < D; d += 64) m.used[d] = m.tmp_used[d];
-                __syncthreads();
+                wsync();
             }
         }
         // expected_gains (:286-306)
@@ -628,16 +1155,20 @@ __global__ __launch_bounds__(64) void mcmc_kernel(const ChunkMeta *chunks, Chunk
         }
         const double expected_gain = jtk_fmax(0.8 * expt, 0.1) * per_cluster_cov + 0.1;
         if (expected_gain < score - max) {
-            __syncthreads();
+            wsync();
             for (uint32_t i = lane; i < n; i += 64) m.accepted[i] = m.best[i];
             for (uint32_t d = lane; d < D; d += 64) m.prev_used[d] = m.used[d];
             max = score;
             max_k = k;
-            __syncthreads();
+            wsync();
         } else {
             break;
         }
     }
+    // release the producer wave (it is parked at barrier A)
+    if (lane == 0) lds_st32(&m.ctl->quit, 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
     if (failed) {
         if (lane == 0) st->status = JTK_ERR_CHUNK_FAILED;
         return;
@@ -673,8 +1204,9 @@ __global__ __launch_bounds__(64) void mcmc_kernel(const ChunkMeta *chunks, Chunk
 
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    size_t b = al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) + 2 * al((size_t)JTK_MAX_COPY * lds_d * 8) +
-               2 * al((size_t)lds_n * 8) + al(lds_n + 1) + 5 * al(lds_n) + 3 * al(lds_d);
+    size_t b = al(sizeof(QCtl)) + al(sizeof(QEntry) * QN) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
+               al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) + 2 * al((size_t)JTK_MAX_COPY * lds_d * 8) +
+               2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d);
     return b;
 }
 
@@ -684,6 +1216,6 @@ void launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, Chun
                  const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d) {
     if (n_chunks == 0) return;
     const size_t lds = mcmc_lds_bytes(lds_n, lds_d);
-    mcmc_kernel<<<n_chunks, 64, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
+    mcmc_kernel<<<n_chunks, 128, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
                                           post_stride, lg, lg_off, lds_n, lds_d);
 }
