@@ -24,7 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from jtk_amd import api, batch as jb, build as jbuild, ffi, synth  # noqa: E402
+from jtk_amd import api, batch as jb, build as jbuild, ffi, sharding, synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 WORKLOADS = {
@@ -56,6 +56,25 @@ def cpu_baseline(params, batch, sample_chunks, threads):
     return dict(value=sample_chunks / dt, unit="chunks/s", cores=threads, kind="port",
                 sample=f"first {sample_chunks} chunks of the same batch, full path (polish+search+clustering), "
                        f"{dt:.1f} s wall, mean RECORD {float(r['record_ms'][:, 0].mean()):.0f} ms/chunk"), sub, r
+
+
+def pmc_traffic(family, workload, n_chunks):
+    """HBM bytes per launch of the dominant kernel family from the rocprofv3 PMC passes committed under profiles/
+    (scripts/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction).  None when no profile of this
+    workload is on file."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        prof = json.load(open(path))
+    except OSError:
+        return None
+    if prof.get("workload") != workload or n_chunks != WORKLOADS[workload]["chunks"]:
+        return None
+    total = 0.0
+    for k in prof["kernel_family"].get(family, []):
+        e = prof["kernels"].get(k)
+        if e:
+            total += (2.0 * e.get("FETCH_SIZE_KiB_per_launch", 0.0) + e.get("WRITE_SIZE_KiB_per_launch", 0.0)) * 1024.0
+    return total
 
 
 def main():
@@ -93,7 +112,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     n_chunks = args.chunks or wl["chunks"]
-    batch, cfg = make_batch_parallel(wl["config"], n_chunks, first_chunk_id=rank * n_chunks)
+    batch, cfg = make_batch_parallel(wl["config"], n_chunks, first_chunk_id=sharding.weak_chunk_ids(rank, n_chunks)[0])
     params = jb.default_params(haploid_coverage=cfg["coverage"], band_frac=cfg["band_frac"])
 
     def barrier():
@@ -110,9 +129,7 @@ def main():
         sess.run(skip_polish=False)            # synchronous: returns when the device has finished
         if dist is not None:                   # the only exchange of the path: labels, RCCL all-gather
             out = sess.fetch()
-            lab = torch.from_numpy(out["label"].astype(np.int32)).cuda()
-            gathered = [torch.empty_like(lab) for _ in range(world)]
-            dist.all_gather(gathered, lab)
+            gathered = sharding.all_gather_labels(dist, out["label"], device=torch.device("cuda", local_rank))
 
     for _ in range(args.warmup):
         step()
@@ -147,7 +164,7 @@ def main():
     dom_ms_per_step = ktime[dom] / args.steps
     achieved = alg_bytes_per_step / 1e9 / (dom_ms_per_step / 1e3) if dom_ms_per_step > 0 else 0.0
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s", frac=achieved / HBM_PEAK_GBPS,
-                    traffic=None, kernel=dom, kernel_ms_per_step=dom_ms_per_step,
+                    traffic=pmc_traffic(dom, args.workload, n_chunks), kernel=dom, kernel_ms_per_step=dom_ms_per_step,
                     launches_per_step=klaunch[dom] / args.steps,
                     algorithmic_bytes_per_step=alg_bytes_per_step,
                     all_kernels_ms_per_step={n: ktime[n] / args.steps for n in ffi.KERNEL_NAMES},
