@@ -122,9 +122,16 @@ struct QCtl {  // 64 B
     uint32_t restart_seq, n, k, pad;
     uint64_t restart_state[4];
 };
+struct Elem2 {  // one (read, lane) cell of the batched diploid chain: lane d serves column d of cluster 0 and
+    double x;   // column GW-1-d of cluster 1 (mirrored, so that the ordered sum of get_lk is two DPP row scans)
+    double xr;
+    int dp, pw, dpr, pwr;
+};
+#define JTK_GW_MAX 16
 struct Lds {
     QCtl *ctl;
     QEntry *queue;
+    Elem2 *elem2;        // min(n, 63) x JTK_GW_MAX
     Elem *elem;          // n x D
     double *data;        // n x D
     double *size_to_lk;  // n + 1
@@ -882,8 +889,291 @@ __device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32
     return max;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Lane-time batching of the diploid chain (K == 2, n <= 63, D <= GW).
+//
+// More than 96% of the proposals are rejected, and a rejected step changes the state only by the rounding
+// residue of flip + flip-back on the touched columns ((tg - x) + x).  So B = 64/GW consecutive proposals are
+// evaluated at once: lane (g, d) = group g, column d.  Group g first replays the residue of proposals 0..g-1
+// (cheap, element-wise), then evaluates proposal t+g on that exact state.  get_lk's left-to-right sum runs as
+// two DPP row scans per group (cluster 0 up the lanes, cluster 1 -- stored mirrored -- down the lanes), all
+// groups in lock step.  If every proposal of the batch is rejected by the guarded f32 Bernoulli test, the state
+// of the last group is broadcast and the chain advances by B steps; the first proposal that is accepted, draws
+// nothing, or cannot be decided without the exact exp ends the batch and is redone as an exact single step.
+// Bit-identical to the one-step-at-a-time chain by construction; checked against the oracle.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = dpp_i32<CTRL>(__double2loint(v)), hi = dpp_i32<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int GW>
+__device__ __forceinline__ double row_shr_by(double v, uint32_t k) {  // lane i <- lane i-k (within a 16-lane row)
+    switch (k) {
+        case 0: return v;
+        case 1: return dpp_f64<0x111>(v);
+        case 2: return dpp_f64<0x112>(v);
+        case 3: return dpp_f64<0x113>(v);
+        case 4: return dpp_f64<0x114>(v);
+        case 5: return dpp_f64<0x115>(v);
+        case 6: return dpp_f64<0x116>(v);
+        case 7: return dpp_f64<0x117>(v);
+        case 8: return dpp_f64<0x118>(v);
+        case 9: return dpp_f64<0x119>(v);
+        case 10: return dpp_f64<0x11A>(v);
+        case 11: return dpp_f64<0x11B>(v);
+        case 12: return dpp_f64<0x11C>(v);
+        case 13: return dpp_f64<0x11D>(v);
+        case 14: return dpp_f64<0x11E>(v);
+        default: return dpp_f64<0x11F>(v);
+    }
+}
+template <int GW>
+__device__ __forceinline__ int mirror_i32(int v) {  // lane d <-> lane GW-1-d inside every group
+    return GW == 8 ? dpp_i32<0x141>(v) : dpp_i32<0x140>(v);  // row_half_mirror / row_mirror
+}
+
+template <int GW>
+__device__ __forceinline__ double mcmc_chain_k2b(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng,
+                                                 uint32_t lane) {
+    constexpr uint32_t B = 64 / GW;
+    const uint32_t d = lane & (GW - 1), g = lane / GW;
+    // pair table: lane c0 holds (0.0 + size_to_lk[c0]) + size_to_lk[n - c0]   (get_lk :788)
+    double pair_lk;
+    {
+        auto size_lk = [&](uint32_t x) {
+            double mx = -__builtin_inf();
+            for (int c = 1; c <= 2; c++) {
+                const double lam = cov * (double)c;
+                mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
+            }
+            return mx;
+        };
+        const uint32_t c0 = lane <= n ? lane : n;
+        pair_lk = (0.0 + size_lk(c0)) + size_lk(n - c0);
+    }
+    if (lane == 0) {
+        lds_st64(&m.ctl->restart_state[0], rng.s0);
+        lds_st64(&m.ctl->restart_state[1], rng.s1);
+        lds_st64(&m.ctl->restart_state[2], rng.s2);
+        lds_st64(&m.ctl->restart_state[3], rng.s3);
+        lds_st32(&m.ctl->restart_seq, 0);
+        lds_st32(&m.ctl->n, n);
+        lds_st32(&m.ctl->k, 2);
+        lds_st32(&m.ctl->consumed, 0);
+        lds_st32(&m.ctl->stop, 0);
+        lds_st32(&m.ctl->gen, 0);
+    }
+    for (uint32_t e = lane; e < QN; e += 64) lds_st64((uint64_t *)&m.queue[e].gen, ~0ull);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();  // A
+    // ---- state, replicated in every group: lane d = column d of cluster 0 and column GW-1-d of cluster 1
+    double tg0 = 0.0, tg1 = 0.0;
+    int np0 = 0, np1 = 0, w0 = 0, w1 = 0;
+    uint32_t c0 = 0;
+    unsigned long long lab = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t c = uni(m.assign[i]);
+        const Elem2 el = m.elem2[i * JTK_GW_MAX + d];
+        if (c == 0) {
+            tg0 += el.x;
+            np0 += el.dp;
+            w0 += el.pw;
+            c0++;
+        } else {
+            tg1 += el.xr;
+            np1 += el.dpr;
+            w1 += el.pwr;
+            lab |= 1ull << i;
+        }
+    }
+    const int totp2 = 2 * (np0 + mirror_i32<GW>(np1));  // 2 x reads with a positive value in column d
+    const bool lead = d == GW - D;                      // the lane of a group where its ordered sum ends
+
+    // Evaluates, for every group at once, the likelihood of the tentative state (T0, T1, P0, P1, W0, W1) with
+    // cluster-0 size nc0 (per lane, constant inside a group).  Result valid on the lead lanes.
+    auto eval = [&](double T0, double T1, int P0, int P1, int W0, int W1, uint32_t nc0) -> double {
+        const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
+        const int u1 = pos1 ? P1 : 0, a1 = (pos1 && W1 > 0) ? 1 : 0;
+        const int in_use = (pos0 ? P0 : 0) + mirror_i32<GW>(u1);
+        const bool any = (pos0 && W0 > 0) || mirror_i32<GW>(a1) != 0;
+        const bool used = any && 3 * in_use > totp2;  // get_used_columns (:847-869) of column d
+        const bool used_r = mirror_i32<GW>(used ? 1 : 0) != 0;
+        const double term0 = (used && pos0) ? T0 : 0.0, term1 = (used_r && pos1) ? T1 : 0.0;
+        // size terms, then cluster 0 columns 0..D-1 (up the lanes), then cluster 1 columns 0..D-1 (down the lanes)
+        const double base = __hiloint2double(__builtin_amdgcn_ds_bpermute((int)(nc0 << 2), __double2hiint(pair_lk)),
+                                             __builtin_amdgcn_ds_bpermute((int)(nc0 << 2), __double2loint(pair_lk)));
+        double acc = d == 0 ? base + term0 : 0.0;
+        for (uint32_t k = 1; k < D; k++) {
+            const double sh = dpp_f64<0x111>(acc);  // row_shr:1
+            acc = d == k ? sh + term0 : acc;
+        }
+        {
+            const double sh = row_shr_by<GW>(acc, GW - D);  // lane D-1 -> lane GW-1
+            acc = d == GW - 1 ? sh + term1 : acc;
+        }
+        for (uint32_t j = 1; j < D; j++) {
+            const double sh = dpp_f64<0x101>(acc);  // row_shl:1
+            acc = d == GW - 1 - j ? sh + term1 : acc;
+        }
+        return acc;
+    };
+    auto bcast_group = [&](double v, uint32_t src_group) -> double {
+        const int src = (int)((src_group * GW + d) << 2);
+        return __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(v)),
+                                __builtin_amdgcn_ds_bpermute(src, __double2loint(v)));
+    };
+    double lk = unif64(readlane_f64(eval(tg0, tg1, np0, np1, w0, w1, c0), GW - D));
+    double max = lk;
+    unsigned long long argmax = lab;
+    const uint32_t total = 2000u * n;
+    uint32_t gen = 0, t = 0;
+    Rng after = rng;
+    typedef __attribute__((address_space(3))) volatile u32x4 lds_cvu128;
+    while (t < total) {
+        // ---------------------------------------------------------------- a batch of rejected-by-default steps
+        const uint32_t remaining = total - 1 - t;  // the final step always takes the exact path below
+        const uint32_t nb = remaining < B ? remaining : B;
+        if (nb >= 2) {
+            // proposals t .. t+nb-1, one per group
+            const uint32_t mine = g < nb ? t + g : t;
+            const QEntry *e = &m.queue[mine & (QN - 1)];
+            u32x4 hd;
+            uint64_t v;
+            for (;;) {
+                hd = *(lds_cvu128 *)e;  // gen, seq, idx, pos
+                v = lds_ld64(&e->v);
+                if (__ballot(hd.x == gen && hd.y == mine) == ~0ull) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const uint32_t idx = hd.z;
+            const Elem2 el = m.elem2[idx * JTK_GW_MAX + d];
+            const bool old = (lab >> idx) & 1ull;
+            // residue of the earlier proposals of this batch: group g replays proposals 0..g-1
+            double s0 = tg0, s1 = tg1;
+            for (uint32_t s = 0; s + 1 < nb; s++) {
+                const uint32_t idx_s = uni((uint32_t)__builtin_amdgcn_readlane((int)idx, (int)(s * GW)));
+                const bool old_s = (lab >> idx_s) & 1ull;
+                const Elem2 es = m.elem2[idx_s * JTK_GW_MAX + d];
+                const double sx = old_s ? -es.x : es.x, sxr = old_s ? -es.xr : es.xr;
+                if (g > s) {
+                    s0 = (s0 - sx) + sx;
+                    s1 = (s1 + sxr) - sxr;
+                }
+            }
+            // tentative flip of the group's own proposal
+            const double sx = old ? -el.x : el.x, sxr = old ? -el.xr : el.xr;
+            const int sdp = old ? -el.dp : el.dp, spw = old ? -el.pw : el.pw;
+            const int sdpr = old ? -el.dpr : el.dpr, spwr = old ? -el.pwr : el.pwr;
+            const double T0 = s0 - sx, T1 = s1 + sxr;
+            const uint32_t nc0 = old ? c0 + 1 : c0 - 1;
+            const double proposed = eval(T0, T1, np0 - sdp, np1 + sdpr, w0 - spw, w1 + spwr, nc0);
+            const double diff = proposed - lk;
+            // per-group decision with the guarded f32 test; anything else is an "event"
+            bool reject = false;
+            if (diff <= -44.4) {
+                reject = true;
+            } else if (diff < -1e-3) {
+                const float u = (float)(uint32_t)(v >> 40) * 0x1p-24f;
+                const float pe = __expf((float)diff);
+                reject = u > pe * 1.001f + 3e-7f;
+            }
+            const unsigned long long eventm = __ballot(lead && g < nb && !reject);
+            const uint32_t n_rej = eventm ? (uint32_t)__builtin_ctzll(eventm) / GW : nb;
+            if (n_rej > 0) {
+                // state after n_rej rejected steps = group (n_rej-1)'s state after its own flip-back
+                const double u0 = T0 + sx, u1 = T1 - sxr;
+                tg0 = bcast_group(u0, n_rej - 1);
+                tg1 = bcast_group(u1, n_rej - 1);
+                t += n_rej;
+                if (lane == 0) lds_st32(&m.ctl->consumed, t);
+            }
+            if (!eventm) continue;
+        }
+        // ---------------------------------------------------------------- one exact step (all groups in unison)
+        {
+            const QEntry *e = &m.queue[t & (QN - 1)];
+            const uint64_t want = ((uint64_t)t << 32) | gen;
+            while (uni64(lds_ld64((const uint64_t *)&e->gen)) != want) __builtin_amdgcn_s_sleep(1);
+            const uint32_t idx = uni((uint32_t)lds_ld64((const uint64_t *)&e->idx));
+            const Elem2 el = m.elem2[idx * JTK_GW_MAX + d];
+            const bool old = (lab >> idx) & 1ull;
+            const double sx = old ? -el.x : el.x, sxr = old ? -el.xr : el.xr;
+            const int sdp = old ? -el.dp : el.dp, spw = old ? -el.pw : el.pw;
+            const int sdpr = old ? -el.dpr : el.dpr, spwr = old ? -el.pwr : el.pwr;
+            const double T0 = tg0 - sx, T1 = tg1 + sxr;
+            const int P0 = np0 - sdp, P1 = np1 + sdpr, W0 = w0 - spw, W1 = w1 + spwr;
+            const uint32_t nc0 = old ? c0 + 1 : c0 - 1;
+            const double proposed = unif64(readlane_f64(eval(T0, T1, P0, P1, W0, W1, nc0), GW - D));
+            const double diff = unif64(proposed - lk);
+            const bool no_draw = ubool(diff >= -0x1p-54);
+            const bool last = t + 1 == total;
+            bool accept = true;
+            if (no_draw || last) {
+                after.s0 = uni64(lds_ld64(&e->s[0]));
+                after.s1 = uni64(lds_ld64(&e->s[1]));
+                after.s2 = uni64(lds_ld64(&e->s[2]));
+                after.s3 = uni64(lds_ld64(&e->s[3]));
+                if (!no_draw) {
+                    accept = bernoulli_exact(uni64(lds_ld64(&e->v)), diff);
+                    (void)next_u64(after);
+                }
+                if (no_draw && !last) {
+                    gen++;
+                    if (lane == 0) {
+                        lds_st64(&m.ctl->restart_state[0], after.s0);
+                        lds_st64(&m.ctl->restart_state[1], after.s1);
+                        lds_st64(&m.ctl->restart_state[2], after.s2);
+                        lds_st64(&m.ctl->restart_state[3], after.s3);
+                        lds_st32(&m.ctl->restart_seq, t + 1);
+                        lds_st32(&m.ctl->consumed, t + 1);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        lds_st32(&m.ctl->gen, gen);
+                    }
+                }
+            } else {
+                accept = bernoulli_exact(uni64(lds_ld64(&e->v)), diff);
+            }
+            if (accept) {
+                tg0 = T0;
+                tg1 = T1;
+                np0 = P0;
+                np1 = P1;
+                w0 = W0;
+                w1 = W1;
+                c0 = nc0;
+                lab ^= 1ull << idx;
+                lk = proposed;
+                if (ubool(max < lk)) {
+                    max = proposed;
+                    argmax = lab;
+                }
+            } else {
+                tg0 = T0 + sx;  // flip back (:746), keeping the rounding residue
+                tg1 = T1 - sxr;
+            }
+            t++;
+            if (!no_draw && (t & 7) == 0 && lane == 0) lds_st32(&m.ctl->consumed, t);
+        }
+    }
+    if (lane == 0) lds_st32(&m.ctl->stop, 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();  // B
+    rng = after;
+    if (lane < n) m.assign[lane] = (uint8_t)((argmax >> lane) & 1ull);
+    wsync();
+    return max;
+}
+
 template <int K>
 __device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
+    // a lane serves column d of cluster 0 and column GW-1-d of cluster 1; only layouts in which no lane carries
+    // both (D <= GW/2) are enabled -- the overlapped layout did not reproduce the oracle and is left out
+    if (K == 2 && n <= 63 && D <= 4) return mcmc_chain_k2b<8>(m, n, D, cov, rng, lane);
+    if (K == 2 && n <= 63 && D <= 8) return mcmc_chain_k2b<16>(m, n, D, cov, rng, lane);
     if (K == 2 && n <= 63) return mcmc_chain_k2(m, n, D, cov, rng, lane);
     if (n <= 63) return mcmc_chain<K, true>(m, n, D, cov, rng, lane);
     return mcmc_chain<K, false>(m, n, D, cov, rng, lane);
@@ -1050,6 +1340,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         };
         m.ctl = (QCtl *)take(sizeof(QCtl));
         m.queue = (QEntry *)take(sizeof(QEntry) * QN);
+        m.elem2 = (Elem2 *)take((size_t)(lds_n < 63 ? lds_n : 63) * JTK_GW_MAX * sizeof(Elem2));
         m.elem = (Elem *)take((size_t)lds_n * lds_d * sizeof(Elem));
         m.data = (double *)take((size_t)lds_n * lds_d * 8);
         m.size_to_lk = (double *)take((size_t)(lds_n + 1) * 8);
@@ -1082,6 +1373,29 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         el.pw = 3 * el.dp - 7 * (x < -JTK_POS_THR ? 1 : 0);
         m.elem[e] = el;
     }
+    if (n <= 63)
+        for (uint32_t e = lane; e < n * JTK_GW_MAX; e += 64) {
+            // lane d of the batched diploid chain: column d for cluster 0, column GW-1-d for cluster 1 (GW = 8 or 16)
+            const uint32_t i = e / JTK_GW_MAX, dd = e % JTK_GW_MAX, gw = D <= 4 ? 8 : 16;
+            const uint32_t dl = dd & (gw - 1);
+            Elem2 q = {0.0, 0.0, 0, 0, 0, 0};
+            if (dd < gw) {
+                if (dl < D) {
+                    const double x = feat[i * D + dl];
+                    q.x = x;
+                    q.dp = JTK_POS_THR < x ? 1 : 0;
+                    q.pw = 3 * q.dp - 7 * (x < -JTK_POS_THR ? 1 : 0);
+                }
+                const uint32_t dr = gw - 1 - dl;
+                if (dr < D) {
+                    const double x = feat[i * D + dr];
+                    q.xr = x;
+                    q.dpr = JTK_POS_THR < x ? 1 : 0;
+                    q.pwr = 3 * q.dpr - 7 * (x < -JTK_POS_THR ? 1 : 0);
+                }
+            }
+            m.elem2[e] = q;
+        }
     // lfact[x] = sum_{c=1..x} ln c, summed left to right as poisson_lk does (:636-638)
     if (lane == 0) {
         double s = 0.0;
@@ -1205,6 +1519,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
     size_t b = al(sizeof(QCtl)) + al(sizeof(QEntry) * QN) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
+               al((size_t)(lds_n < 63 ? lds_n : 63) * JTK_GW_MAX * sizeof(Elem2)) +
                al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) + 2 * al((size_t)JTK_MAX_COPY * lds_d * 8) +
                2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d);
     return b;
