@@ -12,12 +12,10 @@
 // candidate k, local_clustering/mod.rs:97).  A lone wavefront on CDNA4 issues roughly one dependent
 // instruction every 5-7 cycles, so the chain is bound by the instruction count of a step, not by bandwidth.
 // Two things buy speed without changing a single bit of the result:
-//  * PIPELINE: a workgroup is two wavefronts.  Wave 1 ("producer") parses the xoshiro stream into
-//    proposals -- read index, position of the chosen candidate cluster, the u64 the Bernoulli test will
-//    compare, and a snapshot of the generator state -- and hands them to wave 0 ("consumer") through an LDS
-//    ring.  Which draws a proposal consumes does not depend on the chain state, except that an improving
-//    proposal skips the Bernoulli draw (pseudo_mcmc.rs:736); that happens in <2% of the steps, and the
-//    consumer then re-synchronises the producer from the snapshot.
+//  * PIPELINE: a workgroup is two wavefronts.  Wave 1 ("producer") does nothing but run xoshiro256** and
+//    append its raw u64 outputs to an LDS ring; wave 0 ("consumer") runs the algorithm and takes every random
+//    draw -- k-means initialisation, proposals, Bernoulli tests -- from that ring, in stream order.  The stream
+//    itself never depends on the chain, so nothing is ever speculated or rolled back on the producer side.
 //  * A SLIM STEP: lane d keeps LKCount[c][d] of every cluster c in registers (K is a template parameter, so
 //    the cluster index is a static register index); counts are kept as integers (num_pos and 3*num_pos -
 //    7*num_neg, which decides is_informative exactly); a proposal is evaluated on tentative values and then
@@ -30,8 +28,33 @@
 
 namespace {
 
+// ---- LDS accessors for the producer/consumer hand-off.  The pointers reach us as generic pointers; casting
+// them back to the LDS address space makes these ds_read/ds_write instead of waited flat accesses.
+// volatile: re-read every time, in program order (LDS operations of one wave execute in order).
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+typedef __attribute__((address_space(3))) volatile uint64_t lds_vu64;
+__device__ __forceinline__ uint32_t lds_ld32(const uint32_t *p) { return *(lds_vu32 *)p; }
+__device__ __forceinline__ void lds_st32(uint32_t *p, uint32_t v) { *(lds_vu32 *)p = v; }
+__device__ __forceinline__ uint64_t lds_ld64(const uint64_t *p) { return *(lds_vu64 *)p; }
+__device__ __forceinline__ void lds_st64(uint64_t *p, uint64_t v) { *(lds_vu64 *)p = v; }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
+
+// The ring of raw xoshiro256** outputs.  `wr` draws have been produced, the consumer has released `rd`.
+#define RN 512  // draws in the ring (4 KiB)
+struct RCtl {
+    uint32_t rd, quit;  // written by the consumer (read together, 8-byte aligned)
+    uint32_t wr, pad;   // written by the producer
+};
+// The consumer's view of the generator: a position in the stream of Xoshiro256StarStar::seed_from_u64(id * 3490)
+// (local_clustering/mod.rs:97).  next_u64 == rand_xoshiro's next_u64, one stream position later.
 struct Rng {
-    uint64_t s0, s1, s2, s3;
+    uint32_t pos;      // next draw to take (absolute stream position)
+    uint32_t wr_seen;  // producer progress last observed
+    RCtl *ctl;
+    const uint64_t *ring;
 };
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 __device__ __forceinline__ uint64_t splitmix64(uint64_t &x) {
@@ -41,17 +64,21 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t &x) {
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
     return z ^ (z >> 31);
 }
+__device__ __forceinline__ void rng_wait(Rng &r, uint32_t upto) {  // until draws [.., upto) exist
+    while ((int32_t)(r.wr_seen - upto) < 0) {
+        r.wr_seen = uni(lds_ld32(&r.ctl->wr));
+        if ((int32_t)(r.wr_seen - upto) < 0) __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void rng_release(Rng &r, uint32_t lane) {  // draws before r.pos may be overwritten
+    if (lane == 0) lds_st32(&r.ctl->rd, r.pos);
+}
 __device__ __forceinline__ uint64_t next_u64(Rng &r) {
-    const uint64_t m5 = (r.s1 << 2) + r.s1, rr = rotl64(m5, 7);
-    const uint64_t result = (rr << 3) + rr;  // rotl(s1 * 5, 7) * 9
-    const uint64_t t = r.s1 << 17;
-    r.s2 ^= r.s0;
-    r.s3 ^= r.s1;
-    r.s1 ^= r.s2;
-    r.s0 ^= r.s3;
-    r.s2 ^= t;
-    r.s3 = rotl64(r.s3, 45);
-    return result;
+    rng_wait(r, r.pos + 1);
+    const uint64_t v = uni64(lds_ld64(&r.ring[r.pos & (RN - 1)]));
+    r.pos++;
+    if ((r.pos & 63) == 0) lds_st32(&r.ctl->rd, r.pos);  // every lane stores the same value
+    return v;
 }
 __device__ __forceinline__ uint32_t next_u32(Rng &r) { return (uint32_t)(next_u64(r) >> 32); }
 __device__ __forceinline__ uint64_t gen_range_usize(Rng &r, uint64_t n) {
@@ -95,10 +122,6 @@ __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint64_t uni64(uint64_t v) {
-    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
-}
 __device__ __forceinline__ double unif64(double v) { return jtk_bits_f64(uni64(jtk_f64_bits(v))); }
 // a wave-uniform condition as a scalar: branches on it are s_cbranch, not exec-mask regions
 __device__ __forceinline__ bool ubool(bool c) { return uni(c ? 1u : 0u) != 0u; }
@@ -109,19 +132,6 @@ struct Elem {  // one (read, column) cell as the chain needs it
     int dp;    // 1 if x >  POS_THR (counts towards num_pos)
     int pw;    // 3*[x > POS_THR] - 7*[x < -POS_THR]: increment of 3*num_pos - 7*num_neg
 };
-#define QN 64
-struct QEntry {  // 64 B
-    uint32_t gen, seq;  // tag, written last
-    uint32_t idx, j;    // proposed read; position of the chosen cluster among the K-1 candidates
-    uint64_t v;         // the u64 a Bernoulli draw of this step compares
-    uint64_t pad;
-    uint64_t s[4];      // generator state after the proposal draws, before v
-};
-struct QCtl {  // 64 B
-    uint32_t gen, stop, consumed, quit;
-    uint32_t restart_seq, n, k, pad;
-    uint64_t restart_state[4];
-};
 struct Elem2 {  // one (read, lane) cell of the batched diploid chain: lane d serves column d of cluster 0 and
     double x;   // column GW-1-d of cluster 1 (mirrored, so that the ordered sum of get_lk is two DPP row scans)
     double xr;
@@ -129,8 +139,8 @@ struct Elem2 {  // one (read, lane) cell of the batched diploid chain: lane d se
 };
 #define JTK_GW_MAX 16
 struct Lds {
-    QCtl *ctl;
-    QEntry *queue;
+    RCtl *ctl;
+    uint64_t *ring;      // RN raw draws
     Elem2 *elem2;        // min(n, 63) x JTK_GW_MAX
     Elem *elem;          // n x D
     double *data;        // n x D
@@ -394,16 +404,6 @@ __device__ __forceinline__ void lab_set(LaneLabels &a, uint32_t i, uint32_t val,
     }
 }
 
-// ---- LDS accessors for the producer/consumer hand-off.  The pointers reach us as generic pointers (members of
-// struct Lds); casting them back to the LDS address space makes these ds_read/ds_write instead of waited flat
-// accesses.  volatile: re-read every time, in program order (LDS operations of one wave execute in order).
-typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
-typedef __attribute__((address_space(3))) volatile uint64_t lds_vu64;
-__device__ __forceinline__ uint32_t lds_ld32(const uint32_t *p) { return *(lds_vu32 *)p; }
-__device__ __forceinline__ void lds_st32(uint32_t *p, uint32_t v) { *(lds_vu32 *)p = v; }
-__device__ __forceinline__ uint64_t lds_ld64(const uint64_t *p) { return *(lds_vu64 *)p; }
-__device__ __forceinline__ void lds_st64(uint64_t *p, uint64_t v) { *(lds_vu64 *)p = v; }
-
 // Position (0-based among the K-1 candidates) that `(0..K).filter(|c| c != old).choose(rng)` selects
 // (pseudo_mcmc.rs:732): the i-th yielded candidate replaces the pick iff gen_index(i) == 0, whatever `old` is.
 __device__ __forceinline__ uint32_t choose_pos(Rng &r, uint32_t k) {
@@ -413,53 +413,43 @@ __device__ __forceinline__ uint32_t choose_pos(Rng &r, uint32_t k) {
     return pos;
 }
 
-// The producer wave: turns the generator stream into proposals, assuming every step draws its Bernoulli
-// value; re-synchronised by the consumer (ctl->gen) whenever a step did not.  A lone wave issues about one
-// instruction per 4-5 cycles, so this loop is written for instruction count: the control block is read with
-// one 128-bit LDS load per iteration (issued before the draws, looked at after them), an entry is four
-// 128-bit stores, the tag-carrying one last (LDS operations of a wave complete in order).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) volatile u32x4 lds_vu128;
-__device__ __forceinline__ void producer_main(QCtl *ctl, QEntry *queue, uint32_t lane) {
+// The producer wave: Xoshiro256StarStar::seed_from_u64(seed), free running into the ring.  A lone wave issues
+// about one instruction per 4-5 cycles, so the loop is written for instruction count: the scalar unit only advances
+// the 256-bit state (9 instructions per draw) and parks s[1] of 32 consecutive steps in lanes 0..31; the output
+// function rotl(s1 * 5, 7) * 9 of all 32 draws is then evaluated at once on the vector unit and stored with one
+// ds_write_b64.
+#define PBATCH 32
+__device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint64_t seed, uint32_t lane) {
+    uint64_t x = seed;
+    uint64_t s0 = splitmix64(x), s1 = splitmix64(x), s2 = splitmix64(x), s3 = splitmix64(x);
+    uint32_t wr = 0;
     for (;;) {
-        __syncthreads();  // A: a chain has been armed (or the kernel is done)
-        if (uni(lds_ld32(&ctl->quit))) return;
-        const uint32_t n = uni(lds_ld32(&ctl->n)), k = uni(lds_ld32(&ctl->k));
-        Rng r;
-        r.s0 = r.s1 = r.s2 = r.s3 = 0;
-        uint32_t seq = 0, gen_seen = 0xffffffffu;
-        for (;;) {
-            const u32x4 c = *(lds_vu128 *)ctl;  // gen, stop, consumed, quit
-            const uint32_t g = uni(c.x);
-            if (uni(c.y)) break;
-            if (g != gen_seen) {
-                r.s0 = uni64(lds_ld64(&ctl->restart_state[0]));
-                r.s1 = uni64(lds_ld64(&ctl->restart_state[1]));
-                r.s2 = uni64(lds_ld64(&ctl->restart_state[2]));
-                r.s3 = uni64(lds_ld64(&ctl->restart_state[3]));
-                seq = uni(lds_ld32(&ctl->restart_seq));
-                // the restart record is only stable if gen did not move while we read it
-                if (uni(lds_ld32(&ctl->gen)) != g) continue;
-                gen_seen = g;
-            }
-            if ((int32_t)(seq - uni(c.z)) >= QN) {
-                __builtin_amdgcn_s_sleep(2);
-                continue;
-            }
-            const uint32_t idx = (uint32_t)gen_range_usize(r, n);
-            const uint32_t pos = choose_pos(r, k);
-            const Rng snap = r;
-            const uint64_t v = next_u64(r);
-            lds_vu128 *e = (lds_vu128 *)&queue[seq & (QN - 1)];
-            if (lane == 0) {
-                e[2] = u32x4{(uint32_t)snap.s0, (uint32_t)(snap.s0 >> 32), (uint32_t)snap.s1, (uint32_t)(snap.s1 >> 32)};
-                e[3] = u32x4{(uint32_t)snap.s2, (uint32_t)(snap.s2 >> 32), (uint32_t)snap.s3, (uint32_t)(snap.s3 >> 32)};
-                e[1] = u32x4{(uint32_t)v, (uint32_t)(v >> 32), 0u, 0u};
-                e[0] = u32x4{g, seq, idx, pos};  // tag last
-            }
-            seq++;
+        const uint64_t c = uni64(lds_ld64((const uint64_t *)&ctl->rd));  // rd, quit
+        if ((uint32_t)(c >> 32)) return;
+        if ((int32_t)(wr + PBATCH - (uint32_t)c) > RN) {
+            __builtin_amdgcn_s_sleep(2);
+            continue;
         }
-        __syncthreads();  // B: chain finished
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < PBATCH; i++) {
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((uint32_t)s1), "n"(i));
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((uint32_t)(s1 >> 32)), "n"(i));
+            const uint64_t t = s1 << 17;
+            s2 ^= s0;
+            s3 ^= s1;
+            s1 ^= s2;
+            s0 ^= s3;
+            s2 ^= t;
+            s3 = rotl64(s3, 45);
+        }
+        const uint64_t s1v = ((uint64_t)hi << 32) | lo;  // lane i: s[1] before step wr + i
+        const uint64_t m5 = (s1v << 2) + s1v, rr = rotl64(m5, 7);
+        const uint64_t result = (rr << 3) + rr;  // rotl(s1 * 5, 7) * 9
+        if (lane < PBATCH) lds_st64(&ring[(wr + lane) & (RN - 1)], result);
+        wr += PBATCH;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) lds_st32(&ctl->wr, wr);
     }
 }
 
@@ -478,8 +468,8 @@ __device__ __forceinline__ bool bernoulli_exact(uint64_t v, double diff) {
     return v < uni64(__double2ull_rz(scaled));
 }
 
-// mcmc_with_filter (:704-762). m.assign holds the k-means labels on entry, the best-seen labels on exit.
-// Runs on the consumer wave; the producer wave feeds it proposals.
+// mcmc_with_filter (:704-762), generic in K.  m.assign holds the k-means labels on entry, the best-seen labels
+// on exit.  One proposal per iteration; used for K > 2 and for pile-ups the batched diploid path does not take.
 template <int K, bool SMALL>
 __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
     // size_to_lk[x] = max_{c=1..K} poisson_lk(x, cov*c)
@@ -495,22 +485,6 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
             }
         size_to_lk.v[r] = mx;
     }
-    // ---- arm the producer
-    if (lane == 0) {
-        lds_st64(&m.ctl->restart_state[0], rng.s0);
-        lds_st64(&m.ctl->restart_state[1], rng.s1);
-        lds_st64(&m.ctl->restart_state[2], rng.s2);
-        lds_st64(&m.ctl->restart_state[3], rng.s3);
-        lds_st32(&m.ctl->restart_seq, 0);
-        lds_st32(&m.ctl->n, n);
-        lds_st32(&m.ctl->k, K);
-        lds_st32(&m.ctl->consumed, 0);
-        lds_st32(&m.ctl->stop, 0);
-        lds_st32(&m.ctl->gen, 0);
-    }
-    for (uint32_t e = lane; e < QN; e += 64) lds_st64((uint64_t *)&m.queue[e].gen, ~0ull);  // no valid tag
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();  // A
     // ---- initial LKCounts in the reference's order (reads outer)
     double tg[K];
     int np[K], w[K], cl[K];
@@ -580,18 +554,11 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
     double lk = get_lk(tg, np, cl, posm, infm);
     double max = lk;
     const uint32_t total = 2000u * n;
-    uint32_t gen = 0;
-    Rng after = rng;  // generator state after the last step
     for (uint32_t t = 0; t < total; t++) {
-        // ---- proposal t from the producer
-        const QEntry *e = &m.queue[t & (QN - 1)];
-        const uint64_t want = ((uint64_t)t << 32) | gen;
-        while (uni64(lds_ld64((const uint64_t *)&e->gen)) != want) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint64_t ij = uni64(lds_ld64((const uint64_t *)&e->idx));
-        const uint32_t idx = (uint32_t)ij, pos = (uint32_t)(ij >> 32);
+        const uint32_t idx = (uint32_t)gen_range_usize(rng, n);
         const uint32_t old = lab_get<SMALL>(assign, idx);
-        const uint32_t nw = K == 2 ? 1u - old : (pos < old ? pos : pos + 1);
+        const uint32_t pos = choose_pos(rng, K);
+        const uint32_t nw = pos < old ? pos : pos + 1;
         Elem el = {0.0, 0, 0};
         if (lane < D) el = m.elem[idx * D + lane];
         // ---- tentative flip (:764-783): only the two touched clusters change
@@ -626,40 +593,10 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
         }
         const double proposed = get_lk(T, P, ncl, npm, nim);
         const double diff = unif64(proposed - lk);
-        // gen_bool(1.0) draws nothing, and exp(diff) == 1.0 exactly when diff >= -2^-54
-        const bool no_draw = ubool(diff >= -0x1p-54);
+        // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
+        // exactly when diff >= -2^-54
         bool accept = true;
-        if (no_draw) {
-            // the producer assumed a draw: re-synchronise it from the state before that draw
-            after.s0 = uni64(lds_ld64(&e->s[0]));
-            after.s1 = uni64(lds_ld64(&e->s[1]));
-            after.s2 = uni64(lds_ld64(&e->s[2]));
-            after.s3 = uni64(lds_ld64(&e->s[3]));
-            if (t + 1 < total) {
-                gen++;
-                if (lane == 0) {
-                    lds_st64(&m.ctl->restart_state[0], after.s0);
-                    lds_st64(&m.ctl->restart_state[1], after.s1);
-                    lds_st64(&m.ctl->restart_state[2], after.s2);
-                    lds_st64(&m.ctl->restart_state[3], after.s3);
-                    lds_st32(&m.ctl->restart_seq, t + 1);
-                    lds_st32(&m.ctl->consumed, t + 1);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    lds_st32(&m.ctl->gen, gen);
-                }
-            }
-        } else {
-            accept = bernoulli_exact(uni64(lds_ld64(&e->v)), diff);
-            if (t + 1 == total) {
-                after.s0 = uni64(lds_ld64(&e->s[0]));
-                after.s1 = uni64(lds_ld64(&e->s[1]));
-                after.s2 = uni64(lds_ld64(&e->s[2]));
-                after.s3 = uni64(lds_ld64(&e->s[3]));
-                (void)next_u64(after);
-            } else if ((t & 15) == 15 && lane == 0) {
-                lds_st32(&m.ctl->consumed, t + 1);
-            }
-        }
+        if (!ubool(diff >= -0x1p-54)) accept = bernoulli_exact(next_u64(rng), diff);
         if (accept) {
 #pragma unroll
             for (int c = 0; c < K; c++) {
@@ -685,10 +622,7 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
             }
         }
     }
-    if (lane == 0) lds_st32(&m.ctl->stop, 1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();  // B
-    rng = after;
+    wsync();
 #pragma unroll
     for (int r = 0; r < (SMALL ? 1 : 4); r++) {
         const uint32_t i = lane + 64 * r;
@@ -698,199 +632,8 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
     return max;
 }
 
-// The same chain specialised for the diploid case (K == 2, n <= 63): labels are one scalar bitmask, the two
-// cluster sizes are (c0, n - c0) so the size term is one table entry, the flip is a sign change, and the next
-// proposal and its feature row are fetched from LDS one step ahead.  Same arithmetic, same order.
-__device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng,
-                                                uint32_t lane) {
-    // pair table: lane c0 holds (0.0 + size_to_lk[c0]) + size_to_lk[n - c0]   (get_lk :788, clusters in order)
-    double pair_lk;
-    {
-        auto size_lk = [&](uint32_t x) {
-            double mx = -__builtin_inf();
-            for (int c = 1; c <= 2; c++) {
-                const double lam = cov * (double)c;
-                mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
-            }
-            return mx;
-        };
-        const uint32_t c0 = lane <= n ? lane : n;
-        pair_lk = (0.0 + size_lk(c0)) + size_lk(n - c0);
-    }
-    if (lane == 0) {
-        lds_st64(&m.ctl->restart_state[0], rng.s0);
-        lds_st64(&m.ctl->restart_state[1], rng.s1);
-        lds_st64(&m.ctl->restart_state[2], rng.s2);
-        lds_st64(&m.ctl->restart_state[3], rng.s3);
-        lds_st32(&m.ctl->restart_seq, 0);
-        lds_st32(&m.ctl->n, n);
-        lds_st32(&m.ctl->k, 2);
-        lds_st32(&m.ctl->consumed, 0);
-        lds_st32(&m.ctl->stop, 0);
-        lds_st32(&m.ctl->gen, 0);
-    }
-    for (uint32_t e = lane; e < QN; e += 64) lds_st64((uint64_t *)&m.queue[e].gen, ~0ull);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();  // A
-    double tg0 = 0.0, tg1 = 0.0;
-    int np0 = 0, np1 = 0, w0 = 0, w1 = 0;
-    uint32_t c0 = 0;
-    unsigned long long lab = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t c = uni(m.assign[i]);
-        Elem el = {0.0, 0, 0};
-        if (lane < D) el = m.elem[i * D + lane];
-        if (c == 0) {
-            tg0 += el.x;
-            np0 += el.dp;
-            w0 += el.pw;
-            c0++;
-        } else {
-            tg1 += el.x;
-            np1 += el.dp;
-            w1 += el.pw;
-            lab |= 1ull << i;
-        }
-    }
-    const int totp2 = 2 * (np0 + np1);
-    const unsigned long long colm = (1ull << D) - 1ull;  // D <= JTK_MAX_DIM < 64
-    unsigned long long pm0 = __ballot(0.0 < tg0) & colm, pm1 = __ballot(0.0 < tg1) & colm;
-    unsigned long long im0 = __ballot(w0 > 0), im1 = __ballot(w1 > 0);
-    auto get_lk2 = [&](double T0, double T1, int P0, int P1, uint32_t cc0, unsigned long long a0, unsigned long long a1,
-                       unsigned long long b0, unsigned long long b1) -> double {
-        double S = readlane_f64(pair_lk, cc0);
-        const int in_use = ((0.0 < T0) ? P0 : 0) + ((0.0 < T1) ? P1 : 0);
-        const unsigned long long usedm = __ballot(3 * in_use > totp2) & ((a0 & b0) | (a1 & b1));
-        unsigned long long mm = usedm & a0;
-        while (mm) {
-            const uint32_t d = (uint32_t)__builtin_ctzll(mm);
-            mm &= mm - 1;
-            S += readlane_f64(T0, d);
-        }
-        mm = usedm & a1;
-        while (mm) {
-            const uint32_t d = (uint32_t)__builtin_ctzll(mm);
-            mm &= mm - 1;
-            S += readlane_f64(T1, d);
-        }
-        return S;
-    };
-    double lk = get_lk2(tg0, tg1, np0, np1, c0, pm0, pm1, im0, im1);
-    double max = lk;
-    unsigned long long argmax = lab;
-    const uint32_t total = 2000u * n;
-    uint32_t gen = 0;
-    Rng after = rng;
-    typedef __attribute__((address_space(3))) const volatile uint64_t *lds_cp64;
-    // fetch of proposal t: tag+idx words and v; validated (spinning if the producer is behind)
-    auto fetch = [&](uint32_t t, uint32_t &idx, uint64_t &v) {
-        const QEntry *e = &m.queue[t & (QN - 1)];
-        const uint64_t want = ((uint64_t)t << 32) | gen;
-        for (;;) {
-            const uint64_t tag = lds_ld64((const uint64_t *)&e->gen);
-            const uint64_t ij = lds_ld64((const uint64_t *)&e->idx);
-            const uint64_t vv = lds_ld64(&e->v);
-            if (uni64(tag) == want) {
-                idx = uni((uint32_t)ij);
-                v = uni64(vv);
-                return;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    };
-    uint32_t idx;
-    uint64_t v;
-    fetch(0, idx, v);
-    Elem el = {0.0, 0, 0};
-    if (lane < D) el = m.elem[idx * D + lane];
-    for (uint32_t t = 0; t < total; t++) {
-        const uint32_t old = (uint32_t)(lab >> idx) & 1u;
-        // tentative flip: cluster `old` loses the read, the other one gains it
-        const double sx = old ? -el.x : el.x;
-        const int sdp = old ? -el.dp : el.dp, spw = old ? -el.pw : el.pw;
-        const double T0 = tg0 - sx, T1 = tg1 + sx;
-        const int P0 = np0 - sdp, P1 = np1 + sdp, W0 = w0 - spw, W1 = w1 + spw;
-        const uint32_t nc0 = old ? c0 + 1 : c0 - 1;
-        const unsigned long long a0 = __ballot(0.0 < T0) & colm, a1 = __ballot(0.0 < T1) & colm;
-        const unsigned long long b0 = __ballot(W0 > 0), b1 = __ballot(W1 > 0);
-        const double proposed = get_lk2(T0, T1, P0, P1, nc0, a0, a1, b0, b1);
-        const double diff = unif64(proposed - lk);
-        const bool no_draw = ubool(diff >= -0x1p-54);
-        const bool last = t + 1 == total;
-        bool accept = true;
-        const uint32_t cur_idx = idx;
-        const Elem cur = el;
-        if (no_draw || last) {
-            const QEntry *e = &m.queue[t & (QN - 1)];
-            after.s0 = uni64(lds_ld64(&e->s[0]));
-            after.s1 = uni64(lds_ld64(&e->s[1]));
-            after.s2 = uni64(lds_ld64(&e->s[2]));
-            after.s3 = uni64(lds_ld64(&e->s[3]));
-            if (!no_draw) {
-                accept = bernoulli_exact(v, diff);
-                (void)next_u64(after);
-            }
-            if (no_draw && !last) {
-                gen++;
-                if (lane == 0) {
-                    lds_st64(&m.ctl->restart_state[0], after.s0);
-                    lds_st64(&m.ctl->restart_state[1], after.s1);
-                    lds_st64(&m.ctl->restart_state[2], after.s2);
-                    lds_st64(&m.ctl->restart_state[3], after.s3);
-                    lds_st32(&m.ctl->restart_seq, t + 1);
-                    lds_st32(&m.ctl->consumed, t + 1);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    lds_st32(&m.ctl->gen, gen);
-                }
-            }
-        } else {
-            accept = bernoulli_exact(v, diff);
-            if ((t & 15) == 15 && lane == 0) lds_st32(&m.ctl->consumed, t + 1);
-        }
-        // next proposal and its feature row (LDS latency overlaps the commit/undo below)
-        if (!last) {
-            fetch(t + 1, idx, v);
-            el.x = 0.0;
-            el.dp = 0;
-            el.pw = 0;
-            if (lane < D) el = m.elem[idx * D + lane];
-        }
-        if (accept) {
-            tg0 = T0;
-            tg1 = T1;
-            np0 = P0;
-            np1 = P1;
-            w0 = W0;
-            w1 = W1;
-            c0 = nc0;
-            pm0 = a0;
-            pm1 = a1;
-            im0 = b0;
-            im1 = b1;
-            lab ^= 1ull << cur_idx;
-            lk = proposed;
-            if (ubool(max < lk)) {
-                max = proposed;
-                argmax = lab;
-            }
-        } else {
-            // flip back (:746): re-add / re-subtract, keeping the reference's rounding residue
-            const double ux = old ? -cur.x : cur.x;
-            tg0 = T0 + ux;
-            tg1 = T1 - ux;
-        }
-    }
-    if (lane == 0) lds_st32(&m.ctl->stop, 1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();  // B
-    rng = after;
-    if (lane < n) m.assign[lane] = (uint8_t)((argmax >> lane) & 1ull);
-    wsync();
-    return max;
-}
-
 // ------------------------------------------------------------------------------------------------------
-// Lane-time batching of the diploid chain (K == 2, n <= 63, D <= GW).
+// Lane-time batching of the diploid chain (K == 2, n <= 63, D <= GW/2).
 //
 // More than 96% of the proposals are rejected, and a rejected step changes the state only by the rounding
 // residue of flip + flip-back on the touched columns ((tg - x) + x).  So B = 64/GW consecutive proposals are
@@ -900,6 +643,10 @@ __device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32
 // groups in lock step.  If every proposal of the batch is rejected by the guarded f32 Bernoulli test, the state
 // of the last group is broadcast and the chain advances by B steps; the first proposal that is accepted, draws
 // nothing, or cannot be decided without the exact exp ends the batch and is redone as an exact single step.
+//
+// Proposals are parsed from a 64-draw window of the raw stream held one draw per lane: the widening-multiply
+// acceptance of gen_range(0..n) and the top-bit acceptance of gen_index(1) are evaluated for all 64 draws at
+// once, and "next accepted draw at or after p" is a ballot + s_ff1 -- no rejection loops.
 // Bit-identical to the one-step-at-a-time chain by construction; checked against the oracle.
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) {
@@ -936,6 +683,39 @@ __device__ __forceinline__ int mirror_i32(int v) {  // lane d <-> lane GW-1-d in
     return GW == 8 ? dpp_i32<0x141>(v) : dpp_i32<0x140>(v);  // row_half_mirror / row_mirror
 }
 
+// The parser's view of 64 consecutive raw draws (lane l holds the draw at stream position base + l).  Every lane
+// also holds the proposal that WOULD start at its draw: gen_range(0..n) takes the first draw at or after it whose
+// widening multiply is accepted, gen_index(1) (the single candidate of K == 2, pseudo_mcmc.rs:732) then takes
+// draws until one has a clear top bit, and the next draw is the one a Bernoulli test would compare.
+struct Window {
+    uint32_t base;
+    uint32_t nxt;   // per lane: window offset of the following proposal (Bernoulli draw taken), 255 = does not fit
+    uint32_t idx;   // per lane: the read index the proposal starting here picks
+    uint64_t v;     // per lane: the draw its Bernoulli test compares
+};
+__device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t base, uint32_t n, uint32_t lane) {
+    rng.pos = base;
+    rng_release(rng, lane);
+    rng_wait(rng, base + 64);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wd.base = base;
+    const uint64_t draw = lds_ld64(&rng.ring[(base + lane) & (RN - 1)]);
+    const uint64_t zone = ((uint64_t)n << __clzll((long long)n)) - 1;
+    const uint32_t hi = (uint32_t)__umul64hi(draw, (uint64_t)n);
+    const unsigned long long okm = __ballot(draw * (uint64_t)n <= zone);  // gen_range(0..n) accepts this draw
+    const unsigned long long topm = __ballot((int64_t)draw >= 0);          // gen_index(1) accepts this draw
+    const unsigned long long m1 = okm >> lane;
+    const uint32_t pi = lane + (uint32_t)__builtin_ctzll(m1 | (1ull << 63));
+    const unsigned long long m2 = pi < 63 ? topm >> (pi + 1) : 0ull;
+    const uint32_t pv = pi + 1 + (uint32_t)__builtin_ctzll(m2 | (1ull << 63)) + 1;
+    const bool fits = m1 != 0 && m2 != 0 && pv < 64;
+    wd.idx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pi & 63) << 2), (int)hi);
+    const uint32_t vlo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pv & 63) << 2), (int)(uint32_t)draw);
+    const uint32_t vhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pv & 63) << 2), (int)(uint32_t)(draw >> 32));
+    wd.v = ((uint64_t)vhi << 32) | vlo;
+    wd.nxt = fits ? pv + 1 : 255u;
+}
+
 template <int GW>
 __device__ __forceinline__ double mcmc_chain_k2b(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng,
                                                  uint32_t lane) {
@@ -955,21 +735,6 @@ __device__ __forceinline__ double mcmc_chain_k2b(const Lds &m, uint32_t n, uint3
         const uint32_t c0 = lane <= n ? lane : n;
         pair_lk = (0.0 + size_lk(c0)) + size_lk(n - c0);
     }
-    if (lane == 0) {
-        lds_st64(&m.ctl->restart_state[0], rng.s0);
-        lds_st64(&m.ctl->restart_state[1], rng.s1);
-        lds_st64(&m.ctl->restart_state[2], rng.s2);
-        lds_st64(&m.ctl->restart_state[3], rng.s3);
-        lds_st32(&m.ctl->restart_seq, 0);
-        lds_st32(&m.ctl->n, n);
-        lds_st32(&m.ctl->k, 2);
-        lds_st32(&m.ctl->consumed, 0);
-        lds_st32(&m.ctl->stop, 0);
-        lds_st32(&m.ctl->gen, 0);
-    }
-    for (uint32_t e = lane; e < QN; e += 64) lds_st64((uint64_t *)&m.queue[e].gen, ~0ull);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();  // A
     // ---- state, replicated in every group: lane d = column d of cluster 0 and column GW-1-d of cluster 1
     double tg0 = 0.0, tg1 = 0.0;
     int np0 = 0, np1 = 0, w0 = 0, w1 = 0;
@@ -995,7 +760,8 @@ __device__ __forceinline__ double mcmc_chain_k2b(const Lds &m, uint32_t n, uint3
 
     // Evaluates, for every group at once, the likelihood of the tentative state (T0, T1, P0, P1, W0, W1) with
     // cluster-0 size nc0 (per lane, constant inside a group).  Result valid on the lead lanes.
-    auto eval = [&](double T0, double T1, int P0, int P1, int W0, int W1, uint32_t nc0) -> double {
+    // `base` = the size term of get_lk for the group's cluster-0 size (c0 - 1 or c0 + 1, or c0 itself)
+    auto eval = [&](double T0, double T1, int P0, int P1, int W0, int W1, double base) -> double {
         const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
         const int u1 = pos1 ? P1 : 0, a1 = (pos1 && W1 > 0) ? 1 : 0;
         const int in_use = (pos0 ? P0 : 0) + mirror_i32<GW>(u1);
@@ -1004,21 +770,16 @@ __device__ __forceinline__ double mcmc_chain_k2b(const Lds &m, uint32_t n, uint3
         const bool used_r = mirror_i32<GW>(used ? 1 : 0) != 0;
         const double term0 = (used && pos0) ? T0 : 0.0, term1 = (used_r && pos1) ? T1 : 0.0;
         // size terms, then cluster 0 columns 0..D-1 (up the lanes), then cluster 1 columns 0..D-1 (down the lanes)
-        const double base = __hiloint2double(__builtin_amdgcn_ds_bpermute((int)(nc0 << 2), __double2hiint(pair_lk)),
-                                             __builtin_amdgcn_ds_bpermute((int)(nc0 << 2), __double2loint(pair_lk)));
-        double acc = d == 0 ? base + term0 : 0.0;
-        for (uint32_t k = 1; k < D; k++) {
-            const double sh = dpp_f64<0x111>(acc);  // row_shr:1
-            acc = d == k ? sh + term0 : acc;
-        }
-        {
-            const double sh = row_shr_by<GW>(acc, GW - D);  // lane D-1 -> lane GW-1
-            acc = d == GW - 1 ? sh + term1 : acc;
-        }
-        for (uint32_t j = 1; j < D; j++) {
-            const double sh = dpp_f64<0x101>(acc);  // row_shl:1
-            acc = d == GW - 1 - j ? sh + term1 : acc;
-        }
+        // Select-free scans: acc <- shift(acc) + term on every lane.  A lane whose chain value is final recomputes the
+        // same value each step; with D <= GW/2 nothing non-zero can reach a chain's first lane from outside
+        // (the neighbouring lanes hold zero terms and the chains are shorter than the distance to them).
+        const double t0f = d == 0 ? base + term0 : term0;  // (size terms + first column) is the reference's first add
+        double acc = t0f;
+        for (uint32_t k = 1; k < D; k++) acc = dpp_f64<0x111>(acc) + t0f;  // row_shr:1
+        const double jump = row_shr_by<GW>(acc, GW - D);                    // lane D-1 -> lane GW-1
+        const double t1f = d == GW - 1 ? jump + term1 : term1;
+        acc = t1f;
+        for (uint32_t j = 1; j < D; j++) acc = dpp_f64<0x101>(acc) + t1f;  // row_shl:1
         return acc;
     };
     auto bcast_group = [&](double v, uint32_t src_group) -> double {
@@ -1026,143 +787,146 @@ __device__ __forceinline__ double mcmc_chain_k2b(const Lds &m, uint32_t n, uint3
         return __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(v)),
                                 __builtin_amdgcn_ds_bpermute(src, __double2loint(v)));
     };
-    double lk = unif64(readlane_f64(eval(tg0, tg1, np0, np1, w0, w1, c0), GW - D));
+    double lk = unif64(readlane_f64(eval(tg0, tg1, np0, np1, w0, w1, readlane_f64(pair_lk, c0)), GW - D));
     double max = lk;
     unsigned long long argmax = lab;
     const uint32_t total = 2000u * n;
-    uint32_t gen = 0, t = 0;
-    Rng after = rng;
-    typedef __attribute__((address_space(3))) volatile u32x4 lds_cvu128;
+    uint32_t t = 0;
+    Window wd;
+    window_load(wd, rng, rng.pos, n, lane);
+    uint32_t p = 0;  // parse position inside the window
     while (t < total) {
         // ---------------------------------------------------------------- a batch of rejected-by-default steps
-        const uint32_t remaining = total - 1 - t;  // the final step always takes the exact path below
-        const uint32_t nb = remaining < B ? remaining : B;
-        if (nb >= 2) {
-            // proposals t .. t+nb-1, one per group
-            const uint32_t mine = g < nb ? t + g : t;
-            const QEntry *e = &m.queue[mine & (QN - 1)];
-            u32x4 hd;
-            uint64_t v;
-            for (;;) {
-                hd = *(lds_cvu128 *)e;  // gen, seq, idx, pos
-                v = lds_ld64(&e->v);
-                if (__ballot(hd.x == gen && hd.y == mine) == ~0ull) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            const uint32_t idx = hd.z;
-            const Elem2 el = m.elem2[idx * JTK_GW_MAX + d];
-            const bool old = (lab >> idx) & 1ull;
-            // residue of the earlier proposals of this batch: group g replays proposals 0..g-1
-            double s0 = tg0, s1 = tg1;
-            for (uint32_t s = 0; s + 1 < nb; s++) {
-                const uint32_t idx_s = uni((uint32_t)__builtin_amdgcn_readlane((int)idx, (int)(s * GW)));
-                const bool old_s = (lab >> idx_s) & 1ull;
-                const Elem2 es = m.elem2[idx_s * JTK_GW_MAX + d];
-                const double sx = old_s ? -es.x : es.x, sxr = old_s ? -es.xr : es.xr;
-                if (g > s) {
-                    s0 = (s0 - sx) + sx;
-                    s1 = (s1 + sxr) - sxr;
-                }
-            }
-            // tentative flip of the group's own proposal
-            const double sx = old ? -el.x : el.x, sxr = old ? -el.xr : el.xr;
-            const int sdp = old ? -el.dp : el.dp, spw = old ? -el.pw : el.pw;
-            const int sdpr = old ? -el.dpr : el.dpr, spwr = old ? -el.pwr : el.pwr;
-            const double T0 = s0 - sx, T1 = s1 + sxr;
-            const uint32_t nc0 = old ? c0 + 1 : c0 - 1;
-            const double proposed = eval(T0, T1, np0 - sdp, np1 + sdpr, w0 - spw, w1 + spwr, nc0);
-            const double diff = proposed - lk;
-            // per-group decision with the guarded f32 test; anything else is an "event"
-            bool reject = false;
-            if (diff <= -44.4) {
-                reject = true;
-            } else if (diff < -1e-3) {
-                const float u = (float)(uint32_t)(v >> 40) * 0x1p-24f;
-                const float pe = __expf((float)diff);
-                reject = u > pe * 1.001f + 3e-7f;
-            }
-            const unsigned long long eventm = __ballot(lead && g < nb && !reject);
-            const uint32_t n_rej = eventm ? (uint32_t)__builtin_ctzll(eventm) / GW : nb;
-            if (n_rej > 0) {
-                // state after n_rej rejected steps = group (n_rej-1)'s state after its own flip-back
-                const double u0 = T0 + sx, u1 = T1 - sxr;
-                tg0 = bcast_group(u0, n_rej - 1);
-                tg1 = bcast_group(u1, n_rej - 1);
-                t += n_rej;
-                if (lane == 0) lds_st32(&m.ctl->consumed, t);
-            }
-            if (!eventm) continue;
+        uint32_t nb = total - t < B ? total - t : B;
+        if (p > 24) {  // keep at least ~8 proposals' worth of draws ahead
+            window_load(wd, rng, wd.base + p, n, lane);
+            p = 0;
         }
-        // ---------------------------------------------------------------- one exact step (all groups in unison)
+        // the next nb proposals: follow nxt[] from p; group j takes the proposal that starts at start[j]
+        uint32_t pend[B], src = 0;
+        uint32_t q = p, parsed = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < B; j++) {
+            pend[j] = q;
+            if (j < nb && parsed == j && q < 64) {
+                const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)wd.nxt, (int)q);
+                if (nx != 255u) {
+                    if (g == j) src = q;
+                    q = nx;
+                    pend[j] = q;
+                    parsed = j + 1;
+                }
+            }
+        }
+        if (parsed == 0) {  // not even one proposal fits: move the window
+            window_load(wd, rng, wd.base + p, n, lane);
+            p = 0;
+            continue;
+        }
+        nb = parsed;
+        if (g >= nb) src = p;  // idle groups shadow proposal 0 (their results are ignored)
+        const uint32_t idx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)wd.idx);
+        const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)(uint32_t)(wd.v >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)(uint32_t)wd.v);
+        const Elem2 el = m.elem2[idx * JTK_GW_MAX + d];
+        const bool old = (lab >> idx) & 1ull;
+        // residue of the earlier proposals of this batch: group g replays proposals 0..g-1.  All operands are
+        // fetched first (independent LDS reads in flight together), then the short dependent f64 chain runs.
+        double rx[B], rxr[B];
+#pragma unroll
+        for (uint32_t s = 0; s + 1 < B; s++) {
+            const uint32_t idx_s = uni((uint32_t)__builtin_amdgcn_readlane((int)idx, (int)(s * GW)));
+            const bool old_s = (lab >> idx_s) & 1ull;
+            const Elem2 *es = &m.elem2[idx_s * JTK_GW_MAX + d];
+            const double ex = es->x, exr = es->xr;
+            rx[s] = old_s ? -ex : ex;
+            rxr[s] = old_s ? -exr : exr;
+        }
+        double s0 = tg0, s1 = tg1;
+#pragma unroll
+        for (uint32_t s = 0; s + 1 < B; s++)
+            if (s + 1 < nb && g > s) {
+                s0 = (s0 - rx[s]) + rx[s];
+                s1 = (s1 + rxr[s]) - rxr[s];
+            }
+        // tentative flip of the group's own proposal
+        const double sx = old ? -el.x : el.x, sxr = old ? -el.xr : el.xr;
+        const int sdp = old ? -el.dp : el.dp, spw = old ? -el.pw : el.pw;
+        const int sdpr = old ? -el.dpr : el.dpr, spwr = old ? -el.pwr : el.pwr;
+        const double T0 = s0 - sx, T1 = s1 + sxr;
+        const int P0 = np0 - sdp, P1 = np1 + sdpr, W0 = w0 - spw, W1 = w1 + spwr;
+        // size term for cluster-0 size c0 + 1 (the read leaves cluster 1) or c0 - 1; lanes c0 +- 1 exist whenever used
+        const double base_up = readlane_f64(pair_lk, c0 < n ? c0 + 1 : c0), base_dn = readlane_f64(pair_lk, c0 > 0 ? c0 - 1 : c0);
+        const double proposed = eval(T0, T1, P0, P1, W0, W1, old ? base_up : base_dn);
+        const double diff = proposed - lk;
+        // per-group decision with the guarded f32 test; anything else is an "event"
+        bool reject = false;
+        if (diff <= -44.4) {
+            reject = true;
+        } else if (diff < -1e-3) {
+            const float u = (float)(uint32_t)(v >> 40) * 0x1p-24f;
+            const float pe = __expf((float)diff);
+            reject = u > pe * 1.001f + 3e-7f;
+        }
+        const unsigned long long eventm = __ballot(lead && g < nb && !reject);
+        const uint32_t n_rej = eventm ? (uint32_t)__builtin_ctzll(eventm) / GW : nb;
+        if (n_rej > 0) {
+            // state after n_rej rejected steps = group (n_rej-1)'s state after its own flip-back
+            const double u0 = T0 + sx, u1 = T1 - sxr;
+            tg0 = bcast_group(u0, n_rej - 1);
+            tg1 = bcast_group(u1, n_rej - 1);
+            t += n_rej;
+#pragma unroll
+            for (uint32_t j = 0; j < B; j++)
+                if (j + 1 == n_rej) p = pend[j];
+        }
+        if (!eventm) continue;
+        // ---------------------------------------------------------------- the event: one exact step (group n_rej)
         {
-            const QEntry *e = &m.queue[t & (QN - 1)];
-            const uint64_t want = ((uint64_t)t << 32) | gen;
-            while (uni64(lds_ld64((const uint64_t *)&e->gen)) != want) __builtin_amdgcn_s_sleep(1);
-            const uint32_t idx = uni((uint32_t)lds_ld64((const uint64_t *)&e->idx));
-            const Elem2 el = m.elem2[idx * JTK_GW_MAX + d];
-            const bool old = (lab >> idx) & 1ull;
-            const double sx = old ? -el.x : el.x, sxr = old ? -el.xr : el.xr;
-            const int sdp = old ? -el.dp : el.dp, spw = old ? -el.pw : el.pw;
-            const int sdpr = old ? -el.dpr : el.dpr, spwr = old ? -el.pwr : el.pwr;
-            const double T0 = tg0 - sx, T1 = tg1 + sxr;
-            const int P0 = np0 - sdp, P1 = np1 + sdpr, W0 = w0 - spw, W1 = w1 + spwr;
-            const uint32_t nc0 = old ? c0 + 1 : c0 - 1;
-            const double proposed = unif64(readlane_f64(eval(T0, T1, P0, P1, W0, W1, nc0), GW - D));
-            const double diff = unif64(proposed - lk);
-            const bool no_draw = ubool(diff >= -0x1p-54);
-            const bool last = t + 1 == total;
+            // its operands, made uniform
+            const uint32_t ev = n_rej * GW + (GW - D);  // lead lane of the event group
+            const double e_prop = unif64(readlane_f64(proposed, ev));
+            const double e_diff = unif64(e_prop - lk);
+            const uint32_t e_idx = uni((uint32_t)__builtin_amdgcn_readlane((int)idx, (int)(n_rej * GW)));
+            const bool no_draw = ubool(e_diff >= -0x1p-54);
             bool accept = true;
-            if (no_draw || last) {
-                after.s0 = uni64(lds_ld64(&e->s[0]));
-                after.s1 = uni64(lds_ld64(&e->s[1]));
-                after.s2 = uni64(lds_ld64(&e->s[2]));
-                after.s3 = uni64(lds_ld64(&e->s[3]));
-                if (!no_draw) {
-                    accept = bernoulli_exact(uni64(lds_ld64(&e->v)), diff);
-                    (void)next_u64(after);
-                }
-                if (no_draw && !last) {
-                    gen++;
-                    if (lane == 0) {
-                        lds_st64(&m.ctl->restart_state[0], after.s0);
-                        lds_st64(&m.ctl->restart_state[1], after.s1);
-                        lds_st64(&m.ctl->restart_state[2], after.s2);
-                        lds_st64(&m.ctl->restart_state[3], after.s3);
-                        lds_st32(&m.ctl->restart_seq, t + 1);
-                        lds_st32(&m.ctl->consumed, t + 1);
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        lds_st32(&m.ctl->gen, gen);
-                    }
-                }
+            uint32_t p_after = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < B; j++)
+                if (j == n_rej) p_after = pend[j];  // position after this proposal INCLUDING its Bernoulli draw
+            if (no_draw) {
+                p_after -= 1;  // gen_bool(1.0) takes no draw
             } else {
-                accept = bernoulli_exact(uni64(lds_ld64(&e->v)), diff);
+                const uint64_t e_v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)(n_rej * GW)) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)(n_rej * GW));
+                accept = bernoulli_exact(e_v, e_diff);
             }
             if (accept) {
-                tg0 = T0;
-                tg1 = T1;
-                np0 = P0;
-                np1 = P1;
-                w0 = W0;
-                w1 = W1;
-                c0 = nc0;
-                lab ^= 1ull << idx;
-                lk = proposed;
+                // commit the event group's tentative state everywhere
+                tg0 = bcast_group(T0, n_rej);
+                tg1 = bcast_group(T1, n_rej);
+                np0 = __builtin_amdgcn_ds_bpermute((int)((n_rej * GW + d) << 2), P0);
+                np1 = __builtin_amdgcn_ds_bpermute((int)((n_rej * GW + d) << 2), P1);
+                w0 = __builtin_amdgcn_ds_bpermute((int)((n_rej * GW + d) << 2), W0);
+                w1 = __builtin_amdgcn_ds_bpermute((int)((n_rej * GW + d) << 2), W1);
+                c0 = ((lab >> e_idx) & 1ull) ? c0 + 1 : c0 - 1;
+                lab ^= 1ull << e_idx;
+                lk = e_prop;
                 if (ubool(max < lk)) {
-                    max = proposed;
+                    max = e_prop;
                     argmax = lab;
                 }
             } else {
-                tg0 = T0 + sx;  // flip back (:746), keeping the rounding residue
-                tg1 = T1 - sxr;
+                const double u0 = T0 + sx, u1 = T1 - sxr;  // flip back (:746), keeping the rounding residue
+                tg0 = bcast_group(u0, n_rej);
+                tg1 = bcast_group(u1, n_rej);
             }
             t++;
-            if (!no_draw && (t & 7) == 0 && lane == 0) lds_st32(&m.ctl->consumed, t);
+            p = p_after;
         }
     }
-    if (lane == 0) lds_st32(&m.ctl->stop, 1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();  // B
-    rng = after;
+    rng.pos = wd.base + p;
+    rng_release(rng, lane);
     if (lane < n) m.assign[lane] = (uint8_t)((argmax >> lane) & 1ull);
     wsync();
     return max;
@@ -1174,7 +938,6 @@ __device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uin
     // both (D <= GW/2) are enabled -- the overlapped layout did not reproduce the oracle and is left out
     if (K == 2 && n <= 63 && D <= 4) return mcmc_chain_k2b<8>(m, n, D, cov, rng, lane);
     if (K == 2 && n <= 63 && D <= 8) return mcmc_chain_k2b<16>(m, n, D, cov, rng, lane);
-    if (K == 2 && n <= 63) return mcmc_chain_k2(m, n, D, cov, rng, lane);
     if (n <= 63) return mcmc_chain<K, true>(m, n, D, cov, rng, lane);
     return mcmc_chain<K, false>(m, n, D, cov, rng, lane);
 }
@@ -1338,8 +1101,8 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
             p += (bytes + 15) & ~(size_t)15;
             return q;
         };
-        m.ctl = (QCtl *)take(sizeof(QCtl));
-        m.queue = (QEntry *)take(sizeof(QEntry) * QN);
+        m.ctl = (RCtl *)take(sizeof(RCtl));
+        m.ring = (uint64_t *)take(sizeof(uint64_t) * RN);
         m.elem2 = (Elem2 *)take((size_t)(lds_n < 63 ? lds_n : 63) * JTK_GW_MAX * sizeof(Elem2));
         m.elem = (Elem *)take((size_t)lds_n * lds_d * sizeof(Elem));
         m.data = (double *)take((size_t)lds_n * lds_d * 8);
@@ -1358,11 +1121,17 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         m.prev_used = (uint8_t *)take(lds_d);
         m.tmp_used = (uint8_t *)take(lds_d);
     }
-    if (wave == 1) {
-        producer_main(m.ctl, m.queue, lane);
+    if (threadIdx.x == 0) {
+        lds_st32(&m.ctl->rd, 0);
+        lds_st32(&m.ctl->quit, 0);
+        lds_st32(&m.ctl->wr, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (wave == 1) {  // Xoshiro256StarStar::seed_from_u64(chunk.id * 3490)  (local_clustering/mod.rs:97)
+        producer_main(m.ctl, m.ring, uni64(cm.chunk_id) * 3490ULL, lane);
         return;
     }
-    if (lane == 0) lds_st32(&m.ctl->quit, 0);
     const double *feat = feat_all + cm.feat_off;
     for (uint32_t e = lane; e < n * D; e += 64) {
         const double x = feat[e];
@@ -1410,15 +1179,12 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
     wsync();
     const uint32_t *vt = vtype_all + 2 * ((uint64_t)ci * JTK_MAX_DIM);
     if (vt_stride_mode) vt = vtype_all + 2 * vt_off_all[ci];
-    // ---- per-chunk RNG (local_clustering/mod.rs:97)
+    // ---- per-chunk RNG (local_clustering/mod.rs:97): the consumer's position in the producer's stream
     Rng rng;
-    {
-        uint64_t x = uni64(cm.chunk_id) * 3490ULL;
-        rng.s0 = splitmix64(x);
-        rng.s1 = splitmix64(x);
-        rng.s2 = splitmix64(x);
-        rng.s3 = splitmix64(x);
-    }
+    rng.pos = 0;
+    rng.wr_seen = 0;
+    rng.ctl = m.ctl;
+    rng.ring = m.ring;
     // ---- cluster_filtered_variants (:213-274)
     const double per_cluster_cov = unif64(cm.local_coverage);
     double max = 0.0;
@@ -1479,10 +1245,8 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
             break;
         }
     }
-    // release the producer wave (it is parked at barrier A)
+    // stop the producer wave
     if (lane == 0) lds_st32(&m.ctl->quit, 1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
     if (failed) {
         if (lane == 0) st->status = JTK_ERR_CHUNK_FAILED;
         return;
@@ -1518,7 +1282,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
 
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    size_t b = al(sizeof(QCtl)) + al(sizeof(QEntry) * QN) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
+    size_t b = al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
                al((size_t)(lds_n < 63 ? lds_n : 63) * JTK_GW_MAX * sizeof(Elem2)) +
                al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) + 2 * al((size_t)JTK_MAX_COPY * lds_d * 8) +
                2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d);
