@@ -21,6 +21,8 @@
 //    with every lane busy;
 //  * all scaling is by exact powers of two, one exponent per 64 anti-diagonals, so device and oracle agree
 //    bit for bit as long as both use fma where the spec says fma (this file is built -ffp-contract=off).
+#include <type_traits>
+
 #include "device_common.h"
 
 namespace {
@@ -46,8 +48,17 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 __device__ __forceinline__ double pow2i(int e) { return jtk_scalbn(1.0, e); }
+// 2^e for the exponent differences of neighbouring scaling blocks (|e| is a few hundred at most); identical to
+// scalbn(1.0, e) wherever the result is a normal number, which is the only case the fast branch accepts
+__device__ __forceinline__ double fast_pow2(int e) {
+    if (e == 0) return 1.0;
+    if (e > -1000 && e < 1000) return jtk_bits_f64((uint64_t)(1023 + e) << 52);
+    return jtk_scalbn(1.0, e);
+}
 __device__ __forceinline__ int delta_bit(const uint64_t *delta, int t) {  // c[t] - c[t-1], t >= 1
-    return (int)((delta[t >> 6] >> (t & 63)) & 1);
+    const uint64_t w = delta[t >> 6];
+    const uint32_t half = __builtin_amdgcn_readfirstlane((uint32_t)(w >> (t & 32)));
+    return (int)((half >> (t & 31)) & 1u);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -127,8 +138,9 @@ __global__ __launch_bounds__(64) void phmm_kernel(uint32_t n_reads, const ReadMe
     double2 *ring = reinterpret_cast<double2 *>(smem);
     double *s_eM = reinterpret_cast<double *>(smem + 8 * 64 * 16);
     double *s_eI = s_eM + 16;
-    int *s_EF = reinterpret_cast<int *>(s_eI + 20);
     const uint32_t n_blk = ((lds_tmpl + lds_read) >> 6) + 4;
+    uint64_t *s_delta = reinterpret_cast<uint64_t *>(s_eI + 20);  // band deltas of this read, one bit per diagonal
+    int *s_EF = reinterpret_cast<int *>(s_delta + n_blk);
     uint8_t *s_x = reinterpret_cast<uint8_t *>(s_EF + n_blk);
     uint8_t *s_ey = s_x + ((lds_tmpl + 16) & ~15u);
     const int lane = threadIdx.x;
@@ -156,6 +168,7 @@ __global__ __launch_bounds__(64) void phmm_kernel(uint32_t n_reads, const ReadMe
             for (int p = lane; p <= n; p += 64) s_ey[p] = gy[p];
             if (lane < 16) s_eM[lane] = h->eM[lane];
             if (lane < 20) s_eI[lane] = h->eI[lane];
+            for (int wdx = lane; wdx < (T >> 6) + 2; wdx += 64) s_delta[wdx] = delta[wdx];
         }
         __syncthreads();
         const double aMM = h->a[0], aMI = h->a[1], aMD = h->a[2], aIM = h->a[3], aII = h->a[4], aID = h->a[5],
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(64) void phmm_kernel(uint32_t n_reads, const ReadMe
         double toM_1 = 0, toM_2 = 0, toI_1 = 0, toD_1 = 0;  // combos of diagonals t-1 / t-2, lane frame
         double endM = 0, endI = 0, endD = 0;
         for (int t = 0; t <= T; t++) {
-            if (t > 0) c += delta_bit(delta, t);
+            if (t > 0) c += delta_bit(s_delta, t);
             const Lane x = lane_cell(lane, c, r, t, L, n);
             double fm = 0, fi = 0, fd = 0;
             if (t == 0) {
@@ -235,9 +248,9 @@ __global__ __launch_bounds__(64) void phmm_kernel(uint32_t n_reads, const ReadMe
             int cc = c;
             // c[T-4], c[T-5] by walking back
             int tt = T;
-            for (int s = 0; s < 4 && tt >= 1; s++, tt--) cc -= delta_bit(delta, tt);
+            for (int s = 0; s < 4 && tt >= 1; s++, tt--) cc -= delta_bit(s_delta, tt);
             c4 = cc;
-            if (tt >= 1) cc -= delta_bit(delta, tt);
+            if (tt >= 1) cc -= delta_bit(s_delta, tt);
             c5 = cc;
         }
         // ring preload: diagonals T+2 .. T-5 (those > T are zero)
@@ -323,12 +336,16 @@ __global__ __launch_bounds__(64) void phmm_kernel(uint32_t n_reads, const ReadMe
                 }
                 Gprev = G;
                 // (3) the 16 row-crossing products of this cell; F values come from the LDS ring with the
-                //     lane offset of the source row folded into the address
-                {
-                    auto FS = [&](int tt) -> double {  // 2^(EF[tt]-EF[t]), 1 unless tt is in another block
+                //     lane offset of the source row folded into the address.  A source diagonal in another
+                //     64-diagonal block carries another exponent and is re-expressed by an exact power of two; the
+                //     window t-5 .. t+2 lies inside one block for 57 of 64 steps, and then every factor is 1.
+                const bool straddle = ((t - 5) >> 6) != ((t + 2) >> 6);
+                auto products = [&](auto straddle_tag) {
+                    constexpr bool ST = decltype(straddle_tag)::value;
+                    auto FS = [&](int tt) -> double {  // 2^(EF[tt]-EF[t])
+                        if (!ST) return 1.0;
                         if (tt < 0 || tt > T) return 1.0;
-                        const int d = s_EF[tt >> 6] - EFt;
-                        return d == 0 ? 1.0 : pow2i(d);
+                        return fast_pow2(s_EF[tt >> 6] - EFt);
                     };
                     const bool jm = x.active && x.j >= 1;  // M terms consume read base y[j-1]
                     const bool i1 = x.active && x.i >= 1;
@@ -336,8 +353,8 @@ __global__ __launch_bounds__(64) void phmm_kernel(uint32_t n_reads, const ReadMe
                     {
                         const double2 a = ring[((t - 2) & 7) * 64 + ((lane - 1) & 63)];
                         const double2 b = ring[((t - 1) & 7) * 64 + ((lane - 1) & 63)];
-                        const double fmv = (i1 && jm && t >= 2) ? a.x * FS(t - 2) : 0.0;
-                        const double fdv = (i1 && t >= 1) ? b.y * FS(t - 1) : 0.0;
+                        const double fmv = (i1 && jm && t >= 2) ? (ST ? a.x * FS(t - 2) : a.x) : 0.0;
+                        const double fdv = (i1 && t >= 1) ? (ST ? b.y * FS(t - 1) : b.y) : 0.0;
 #pragma unroll
                         for (int q = 0; q < 4; q++) acc[q] = fma(y1 == q ? fmv : 0.0, vm, acc[q]);
                         acc[4] = fma(fdv, vd, acc[4]);
@@ -346,7 +363,7 @@ __global__ __launch_bounds__(64) void phmm_kernel(uint32_t n_reads, const ReadMe
                     {
                         const double2 a = ring[((t - 1) & 7) * 64 + lane];
                         const double2 b = ring[(t & 7) * 64 + lane];
-                        const double fmv = (jm && t >= 1) ? a.x * FS(t - 1) : 0.0;
+                        const double fmv = (jm && t >= 1) ? (ST ? a.x * FS(t - 1) : a.x) : 0.0;
                         const double fdv = x.active ? b.y : 0.0;
 #pragma unroll
                         for (int q = 0; q < 4; q++) acc[5 + q] = fma(y1 == q ? fmv : 0.0, vm, acc[5 + q]);
@@ -357,8 +374,8 @@ __global__ __launch_bounds__(64) void phmm_kernel(uint32_t n_reads, const ReadMe
                     for (int cc = 1; cc <= 3; cc++) {
                         const double2 a = ring[((t + cc - 2) & 7) * 64 + ((lane - 1 + cc) & 63)];
                         const double2 b = ring[((t + cc - 1) & 7) * 64 + ((lane - 1 + cc) & 63)];
-                        const double fmv = (i1 && jm && t + cc - 2 >= 0 && t + cc - 2 <= T) ? a.x * FS(t + cc - 2) : 0.0;
-                        const double fdv = (i1 && t + cc - 1 <= T) ? b.y * FS(t + cc - 1) : 0.0;
+                        const double fmv = (i1 && jm && t + cc - 2 >= 0 && t + cc - 2 <= T) ? (ST ? a.x * FS(t + cc - 2) : a.x) : 0.0;
+                        const double fdv = (i1 && t + cc - 1 <= T) ? (ST ? b.y * FS(t + cc - 1) : b.y) : 0.0;
                         double v = acc[10 + cc - 1];
                         v = fma(fmv, hM, v);
                         v = fma(fdv, vd, v);
@@ -375,14 +392,18 @@ __global__ __launch_bounds__(64) void phmm_kernel(uint32_t n_reads, const ReadMe
                             okm = okm && (x.i - 4 >= c5 - r);
                             okd = okd && (x.i - 4 >= c4 - r);
                         }
-                        const double fmv = okm ? a.x * FS(t - dd - 2) : 0.0;
-                        const double fdv = okd ? b.y * FS(t - dd - 1) : 0.0;
+                        const double fmv = okm ? (ST ? a.x * FS(t - dd - 2) : a.x) : 0.0;
+                        const double fdv = okd ? (ST ? b.y * FS(t - dd - 1) : b.y) : 0.0;
                         double v = acc[13 + dd - 1];
                         v = fma(fmv, hM, v);
                         v = fma(fdv, vd, v);
                         acc[13 + dd - 1] = v;
                     }
-                }
+                };
+                if (straddle)
+                    products(std::true_type{});
+                else
+                    products(std::false_type{});
                 __syncthreads();
                 // slide: diagonal t-6 replaces diagonal t+2 in the ring; refill the queue slot
                 ring[((t - 6) & 7) * 64 + lane] = pf[u];
@@ -396,9 +417,9 @@ __global__ __launch_bounds__(64) void phmm_kernel(uint32_t n_reads, const ReadMe
                 hI_1 = hI;
                 bD_1 = vd;
                 // centres for the next step (t-1): c[t] -> c[t-1], c5 = c[t-6], c4 = c[t-5]
-                delta_next = t >= 1 ? delta_bit(delta, t) : 0;
+                delta_next = t >= 1 ? delta_bit(s_delta, t) : 0;
                 c4 = c5;
-                if (t - 5 >= 1) c5 -= delta_bit(delta, t - 5);
+                if (t - 5 >= 1) c5 -= delta_bit(s_delta, t - 5);
             }
         }
         // rows still in the band after t == 0
@@ -495,7 +516,7 @@ void launch_band_prep(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, co
 
 size_t phmm_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
     const uint32_t n_blk = ((max_tmpl + max_read) >> 6) + 4;
-    size_t b = 8 * 64 * 16 + 36 * 8 + (size_t)n_blk * 4;
+    size_t b = 8 * 64 * 16 + 36 * 8 + (size_t)n_blk * 12;
     b += ((max_tmpl + 16) & ~15u) + max_read + 16;
     return (b + 15) & ~(size_t)15;
 }
