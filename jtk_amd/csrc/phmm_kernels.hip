@@ -126,7 +126,7 @@ __device__ __forceinline__ Lane lane_cell(int lane, int c, int r, int t, int L, 
     return x;
 }
 
-__global__ __launch_bounds__(64) void phmm_kernel(uint32_t n_reads, const ReadMeta *reads,
+__global__ __launch_bounds__(64, 3) void phmm_kernel(uint32_t n_reads, const ReadMeta *reads,
                                                   const ChunkMeta *chunks, const ChunkState *state,
                                                   DevBufs bufs, const uint8_t *ey_all, const uint64_t *delta_all,
                                                   const HmmDev *hmm2, double *scratch_all,

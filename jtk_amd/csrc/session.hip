@@ -328,7 +328,8 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
-        const uint32_t want = (uint32_t)prop.multiProcessorCount * 8;
+        // resident waves of phmm_kernel: 3 per SIMD by registers, 11 per CU by its ~14 KB of LDS
+        const uint32_t want = (uint32_t)prop.multiProcessorCount * 11;
         s->n_waves = n_reads < want ? (uint32_t)n_reads : want;
         if (s->n_waves == 0) s->n_waves = 1;
         s->scratch_stride = (uint64_t)(s->max_tmpl + s->max_read + 8) * 64 * 2;  // doubles
