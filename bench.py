@@ -91,6 +91,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # diagnostic only: JTK_BENCH_BACKEND=gloo runs the multi-rank path with every rank on GPU 0 (1-GPU boxes)
+    backend = os.environ.get("JTK_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     jbuild.build()
@@ -106,7 +110,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -129,7 +136,8 @@ def main():
         sess.run(skip_polish=False)            # synchronous: returns when the device has finished
         if dist is not None:                   # the only exchange of the path: labels, RCCL all-gather
             out = sess.fetch()
-            gathered = sharding.all_gather_labels(dist, out["label"], device=torch.device("cuda", local_rank))
+            gathered = sharding.all_gather_labels(
+                dist, out["label"], device=torch.device("cuda", local_rank) if backend == "nccl" else None)
 
     for _ in range(args.warmup):
         step()
@@ -148,7 +156,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
