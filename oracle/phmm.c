@@ -143,7 +143,7 @@ static int forward(const jtk_hmm_t *h, const uint8_t *tmpl, size_t L, const uint
         int Eprev1 = t >= 1 ? f->E[t - 1] : 0, Eprev2 = t >= 2 ? f->E[t - 2] : 0;
         /* raw values of diagonal t are produced in the scale of diagonal t-1 */
         int Ecur = Eprev1;
-        double s2 = pow2i(Eprev2 - Ecur); /* re-express diagonal t-2 (previous block at most) */
+        double s2 = Eprev2 == Ecur ? 1.0 : pow2i(Eprev2 - Ecur); /* re-express diagonal t-2 (previous block at most) */
         double m = 0.0;
         for (size_t w = 0; w < W; w++) {
             int64_t i = (int64_t)f->c[t] - f->r + (int64_t)w, j = (int64_t)t - i;
@@ -271,6 +271,7 @@ double jo_phmm_modification_table(const jtk_hmm_t *h, const uint8_t *tmpl, size_
            *hM = (double *)calloc(3 * W, sizeof(double)), *hI = (double *)calloc(3 * W, sizeof(double));
     int *EB = (int *)calloc(T + 3, sizeof(int));
     double *acc = (double *)calloc((L + 2) * A_N, sizeof(double));
+    double *cbI_buf = (double *)malloc(W * sizeof(double));
     /* backward band accessor for diagonal tt stored in slot tt % 3 */
 #define BGET(arr, tt, ii)                                                                        \
     (((tt) > (int64_t)T || (ii) < (int64_t)f.c[tt] - r || (ii) > (int64_t)f.c[tt] + r)            \
@@ -288,11 +289,11 @@ double jo_phmm_modification_table(const jtk_hmm_t *h, const uint8_t *tmpl, size_
         /* (1) backward values of diagonal t, produced in the scale of diagonal t+1 */
         int Ecur = t < (int64_t)T ? EB[t + 1] : 0;
         int E1 = t + 1 <= (int64_t)T ? EB[t + 1] : 0, E2 = t + 2 <= (int64_t)T ? EB[t + 2] : 0;
-        double s2 = pow2i(E2 - Ecur);
+        double s2 = E2 == Ecur ? 1.0 : pow2i(E2 - Ecur);
         (void)E1;
         double *cbM = bM + ((size_t)t % 3) * W, *cbD = bD + ((size_t)t % 3) * W,
                *chM = hM + ((size_t)t % 3) * W, *chI = hI + ((size_t)t % 3) * W;
-        double *cbI = (double *)malloc(W * sizeof(double));
+        double *cbI = cbI_buf;
         double m = 0.0;
         for (size_t w = 0; w < W; w++) {
             int64_t i = lo_i + (int64_t)w, j = t - i;
@@ -339,7 +340,6 @@ double jo_phmm_modification_table(const jtk_hmm_t *h, const uint8_t *tmpl, size_
             chM[w] = a;
             chI[w] = b;
         }
-        free(cbI);
         /* (2) common exponent of this step; rescale the live accumulators when it changes */
         int G = f.E[t] + EB[t];
         if (t < (int64_t)T && G != Gprev) {
@@ -350,12 +350,18 @@ double jo_phmm_modification_table(const jtk_hmm_t *h, const uint8_t *tmpl, size_
         }
         Gprev = G;
         /* (3) accumulate the terms of every band cell (row iota = i, column j2 = j) */
+        double fsc[8]; /* 2^(E_F[tt]-E_F[t]) for tt = t-5 .. t+2: exact re-expression of a source diagonal */
+        for (int q = 0; q < 8; q++) {
+            const int64_t tt = t - 5 + q;
+            const int de = (tt >= 0 && tt <= (int64_t)T) ? f.E[tt] - f.E[t] : 0;
+            fsc[q] = de == 0 ? 1.0 : pow2i(de);
+        }
         for (size_t w = 0; w < W; w++) {
             int64_t i = lo_i + (int64_t)w, j2 = t - i;
             if (i < 0 || i > (int64_t)L || j2 < 0 || j2 > (int64_t)n) continue;
             double *a = acc + (size_t)i * A_N;
             double vM = cbM[w], vD = cbD[w], vH = chM[w];
-#define FSC(tt) pow2i(((tt) >= 0 && (tt) <= (int64_t)T) ? f.E[tt] - f.E[t] : 0)
+#define FSC(tt) fsc[(tt) - t + 5]
             /* sub (entry i-1): M toM(i-1,j2-1) diag t-2 ; D toD(i-1,j2) diag t-1 */
             if (i >= 1) {
                 if (j2 >= 1) {
@@ -416,6 +422,7 @@ double jo_phmm_modification_table(const jtk_hmm_t *h, const uint8_t *tmpl, size_
     free(hI);
     free(EB);
     free(acc);
+    free(cbI_buf);
     fwd_free(&f);
     return lk;
 }
