@@ -15,7 +15,7 @@ SOURCES = ["phmm_kernels.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc
 # -ffp-contract=off: device f64 arithmetic must round exactly like the reference (no implicit fma);
 # the pair-HMM specification uses explicit fma() where it wants one.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-fgpu-rdc=false" if False else "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("JTK_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _stale(target, deps):

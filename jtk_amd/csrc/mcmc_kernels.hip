@@ -24,6 +24,8 @@
 //    terms (ballot + v_readlane).
 // Sums that the reference evaluates left to right are evaluated left to right here -- integer labels only
 // match if every f64 rounding matches.
+#include <vector>
+
 #include "device_common.h"
 
 namespace {
@@ -43,7 +45,13 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 }
 
 // The ring of raw xoshiro256** outputs.  `wr` draws have been produced, the consumer has released `rd`.
-#define RN 512  // draws in the ring (4 KiB)
+#define RN 4096  // draws in the ring (32 KiB): two superblocks of the producer
+// stream position -> ring slot.  Inside a superblock, draw j of segment g sits at j * 64 + ((g + j) & 63): the
+// producer's 64 lanes (one segment each) and the consumer's 64-draw windows (consecutive j) both hit distinct banks.
+__device__ __forceinline__ uint32_t ring_slot(uint32_t pos) {
+    const uint32_t o = pos & (RN / 2 - 1), g = o >> 5, j = o & 31;
+    return (pos & (RN / 2)) | (j * 64 + ((g + j) & 63));
+}
 struct RCtl {
     uint32_t rd, quit;  // written by the consumer (read together, 8-byte aligned)
     uint32_t wr, pad;   // written by the producer
@@ -75,7 +83,7 @@ __device__ __forceinline__ void rng_release(Rng &r, uint32_t lane) {  // draws b
 }
 __device__ __forceinline__ uint64_t next_u64(Rng &r) {
     rng_wait(r, r.pos + 1);
-    const uint64_t v = uni64(lds_ld64(&r.ring[r.pos & (RN - 1)]));
+    const uint64_t v = uni64(lds_ld64(&r.ring[ring_slot(r.pos)]));
     r.pos++;
     if ((r.pos & 63) == 0) lds_st32(&r.ctl->rd, r.pos);  // every lane stores the same value
     return v;
@@ -132,16 +140,14 @@ struct Elem {  // one (read, column) cell as the chain needs it
     int dp;    // 1 if x >  POS_THR (counts towards num_pos)
     int pw;    // 3*[x > POS_THR] - 7*[x < -POS_THR]: increment of 3*num_pos - 7*num_neg
 };
-struct Elem2 {  // one (read, lane) cell of the batched diploid chain: lane d serves column d of cluster 0 and
-    double x;   // column GW-1-d of cluster 1 (mirrored, so that the ordered sum of get_lk is two DPP row scans)
-    double xr;
-    int dp, pw, dpr, pwr;
-};
-#define JTK_GW_MAX 16
 struct Lds {
     RCtl *ctl;
     uint64_t *ring;      // RN raw draws
-    Elem2 *elem2;        // min(n, 63) x JTK_GW_MAX
+    double *k2_pair;     // 64: size terms of get_lk by cluster-0 size (diploid chain)
+    double *k2_tg;       // 32: published LKCount[c][d].total_gain at 16*c + d
+    int *k2_np, *k2_w;   // 32 each: num_pos and 3*num_pos - 7*num_neg
+    int *k2_totp2;       // 16: 2 x reads with a positive value per column
+    unsigned long long *k2_stats;  // 16 debug counters (JTK_MCMC_STATS builds only)
     Elem *elem;          // n x D
     double *data;        // n x D
     double *size_to_lk;  // n + 1
@@ -413,43 +419,79 @@ __device__ __forceinline__ uint32_t choose_pos(Rng &r, uint32_t k) {
     return pos;
 }
 
-// The producer wave: Xoshiro256StarStar::seed_from_u64(seed), free running into the ring.  A lone wave issues
-// about one instruction per 4-5 cycles, so the loop is written for instruction count: the scalar unit only advances
-// the 256-bit state (9 instructions per draw) and parks s[1] of 32 consecutive steps in lanes 0..31; the output
-// function rotl(s1 * 5, 7) * 9 of all 32 draws is then evaluated at once on the vector unit and stored with one
-// ds_write_b64.
-#define PBATCH 32
+// The producer wave: Xoshiro256StarStar::seed_from_u64(seed), free running into the ring.
+//
+// xoshiro's state update is linear over GF(2), so the stream can be cut into segments that are generated side by
+// side: lane l of the producer owns segment l of the current superblock (SEG consecutive draws) and runs the plain
+// generator on its own copy of the state with ordinary 64-bit vector arithmetic -- 64 draws per ~20 instructions
+// instead of one draw per ~11 scalar instructions.  After a superblock every lane stands at the start of the NEXT
+// lane's segment and has to skip the other 63 segments: multiplication of the 256-bit state by the constant matrix
+// M^(63*SEG), done as 64 nibble look-ups in a 32 KiB table (g_jump_tab, computed once on the host from the step
+// function itself) XOR-ed together.  The sequence of draws is exactly that of the sequential generator.
+#define SEG 32              // draws per lane per superblock
+#define SBLK (64 * SEG)     // draws per superblock
+static_assert(RN == 2 * SBLK, "the ring holds two superblocks");
+__device__ ulonglong2 g_jump_tab[64 * 16 * 2];  // [nibble position][nibble value] -> 256-bit column sum of M^(63*SEG)
+
+struct Xo {
+    uint64_t s0, s1, s2, s3;
+};
+__device__ __forceinline__ void xo_step(Xo &x) {
+    const uint64_t t = x.s1 << 17;
+    x.s2 ^= x.s0;
+    x.s3 ^= x.s1;
+    x.s1 ^= x.s2;
+    x.s0 ^= x.s3;
+    x.s2 ^= t;
+    x.s3 = rotl64(x.s3, 45);
+}
+__device__ __forceinline__ void xo_jump(Xo &x) {
+    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const uint64_t w[4] = {x.s0, x.s1, x.s2, x.s3};
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t v = (uint32_t)(w[q] >> (4 * k)) & 15u;
+            const ulonglong2 *e = &g_jump_tab[((q * 16 + k) * 16 + v) * 2];
+            const ulonglong2 lo = e[0], hi = e[1];
+            a0 ^= lo.x;
+            a1 ^= lo.y;
+            a2 ^= hi.x;
+            a3 ^= hi.y;
+        }
+    x.s0 = a0;
+    x.s1 = a1;
+    x.s2 = a2;
+    x.s3 = a3;
+}
 __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint64_t seed, uint32_t lane) {
-    uint64_t x = seed;
-    uint64_t s0 = splitmix64(x), s1 = splitmix64(x), s2 = splitmix64(x), s3 = splitmix64(x);
+    uint64_t z = seed;
+    Xo x;
+    x.s0 = splitmix64(z);
+    x.s1 = splitmix64(z);
+    x.s2 = splitmix64(z);
+    x.s3 = splitmix64(z);
+    for (uint32_t j = 0; j < lane * SEG; j++) xo_step(x);  // lane l starts at stream position l * SEG
     uint32_t wr = 0;
     for (;;) {
         const uint64_t c = uni64(lds_ld64((const uint64_t *)&ctl->rd));  // rd, quit
         if ((uint32_t)(c >> 32)) return;
-        if ((int32_t)(wr + PBATCH - (uint32_t)c) > RN) {
+        if ((int32_t)(wr + SBLK - (uint32_t)c) > RN) {
             __builtin_amdgcn_s_sleep(2);
             continue;
         }
-        uint32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int i = 0; i < PBATCH; i++) {
-            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((uint32_t)s1), "n"(i));
-            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((uint32_t)(s1 >> 32)), "n"(i));
-            const uint64_t t = s1 << 17;
-            s2 ^= s0;
-            s3 ^= s1;
-            s1 ^= s2;
-            s0 ^= s3;
-            s2 ^= t;
-            s3 = rotl64(s3, 45);
+        uint64_t *blk = ring + (wr & (RN - 1));
+#pragma unroll 8
+        for (uint32_t j = 0; j < SEG; j++) {
+            const uint64_t m5 = (x.s1 << 2) + x.s1, rr = rotl64(m5, 7);
+            lds_st64(&blk[j * 64 + ((lane + j) & 63)], (rr << 3) + rr);  // rotl(s1 * 5, 7) * 9, skewed: no bank conflicts
+            xo_step(x);
         }
-        const uint64_t s1v = ((uint64_t)hi << 32) | lo;  // lane i: s[1] before step wr + i
-        const uint64_t m5 = (s1v << 2) + s1v, rr = rotl64(m5, 7);
-        const uint64_t result = (rr << 3) + rr;  // rotl(s1 * 5, 7) * 9
-        if (lane < PBATCH) lds_st64(&ring[(wr + lane) & (RN - 1)], result);
-        wr += PBATCH;
+        wr += SBLK;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_st32(&ctl->wr, wr);
+        xo_jump(x);
     }
 }
 
@@ -633,56 +675,25 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Lane-time batching of the diploid chain (K == 2, n <= 63, D <= GW/2).
+// The diploid chain (K == 2, n <= 63, D <= 16) as a table-driven walk.
 //
-// More than 96% of the proposals are rejected, and a rejected step changes the state only by the rounding
-// residue of flip + flip-back on the touched columns ((tg - x) + x).  So B = 64/GW consecutive proposals are
-// evaluated at once: lane (g, d) = group g, column d.  Group g first replays the residue of proposals 0..g-1
-// (cheap, element-wise), then evaluates proposal t+g on that exact state.  get_lk's left-to-right sum runs as
-// two DPP row scans per group (cluster 0 up the lanes, cluster 1 -- stored mirrored -- down the lanes), all
-// groups in lock step.  If every proposal of the batch is rejected by the guarded f32 Bernoulli test, the state
-// of the last group is broadcast and the chain advances by B steps; the first proposal that is accepted, draws
-// nothing, or cannot be decided without the exact exp ends the batch and is redone as an exact single step.
+// More than 96% of the proposals are rejected, and in a given state the fate of "flip read i" is the same every
+// time it is proposed: proposed - lk depends on the state only.  So the chain keeps, per read (one lane each), a
+// REJECTION THRESHOLD thr[i]: the proposal is certainly rejected when the uniform behind its Bernoulli draw
+// exceeds thr[i].  thr[i] comes from an order-free evaluation of get_lk (error ~1e-12, far inside the 1e-3 guard
+// band of the f32 test), and is 2.0 ("cannot tell") when the proposal could be accepted, draws nothing, or when
+// flip + flip-back would leave a rounding residue in a cluster sum ((tg - x) + x != tg).  A certainly rejected
+// proposal of a residue-free read changes nothing at all, so the walk only has to find the next proposal that is
+// NOT one of those -- an EVENT -- and redo that single step with the reference's exact arithmetic (ordered
+// left-to-right sum, exact exp only when the guarded test cannot decide).  After an event that changed the state
+// (accept, or a residue) the table is rebuilt, all reads in parallel.
 //
 // Proposals are parsed from a 64-draw window of the raw stream held one draw per lane: the widening-multiply
 // acceptance of gen_range(0..n) and the top-bit acceptance of gen_index(1) are evaluated for all 64 draws at
-// once, and "next accepted draw at or after p" is a ballot + s_ff1 -- no rejection loops.
+// once ("next accepted draw at or after p" is a ballot + s_ff1 -- no rejection loops), every lane holds the
+// proposal that WOULD start at its draw and whether it is certainly rejected; the walk then follows nxt[] through
+// the window with one v_readlane per step.
 // Bit-identical to the one-step-at-a-time chain by construction; checked against the oracle.
-template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    const int lo = dpp_i32<CTRL>(__double2loint(v)), hi = dpp_i32<CTRL>(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-template <int GW>
-__device__ __forceinline__ double row_shr_by(double v, uint32_t k) {  // lane i <- lane i-k (within a 16-lane row)
-    switch (k) {
-        case 0: return v;
-        case 1: return dpp_f64<0x111>(v);
-        case 2: return dpp_f64<0x112>(v);
-        case 3: return dpp_f64<0x113>(v);
-        case 4: return dpp_f64<0x114>(v);
-        case 5: return dpp_f64<0x115>(v);
-        case 6: return dpp_f64<0x116>(v);
-        case 7: return dpp_f64<0x117>(v);
-        case 8: return dpp_f64<0x118>(v);
-        case 9: return dpp_f64<0x119>(v);
-        case 10: return dpp_f64<0x11A>(v);
-        case 11: return dpp_f64<0x11B>(v);
-        case 12: return dpp_f64<0x11C>(v);
-        case 13: return dpp_f64<0x11D>(v);
-        case 14: return dpp_f64<0x11E>(v);
-        default: return dpp_f64<0x11F>(v);
-    }
-}
-template <int GW>
-__device__ __forceinline__ int mirror_i32(int v) {  // lane d <-> lane GW-1-d inside every group
-    return GW == 8 ? dpp_i32<0x141>(v) : dpp_i32<0x140>(v);  // row_half_mirror / row_mirror
-}
-
 // The parser's view of 64 consecutive raw draws (lane l holds the draw at stream position base + l).  Every lane
 // also holds the proposal that WOULD start at its draw: gen_range(0..n) takes the first draw at or after it whose
 // widening multiply is accepted, gen_index(1) (the single candidate of K == 2, pseudo_mcmc.rs:732) then takes
@@ -699,7 +710,7 @@ __device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t base,
     rng_wait(rng, base + 64);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     wd.base = base;
-    const uint64_t draw = lds_ld64(&rng.ring[(base + lane) & (RN - 1)]);
+    const uint64_t draw = lds_ld64(&rng.ring[ring_slot(base + lane)]);
     const uint64_t zone = ((uint64_t)n << __clzll((long long)n)) - 1;
     const uint32_t hi = (uint32_t)__umul64hi(draw, (uint64_t)n);
     const unsigned long long okm = __ballot(draw * (uint64_t)n <= zone);  // gen_range(0..n) accepts this draw
@@ -716,13 +727,18 @@ __device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t base,
     wd.nxt = fits ? pv + 1 : 255u;
 }
 
-template <int GW>
-__device__ __forceinline__ double mcmc_chain_k2b(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng,
+#ifdef JTK_MCMC_STATS
+#define ST_T0() const unsigned long long st_t0 = __builtin_readcyclecounter()
+#define ST_ADD(k) if (lane == 0) m.k2_stats[k] += __builtin_readcyclecounter() - st_t0
+#define ST_CNT(k, v) if (lane == 0) m.k2_stats[k] += (v)
+#else
+#define ST_T0()
+#define ST_ADD(k)
+#define ST_CNT(k, v)
+#endif
+__device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng,
                                                  uint32_t lane) {
-    constexpr uint32_t B = 64 / GW;
-    const uint32_t d = lane & (GW - 1), g = lane / GW;
-    // pair table: lane c0 holds (0.0 + size_to_lk[c0]) + size_to_lk[n - c0]   (get_lk :788)
-    double pair_lk;
+    // pair table: entry c0 is (0.0 + size_to_lk[c0]) + size_to_lk[n - c0]   (get_lk :788)
     {
         auto size_lk = [&](uint32_t x) {
             double mx = -__builtin_inf();
@@ -733,198 +749,184 @@ __device__ __forceinline__ double mcmc_chain_k2b(const Lds &m, uint32_t n, uint3
             return mx;
         };
         const uint32_t c0 = lane <= n ? lane : n;
-        pair_lk = (0.0 + size_lk(c0)) + size_lk(n - c0);
+        m.k2_pair[lane] = (0.0 + size_lk(c0)) + size_lk(n - c0);
     }
-    // ---- state, replicated in every group: lane d = column d of cluster 0 and column GW-1-d of cluster 1
-    double tg0 = 0.0, tg1 = 0.0;
-    int np0 = 0, np1 = 0, w0 = 0, w1 = 0;
+    // ---- exact state: lane 16*c + d holds LKCount[c][d]
+    const uint32_t sc = (lane >> 4) & 1u, sd = lane & 15u;
+    const bool slane = lane < 32 && sd < D;
+    double tg = 0.0;
+    int np = 0, w = 0;
     uint32_t c0 = 0;
     unsigned long long lab = 0;
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t c = uni(m.assign[i]);
-        const Elem2 el = m.elem2[i * JTK_GW_MAX + d];
-        if (c == 0) {
-            tg0 += el.x;
-            np0 += el.dp;
-            w0 += el.pw;
-            c0++;
-        } else {
-            tg1 += el.xr;
-            np1 += el.dpr;
-            w1 += el.pwr;
-            lab |= 1ull << i;
+        Elem el = {0.0, 0, 0};
+        if (slane) el = m.elem[i * D + sd];
+        if (c == sc) {
+            tg += el.x;
+            np += el.dp;
+            w += el.pw;
         }
+        if (c == 0)
+            c0++;
+        else
+            lab |= 1ull << i;
     }
-    const int totp2 = 2 * (np0 + mirror_i32<GW>(np1));  // 2 x reads with a positive value in column d
-    const bool lead = d == GW - D;                      // the lane of a group where its ordered sum ends
-
-    // Evaluates, for every group at once, the likelihood of the tentative state (T0, T1, P0, P1, W0, W1) with
-    // cluster-0 size nc0 (per lane, constant inside a group).  Result valid on the lead lanes.
-    // `base` = the size term of get_lk for the group's cluster-0 size (c0 - 1 or c0 + 1, or c0 itself)
-    auto eval = [&](double T0, double T1, int P0, int P1, int W0, int W1, double base) -> double {
-        const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
-        const int u1 = pos1 ? P1 : 0, a1 = (pos1 && W1 > 0) ? 1 : 0;
-        const int in_use = (pos0 ? P0 : 0) + mirror_i32<GW>(u1);
-        const bool any = (pos0 && W0 > 0) || mirror_i32<GW>(a1) != 0;
-        const bool used = any && 3 * in_use > totp2;  // get_used_columns (:847-869) of column d
-        const bool used_r = mirror_i32<GW>(used ? 1 : 0) != 0;
-        const double term0 = (used && pos0) ? T0 : 0.0, term1 = (used_r && pos1) ? T1 : 0.0;
-        // size terms, then cluster 0 columns 0..D-1 (up the lanes), then cluster 1 columns 0..D-1 (down the lanes)
-        // Select-free scans: acc <- shift(acc) + term on every lane.  A lane whose chain value is final recomputes the
-        // same value each step; with D <= GW/2 nothing non-zero can reach a chain's first lane from outside
-        // (the neighbouring lanes hold zero terms and the chains are shorter than the distance to them).
-        const double t0f = d == 0 ? base + term0 : term0;  // (size terms + first column) is the reference's first add
-        double acc = t0f;
-        for (uint32_t k = 1; k < D; k++) acc = dpp_f64<0x111>(acc) + t0f;  // row_shr:1
-        const double jump = row_shr_by<GW>(acc, GW - D);                    // lane D-1 -> lane GW-1
-        const double t1f = d == GW - 1 ? jump + term1 : term1;
-        acc = t1f;
-        for (uint32_t j = 1; j < D; j++) acc = dpp_f64<0x101>(acc) + t1f;  // row_shl:1
-        return acc;
+    const int totp2_l = 2 * (np + __shfl_xor(np, 16, 64));  // 2 x reads with a positive value in column sd
+    if (lane < 16) m.k2_totp2[lane] = totp2_l;
+    wsync();
+    // get_lk (:785-795) of a tentative state, exactly: size terms, then clusters outer / columns inner, left to right
+    auto exact_eval = [&](double T, int P, int W, double base) -> double {
+        const bool pos = slane && 0.0 < T;
+        const int u = pos ? P : 0, a = (pos && W > 0) ? 1 : 0;
+        const int in_use = u + __shfl_xor(u, 16, 64), any = a | __shfl_xor(a, 16, 64);
+        const bool used = any != 0 && 3 * in_use > totp2_l;  // get_used_columns (:847-869)
+        const double term = (used && pos) ? T : 0.0;        // an unused column adds nothing, total_gain.max(0) adds 0
+        double S = base;
+        for (uint32_t q = 0; q < D; q++) S += readlane_f64(term, q);
+        for (uint32_t q = 0; q < D; q++) S += readlane_f64(term, 16 + q);
+        return unif64(S);
     };
-    auto bcast_group = [&](double v, uint32_t src_group) -> double {
-        const int src = (int)((src_group * GW + d) << 2);
-        return __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(v)),
-                                __builtin_amdgcn_ds_bpermute(src, __double2loint(v)));
+    auto pair_at = [&](uint32_t c) -> double { return unif64(m.k2_pair[c <= n ? c : n]); };
+    auto publish = [&]() {
+        if (slane) {
+            m.k2_tg[lane] = tg;
+            m.k2_np[lane] = np;
+            m.k2_w[lane] = w;
+        }
+        wsync();
     };
-    double lk = unif64(readlane_f64(eval(tg0, tg1, np0, np1, w0, w1, readlane_f64(pair_lk, c0)), GW - D));
+    double lk = exact_eval(tg, np, w, pair_at(c0));
+    // the rejection threshold of "flip read `lane`" in the published state
+    auto rebuild = [&]() -> float {
+        const uint32_t i = lane < n ? lane : 0;
+        const bool a = (lab >> i) & 1ull;  // the read sits in cluster a and would move to 1 - a
+        double sum = 0.0;
+        bool pert = false;
+        for (uint32_t d = 0; d < D; d++) {
+            const Elem el = m.elem[i * D + d];
+            const double s0 = m.k2_tg[d], s1 = m.k2_tg[16 + d];
+            const double x0 = a ? el.x : -el.x;  // what cluster 0 gains
+            const int dp0 = a ? el.dp : -el.dp, pw0 = a ? el.pw : -el.pw;
+            const double T0 = s0 + x0, T1 = s1 - x0;  // s - x == s + (-x) bit for bit
+            const int P0 = m.k2_np[d] + dp0, P1 = m.k2_np[16 + d] - dp0;
+            const int W0 = m.k2_w[d] + pw0, W1 = m.k2_w[16 + d] - pw0;
+            const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
+            const int in_use = (pos0 ? P0 : 0) + (pos1 ? P1 : 0);
+            const bool any = (pos0 && W0 > 0) || (pos1 && W1 > 0);
+            if (any && 3 * in_use > m.k2_totp2[d]) sum += (pos0 ? T0 : 0.0) + (pos1 ? T1 : 0.0);
+            pert = pert || (T0 - x0 != s0) || (T1 + x0 != s1);  // flip back (:746) would not restore the sum
+        }
+        const uint32_t c0n = a ? c0 + 1 : c0 - 1;
+        const double dA = (m.k2_pair[c0n <= n ? c0n : n] + sum) - lk;
+        float thr = 2.0f;
+        if (!pert && dA < -1e-3) thr = dA <= -44.5 ? -1.0f : __expf((float)dA) * 1.001f + 3e-7f;
+        return thr;
+    };
     double max = lk;
     unsigned long long argmax = lab;
+    publish();
+    float thr_tab = rebuild();
     const uint32_t total = 2000u * n;
-    uint32_t t = 0;
+    uint32_t t = 0, p = 0;
     Window wd;
     window_load(wd, rng, rng.pos, n, lane);
-    uint32_t p = 0;  // parse position inside the window
+    auto calc_rejm = [&]() -> unsigned long long {
+        const float thr = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((wd.idx & 63u) << 2), __float_as_int(thr_tab)));
+        const float u = (float)(uint32_t)(wd.v >> 40) * 0x1p-24f;  // the Bernoulli draw / 2^64 within 2^-24
+        return __ballot(wd.nxt != 255u && u > thr);
+    };
+    unsigned long long rejm = calc_rejm();
+    ST_T0();
     while (t < total) {
-        // ---------------------------------------------------------------- a batch of rejected-by-default steps
-        uint32_t nb = total - t < B ? total - t : B;
-        if (p > 24) {  // keep at least ~8 proposals' worth of draws ahead
-            window_load(wd, rng, wd.base + p, n, lane);
-            p = 0;
-        }
-        // the next nb proposals: follow nxt[] from p; group j takes the proposal that starts at start[j]
-        uint32_t pend[B], src = 0;
-        uint32_t q = p, parsed = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < B; j++) {
-            pend[j] = q;
-            if (j < nb && parsed == j && q < 64) {
-                const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)wd.nxt, (int)q);
-                if (nx != 255u) {
-                    if (g == j) src = q;
-                    q = nx;
-                    pend[j] = q;
-                    parsed = j + 1;
-                }
+        // ---- walk over certainly rejected proposals
+        bool event = false;
+#ifdef JTK_MCMC_STATS
+        const unsigned long long w0 = __builtin_readcyclecounter();
+#endif
+        while (t < total && p < 64) {
+            const uint32_t nx = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.nxt, (int)p));
+            if (nx == 255u) break;
+            if (!((rejm >> p) & 1ull)) {
+                event = true;
+                break;
             }
+            p = nx;
+            t++;
         }
-        if (parsed == 0) {  // not even one proposal fits: move the window
+#ifdef JTK_MCMC_STATS
+        const unsigned long long w1 = __builtin_readcyclecounter();
+        ST_CNT(1, w1 - w0);
+#endif
+        if (!event) {
+            if (t >= total) break;
             window_load(wd, rng, wd.base + p, n, lane);
             p = 0;
+            rejm = calc_rejm();
+#ifdef JTK_MCMC_STATS
+            ST_CNT(2, __builtin_readcyclecounter() - w1);
+            ST_CNT(6, 1);
+#endif
             continue;
         }
-        nb = parsed;
-        if (g >= nb) src = p;  // idle groups shadow proposal 0 (their results are ignored)
-        const uint32_t idx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)wd.idx);
-        const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)(uint32_t)(wd.v >> 32)) << 32) |
-                           (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)(uint32_t)wd.v);
-        const Elem2 el = m.elem2[idx * JTK_GW_MAX + d];
-        const bool old = (lab >> idx) & 1ull;
-        // residue of the earlier proposals of this batch: group g replays proposals 0..g-1.  All operands are
-        // fetched first (independent LDS reads in flight together), then the short dependent f64 chain runs.
-        double rx[B], rxr[B];
-#pragma unroll
-        for (uint32_t s = 0; s + 1 < B; s++) {
-            const uint32_t idx_s = uni((uint32_t)__builtin_amdgcn_readlane((int)idx, (int)(s * GW)));
-            const bool old_s = (lab >> idx_s) & 1ull;
-            const Elem2 *es = &m.elem2[idx_s * JTK_GW_MAX + d];
-            const double ex = es->x, exr = es->xr;
-            rx[s] = old_s ? -ex : ex;
-            rxr[s] = old_s ? -exr : exr;
-        }
-        double s0 = tg0, s1 = tg1;
-#pragma unroll
-        for (uint32_t s = 0; s + 1 < B; s++)
-            if (s + 1 < nb && g > s) {
-                s0 = (s0 - rx[s]) + rx[s];
-                s1 = (s1 + rxr[s]) - rxr[s];
-            }
-        // tentative flip of the group's own proposal
-        const double sx = old ? -el.x : el.x, sxr = old ? -el.xr : el.xr;
-        const int sdp = old ? -el.dp : el.dp, spw = old ? -el.pw : el.pw;
-        const int sdpr = old ? -el.dpr : el.dpr, spwr = old ? -el.pwr : el.pwr;
-        const double T0 = s0 - sx, T1 = s1 + sxr;
-        const int P0 = np0 - sdp, P1 = np1 + sdpr, W0 = w0 - spw, W1 = w1 + spwr;
-        // size term for cluster-0 size c0 + 1 (the read leaves cluster 1) or c0 - 1; lanes c0 +- 1 exist whenever used
-        const double base_up = readlane_f64(pair_lk, c0 < n ? c0 + 1 : c0), base_dn = readlane_f64(pair_lk, c0 > 0 ? c0 - 1 : c0);
-        const double proposed = eval(T0, T1, P0, P1, W0, W1, old ? base_up : base_dn);
+        // ---- the event: one exact step
+        const uint32_t e_idx = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.idx, (int)p));
+        const uint32_t e_nxt = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.nxt, (int)p));
+        const bool old = (lab >> e_idx) & 1ull;
+        Elem el = {0.0, 0, 0};
+        if (slane) el = m.elem[e_idx * D + sd];
+        const bool leave = sc == (old ? 1u : 0u);
+        const double T = leave ? tg - el.x : tg + el.x;
+        const int P = leave ? np - el.dp : np + el.dp, W = leave ? w - el.pw : w + el.pw;
+        const uint32_t c0n = old ? c0 + 1 : c0 - 1;
+        const double proposed = exact_eval(T, P, W, pair_at(c0n));
         const double diff = proposed - lk;
-        // per-group decision with the guarded f32 test; anything else is an "event"
-        bool reject = false;
-        if (diff <= -44.4) {
-            reject = true;
-        } else if (diff < -1e-3) {
-            const float u = (float)(uint32_t)(v >> 40) * 0x1p-24f;
-            const float pe = __expf((float)diff);
-            reject = u > pe * 1.001f + 3e-7f;
+        // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
+        // exactly when diff >= -2^-54
+        const bool no_draw = ubool(diff >= -0x1p-54);
+        bool accept = true;
+        if (!no_draw) {
+            const uint64_t e_v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wd.v >> 32), (int)p) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wd.v, (int)p);
+            accept = bernoulli_exact(uni64(e_v), diff);
         }
-        const unsigned long long eventm = __ballot(lead && g < nb && !reject);
-        const uint32_t n_rej = eventm ? (uint32_t)__builtin_ctzll(eventm) / GW : nb;
-        if (n_rej > 0) {
-            // state after n_rej rejected steps = group (n_rej-1)'s state after its own flip-back
-            const double u0 = T0 + sx, u1 = T1 - sxr;
-            tg0 = bcast_group(u0, n_rej - 1);
-            tg1 = bcast_group(u1, n_rej - 1);
-            t += n_rej;
-#pragma unroll
-            for (uint32_t j = 0; j < B; j++)
-                if (j + 1 == n_rej) p = pend[j];
-        }
-        if (!eventm) continue;
-        // ---------------------------------------------------------------- the event: one exact step (group n_rej)
-        {
-            // its operands, made uniform
-            const uint32_t ev = n_rej * GW + (GW - D);  // lead lane of the event group
-            const double e_prop = unif64(readlane_f64(proposed, ev));
-            const double e_diff = unif64(e_prop - lk);
-            const uint32_t e_idx = uni((uint32_t)__builtin_amdgcn_readlane((int)idx, (int)(n_rej * GW)));
-            const bool no_draw = ubool(e_diff >= -0x1p-54);
-            bool accept = true;
-            uint32_t p_after = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < B; j++)
-                if (j == n_rej) p_after = pend[j];  // position after this proposal INCLUDING its Bernoulli draw
-            if (no_draw) {
-                p_after -= 1;  // gen_bool(1.0) takes no draw
-            } else {
-                const uint64_t e_v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)(n_rej * GW)) << 32) |
-                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)(n_rej * GW));
-                accept = bernoulli_exact(e_v, e_diff);
+        bool changed = true;
+        if (accept) {
+            tg = T;
+            np = P;
+            w = W;
+            c0 = c0n;
+            lab ^= 1ull << e_idx;
+            lk = proposed;
+            if (ubool(max < lk)) {
+                max = proposed;
+                argmax = lab;
             }
-            if (accept) {
-                // commit the event group's tentative state everywhere
-                tg0 = bcast_group(T0, n_rej);
-                tg1 = bcast_group(T1, n_rej);
-                np0 = __builtin_amdgcn_ds_bpermute((int)((n_rej * GW + d) << 2), P0);
-                np1 = __builtin_amdgcn_ds_bpermute((int)((n_rej * GW + d) << 2), P1);
-                w0 = __builtin_amdgcn_ds_bpermute((int)((n_rej * GW + d) << 2), W0);
-                w1 = __builtin_amdgcn_ds_bpermute((int)((n_rej * GW + d) << 2), W1);
-                c0 = ((lab >> e_idx) & 1ull) ? c0 + 1 : c0 - 1;
-                lab ^= 1ull << e_idx;
-                lk = e_prop;
-                if (ubool(max < lk)) {
-                    max = e_prop;
-                    argmax = lab;
-                }
-            } else {
-                const double u0 = T0 + sx, u1 = T1 - sxr;  // flip back (:746), keeping the rounding residue
-                tg0 = bcast_group(u0, n_rej);
-                tg1 = bcast_group(u1, n_rej);
-            }
-            t++;
-            p = p_after;
+        } else {
+            const double back = leave ? T + el.x : T - el.x;  // flip back (:746), keeping the rounding residue
+            changed = __ballot(slane && back != tg) != 0ull;
+            tg = back;
         }
+        t++;
+        p = no_draw ? e_nxt - 1 : e_nxt;
+#ifdef JTK_MCMC_STATS
+        const unsigned long long w2 = __builtin_readcyclecounter();
+        ST_CNT(3, w2 - w1);
+        ST_CNT(7, 1);
+        ST_CNT(8, accept ? 1 : 0);
+        ST_CNT(9, changed ? 1 : 0);
+#endif
+        if (changed) {
+            publish();
+            thr_tab = rebuild();
+            rejm = calc_rejm();
+        }
+#ifdef JTK_MCMC_STATS
+        ST_CNT(4, __builtin_readcyclecounter() - w2);
+#endif
     }
+    ST_ADD(0);
+    ST_CNT(5, total);
     rng.pos = wd.base + p;
     rng_release(rng, lane);
     if (lane < n) m.assign[lane] = (uint8_t)((argmax >> lane) & 1ull);
@@ -934,10 +936,7 @@ __device__ __forceinline__ double mcmc_chain_k2b(const Lds &m, uint32_t n, uint3
 
 template <int K>
 __device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
-    // a lane serves column d of cluster 0 and column GW-1-d of cluster 1; only layouts in which no lane carries
-    // both (D <= GW/2) are enabled -- the overlapped layout did not reproduce the oracle and is left out
-    if (K == 2 && n <= 63 && D <= 4) return mcmc_chain_k2b<8>(m, n, D, cov, rng, lane);
-    if (K == 2 && n <= 63 && D <= 8) return mcmc_chain_k2b<16>(m, n, D, cov, rng, lane);
+    if (K == 2 && n <= 63 && D >= 1 && D <= 16) return mcmc_chain_k2t(m, n, D, cov, rng, lane);
     if (n <= 63) return mcmc_chain<K, true>(m, n, D, cov, rng, lane);
     return mcmc_chain<K, false>(m, n, D, cov, rng, lane);
 }
@@ -1103,7 +1102,12 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         };
         m.ctl = (RCtl *)take(sizeof(RCtl));
         m.ring = (uint64_t *)take(sizeof(uint64_t) * RN);
-        m.elem2 = (Elem2 *)take((size_t)(lds_n < 63 ? lds_n : 63) * JTK_GW_MAX * sizeof(Elem2));
+        m.k2_pair = (double *)take(64 * 8);
+        m.k2_tg = (double *)take(32 * 8);
+        m.k2_np = (int *)take(32 * 4);
+        m.k2_w = (int *)take(32 * 4);
+        m.k2_totp2 = (int *)take(16 * 4);
+        m.k2_stats = (unsigned long long *)take(16 * 8);
         m.elem = (Elem *)take((size_t)lds_n * lds_d * sizeof(Elem));
         m.data = (double *)take((size_t)lds_n * lds_d * 8);
         m.size_to_lk = (double *)take((size_t)(lds_n + 1) * 8);
@@ -1142,29 +1146,6 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         el.pw = 3 * el.dp - 7 * (x < -JTK_POS_THR ? 1 : 0);
         m.elem[e] = el;
     }
-    if (n <= 63)
-        for (uint32_t e = lane; e < n * JTK_GW_MAX; e += 64) {
-            // lane d of the batched diploid chain: column d for cluster 0, column GW-1-d for cluster 1 (GW = 8 or 16)
-            const uint32_t i = e / JTK_GW_MAX, dd = e % JTK_GW_MAX, gw = D <= 4 ? 8 : 16;
-            const uint32_t dl = dd & (gw - 1);
-            Elem2 q = {0.0, 0.0, 0, 0, 0, 0};
-            if (dd < gw) {
-                if (dl < D) {
-                    const double x = feat[i * D + dl];
-                    q.x = x;
-                    q.dp = JTK_POS_THR < x ? 1 : 0;
-                    q.pw = 3 * q.dp - 7 * (x < -JTK_POS_THR ? 1 : 0);
-                }
-                const uint32_t dr = gw - 1 - dl;
-                if (dr < D) {
-                    const double x = feat[i * D + dr];
-                    q.xr = x;
-                    q.dpr = JTK_POS_THR < x ? 1 : 0;
-                    q.pwr = 3 * q.dpr - 7 * (x < -JTK_POS_THR ? 1 : 0);
-                }
-            }
-            m.elem2[e] = q;
-        }
     // lfact[x] = sum_{c=1..x} ln c, summed left to right as poisson_lk does (:636-638)
     if (lane == 0) {
         double s = 0.0;
@@ -1176,6 +1157,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
     }
     for (uint32_t d = lane; d < D; d += 64) m.prev_used[d] = 0;
     for (uint32_t i = lane; i < n; i += 64) m.accepted[i] = 0;
+    if (lane < 16) m.k2_stats[lane] = 0;
     wsync();
     const uint32_t *vt = vtype_all + 2 * ((uint64_t)ci * JTK_MAX_DIM);
     if (vt_stride_mode) vt = vtype_all + 2 * vt_off_all[ci];
@@ -1247,6 +1229,12 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
     }
     // stop the producer wave
     if (lane == 0) lds_st32(&m.ctl->quit, 1);
+#ifdef JTK_MCMC_STATS
+    if (lane == 0)
+        printf("K2STAT chunk %u n %u D %u cyc %llu walk %llu win %llu event %llu rebuild %llu steps %llu windows %llu events %llu accepts %llu changed %llu\n",
+               ci, n, D, m.k2_stats[0], m.k2_stats[1], m.k2_stats[2], m.k2_stats[3], m.k2_stats[4], m.k2_stats[5],
+               m.k2_stats[6], m.k2_stats[7], m.k2_stats[8], m.k2_stats[9]);
+#endif
     if (failed) {
         if (lane == 0) st->status = JTK_ERR_CHUNK_FAILED;
         return;
@@ -1283,10 +1271,77 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
     size_t b = al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
-               al((size_t)(lds_n < 63 ? lds_n : 63) * JTK_GW_MAX * sizeof(Elem2)) +
+               al(64 * 8) + al(32 * 8) + 2 * al(32 * 4) + al(16 * 4) + al(16 * 8) +
                al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) + 2 * al((size_t)JTK_MAX_COPY * lds_d * 8) +
                2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d);
     return b;
+}
+
+// ---- host: the nibble table of M^(63*SEG), from nothing but the generator's own step function
+namespace {
+struct V256 {
+    uint64_t w[4];
+};
+V256 host_xo_step(V256 v) {
+    uint64_t s0 = v.w[0], s1 = v.w[1], s2 = v.w[2], s3 = v.w[3];
+    const uint64_t t = s1 << 17;
+    s2 ^= s0;
+    s3 ^= s1;
+    s1 ^= s2;
+    s0 ^= s3;
+    s2 ^= t;
+    s3 = (s3 << 45) | (s3 >> 19);
+    return V256{{s0, s1, s2, s3}};
+}
+struct M256 {
+    V256 col[256];  // image of unit vector b (bit b & 63 of word b >> 6)
+};
+V256 m_apply(const M256 &a, const V256 &v) {
+    V256 r{{0, 0, 0, 0}};
+    for (int b = 0; b < 256; b++)
+        if ((v.w[b >> 6] >> (b & 63)) & 1ull)
+            for (int q = 0; q < 4; q++) r.w[q] ^= a.col[b].w[q];
+    return r;
+}
+void m_mul(const M256 &a, const M256 &b, M256 &out) {  // out = a * b
+    for (int i = 0; i < 256; i++) out.col[i] = m_apply(a, b.col[i]);
+}
+const std::vector<uint64_t> &jump_table_host() {
+    static std::vector<uint64_t> tab;
+    if (!tab.empty()) return tab;
+    auto *m = new M256, *acc = new M256, *tmp = new M256;
+    for (int b = 0; b < 256; b++) {
+        V256 e{{0, 0, 0, 0}};
+        e.w[b >> 6] = 1ull << (b & 63);
+        m->col[b] = host_xo_step(e);
+        acc->col[b] = e;  // identity
+    }
+    for (uint32_t e = 63u * SEG; e; e >>= 1) {  // acc = M^(63*SEG) by square and multiply
+        if (e & 1u) {
+            m_mul(*m, *acc, *tmp);
+            *acc = *tmp;
+        }
+        m_mul(*m, *m, *tmp);
+        *m = *tmp;
+    }
+    tab.resize(64 * 16 * 4);
+    for (int k = 0; k < 64; k++)
+        for (int v = 0; v < 16; v++) {
+            V256 x{{0, 0, 0, 0}};
+            x.w[k >> 4] = (uint64_t)v << (4 * (k & 15));
+            const V256 r = m_apply(*acc, x);
+            for (int q = 0; q < 4; q++) tab[((size_t)k * 16 + v) * 4 + q] = r.w[q];
+        }
+    delete m;
+    delete acc;
+    delete tmp;
+    return tab;
+}
+}  // namespace
+
+int mcmc_upload_jump_table(hipStream_t s) {
+    const std::vector<uint64_t> &tab = jump_table_host();
+    return (int)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_jump_tab), tab.data(), tab.size() * 8, 0, hipMemcpyHostToDevice, s);
 }
 
 void launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
@@ -1295,6 +1350,7 @@ void launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, Chun
                  const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d) {
     if (n_chunks == 0) return;
     const size_t lds = mcmc_lds_bytes(lds_n, lds_d);
+    if (mcmc_upload_jump_table(s) != 0) return;  // 32 KiB, stream-ordered before the kernel; the launch then fails loudly
     mcmc_kernel<<<n_chunks, 128, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
                                           post_stride, lg, lg_off, lds_n, lds_d);
 }
