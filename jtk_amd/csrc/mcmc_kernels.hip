@@ -132,7 +132,7 @@ __device__ __forceinline__ void wsync() {
 }
 __device__ __forceinline__ double unif64(double v) { return jtk_bits_f64(uni64(jtk_f64_bits(v))); }
 // a wave-uniform condition as a scalar: branches on it are s_cbranch, not exec-mask regions
-__device__ __forceinline__ bool ubool(bool c) { return uni(c ? 1u : 0u) != 0u; }
+__device__ __forceinline__ bool ubool(bool c) { return __ballot(c) != 0ull; }  // c is the same in every lane
 
 // LDS work area of one chunk
 struct Elem {  // one (read, column) cell as the chain needs it
@@ -143,10 +143,6 @@ struct Elem {  // one (read, column) cell as the chain needs it
 struct Lds {
     RCtl *ctl;
     uint64_t *ring;      // RN raw draws
-    double *k2_pair;     // 64: size terms of get_lk by cluster-0 size (diploid chain)
-    double *k2_tg;       // 32: published LKCount[c][d].total_gain at 16*c + d
-    int *k2_np, *k2_w;   // 32 each: num_pos and 3*num_pos - 7*num_neg
-    int *k2_totp2;       // 16: 2 x reads with a positive value per column
     unsigned long long *k2_stats;  // 16 debug counters (JTK_MCMC_STATS builds only)
     Elem *elem;          // n x D
     double *data;        // n x D
@@ -499,13 +495,12 @@ __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint64_
 // gen_bool compares the u64 draw v with p_int = floor(exp(diff) * 2^64).  The exact exp is only evaluated
 // when an f32 estimate with a guard band cannot decide, so the decision is always the exact one.
 __device__ __forceinline__ bool bernoulli_exact(uint64_t v, double diff) {
-    if (ubool(diff <= -44.4)) return false;  // exp(diff) * 2^64 < 1  =>  p_int == 0
-    if (ubool(diff < -1e-3)) {
-        const float u = (float)(uint32_t)(v >> 40) * 0x1p-24f;  // v / 2^64 within 2^-24
-        const float pe = __expf((float)diff);
-        if (ubool(u < pe * 0.999f - 3e-7f)) return true;
-        if (ubool(u > pe * 1.001f + 3e-7f)) return false;
-    }
+    // f32 estimate first: u = v / 2^64 within 2^-24, pe = exp(diff) within ~1e-5 relative
+    const float u = (float)(uint32_t)(v >> 40) * 0x1p-24f;
+    const float pe = __expf((float)diff);
+    const bool in_range = diff < -1e-3 && diff > -44.4;
+    if (ubool(diff <= -44.4 || (in_range && u > pe * 1.001f + 3e-7f))) return false;  // exp(diff) * 2^64 < 1 => p_int == 0
+    if (ubool(in_range && u < pe * 0.999f - 3e-7f)) return true;
     const double scaled = unif64(jtk_exp(diff)) * 18446744073709551616.0;
     return v < uni64(__double2ull_rz(scaled));
 }
@@ -675,7 +670,7 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// The diploid chain (K == 2, n <= 63, D <= 16) as a table-driven walk.
+// The diploid chain (K == 2, n <= 63, D <= 8) as a table-driven walk.
 //
 // More than 96% of the proposals are rejected, and in a given state the fate of "flip read i" is the same every
 // time it is proposed: proposed - lk depends on the state only.  So the chain keeps, per read (one lane each), a
@@ -719,7 +714,7 @@ __device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t base,
     const uint32_t pi = lane + (uint32_t)__builtin_ctzll(m1 | (1ull << 63));
     const unsigned long long m2 = pi < 63 ? topm >> (pi + 1) : 0ull;
     const uint32_t pv = pi + 1 + (uint32_t)__builtin_ctzll(m2 | (1ull << 63)) + 1;
-    const bool fits = m1 != 0 && m2 != 0 && pv < 64;
+    const bool fits = m1 != 0 && m2 != 0 && pv < 63;  // nxt = pv + 1 stays inside the window
     wd.idx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pi & 63) << 2), (int)hi);
     const uint32_t vlo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pv & 63) << 2), (int)(uint32_t)draw);
     const uint32_t vhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pv & 63) << 2), (int)(uint32_t)(draw >> 32));
@@ -728,17 +723,20 @@ __device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t base,
 }
 
 #ifdef JTK_MCMC_STATS
-#define ST_T0() const unsigned long long st_t0 = __builtin_readcyclecounter()
-#define ST_ADD(k) if (lane == 0) m.k2_stats[k] += __builtin_readcyclecounter() - st_t0
-#define ST_CNT(k, v) if (lane == 0) m.k2_stats[k] += (v)
+// counters live in scalar registers during the chain and are folded into LDS once per chain
+#define ST_T0() unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_t0 = __builtin_readcyclecounter()
+#define ST_ADD(k) st_acc[k] += __builtin_readcyclecounter() - st_t0; if (lane == 0) { for (int q_ = 0; q_ < 10; q_++) m.k2_stats[q_] += st_acc[q_]; }
+#define ST_CNT(k, v) st_acc[k] += (v)
 #else
 #define ST_T0()
 #define ST_ADD(k)
 #define ST_CNT(k, v)
 #endif
+template <int DMAX>
 __device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng,
                                                  uint32_t lane) {
-    // pair table: entry c0 is (0.0 + size_to_lk[c0]) + size_to_lk[n - c0]   (get_lk :788)
+    // pair table: lane c0 holds (0.0 + size_to_lk[c0]) + size_to_lk[n - c0]   (get_lk :788)
+    double pair_v;
     {
         auto size_lk = [&](uint32_t x) {
             double mx = -__builtin_inf();
@@ -749,137 +747,176 @@ __device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint3
             return mx;
         };
         const uint32_t c0 = lane <= n ? lane : n;
-        m.k2_pair[lane] = (0.0 + size_lk(c0)) + size_lk(n - c0);
+        pair_v = (0.0 + size_lk(c0)) + size_lk(n - c0);
     }
-    // ---- exact state: lane 16*c + d holds LKCount[c][d]
-    const uint32_t sc = (lane >> 4) & 1u, sd = lane & 15u;
-    const bool slane = lane < 32 && sd < D;
-    double tg = 0.0;
-    int np = 0, w = 0;
+    // ---- exact state, REPLICATED in every lane (wave-uniform values in vector registers, so neither the exact
+    //      step nor the table rebuild needs a cross-lane operation): LKCount[c][d] for d < DMAX; columns >= D are
+    //      all-zero, never used and add +0.0.  The two counters travel packed:
+    //      pk = num_pos + 65536 * (3*num_pos - 7*num_neg), so pk > 0xffff <=> the second one is positive.
+    double tg0[DMAX], tg1[DMAX];
+    int pk0[DMAX], pk1[DMAX], tp2[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; d++) {
+        tg0[d] = tg1[d] = 0.0;
+        pk0[d] = pk1[d] = tp2[d] = 0;
+    }
     uint32_t c0 = 0;
     unsigned long long lab = 0;
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t c = uni(m.assign[i]);
-        Elem el = {0.0, 0, 0};
-        if (slane) el = m.elem[i * D + sd];
-        if (c == sc) {
-            tg += el.x;
-            np += el.dp;
-            w += el.pw;
+#pragma unroll
+        for (int d = 0; d < DMAX; d++) {
+            Elem el = {0.0, 0, 0};
+            if ((uint32_t)d < D) el = m.elem[i * D + d];
+            tp2[d] += 2 * el.dp;  // 2 x reads with a positive value in this column: constant along the chain
+            if (c == 0) {
+                tg0[d] += el.x;
+                pk0[d] += el.dp + 65536 * el.pw;
+            } else {
+                tg1[d] += el.x;
+                pk1[d] += el.dp + 65536 * el.pw;
+            }
         }
         if (c == 0)
             c0++;
         else
             lab |= 1ull << i;
     }
-    const int totp2_l = 2 * (np + __shfl_xor(np, 16, 64));  // 2 x reads with a positive value in column sd
-    if (lane < 16) m.k2_totp2[lane] = totp2_l;
-    wsync();
-    // get_lk (:785-795) of a tentative state, exactly: size terms, then clusters outer / columns inner, left to right
-    auto exact_eval = [&](double T, int P, int W, double base) -> double {
-        const bool pos = slane && 0.0 < T;
-        const int u = pos ? P : 0, a = (pos && W > 0) ? 1 : 0;
-        const int in_use = u + __shfl_xor(u, 16, 64), any = a | __shfl_xor(a, 16, 64);
-        const bool used = any != 0 && 3 * in_use > totp2_l;  // get_used_columns (:847-869)
-        const double term = (used && pos) ? T : 0.0;        // an unused column adds nothing, total_gain.max(0) adds 0
-        double S = base;
-        for (uint32_t q = 0; q < D; q++) S += readlane_f64(term, q);
-        for (uint32_t q = 0; q < D; q++) S += readlane_f64(term, 16 + q);
-        return unif64(S);
-    };
-    auto pair_at = [&](uint32_t c) -> double { return unif64(m.k2_pair[c <= n ? c : n]); };
-    auto publish = [&]() {
-        if (slane) {
-            m.k2_tg[lane] = tg;
-            m.k2_np[lane] = np;
-            m.k2_w[lane] = w;
+    // ---- read `lane`'s row, signed by the direction of its flip: sx[d] is what cluster 0 would gain
+    const uint32_t ri = lane < n ? lane : 0;
+    double sx[DMAX];
+    int spk[DMAX];
+    {
+        const bool a = (lab >> ri) & 1ull;
+#pragma unroll
+        for (int d = 0; d < DMAX; d++) {
+            Elem el = {0.0, 0, 0};
+            if ((uint32_t)d < D) el = m.elem[ri * D + d];
+            sx[d] = a ? el.x : -el.x;
+            spk[d] = a ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
         }
-        wsync();
+    }
+    wsync();
+    auto pair_at = [&](uint32_t c) -> double { return readlane_f64(pair_v, c <= n ? c : n); };
+    // get_lk (:785-795) of a tentative state, exactly: size terms, then clusters outer / columns inner, left to right
+    auto exact_eval = [&](const double *T0, const double *T1, const int *K0, const int *K1, double base) -> double {
+        bool used[DMAX];
+#pragma unroll
+        for (int d = 0; d < DMAX; d++) {
+            const bool pos0 = 0.0 < T0[d], pos1 = 0.0 < T1[d];
+            const int in_use = ((pos0 ? K0[d] : 0) + (pos1 ? K1[d] : 0)) & 0xffff;
+            const bool any = (pos0 && K0[d] > 0xffff) || (pos1 && K1[d] > 0xffff);
+            used[d] = any && 3 * in_use > tp2[d];  // get_used_columns (:847-869)
+        }
+        double S = base;
+#pragma unroll
+        for (int d = 0; d < DMAX; d++) S += (used[d] && 0.0 < T0[d]) ? T0[d] : 0.0;
+#pragma unroll
+        for (int d = 0; d < DMAX; d++) S += (used[d] && 0.0 < T1[d]) ? T1[d] : 0.0;
+        return S;
     };
-    double lk = exact_eval(tg, np, w, pair_at(c0));
-    // the rejection threshold of "flip read `lane`" in the published state
+    double lk = exact_eval(tg0, tg1, pk0, pk1, pair_at(c0));
+    double pair_up = pair_at(c0 + 1), pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
+    // the rejection threshold of "flip read `lane`" in the current state (order-free sum; see the header)
     auto rebuild = [&]() -> float {
-        const uint32_t i = lane < n ? lane : 0;
-        const bool a = (lab >> i) & 1ull;  // the read sits in cluster a and would move to 1 - a
         double sum = 0.0;
         bool pert = false;
-        for (uint32_t d = 0; d < D; d++) {
-            const Elem el = m.elem[i * D + d];
-            const double s0 = m.k2_tg[d], s1 = m.k2_tg[16 + d];
-            const double x0 = a ? el.x : -el.x;  // what cluster 0 gains
-            const int dp0 = a ? el.dp : -el.dp, pw0 = a ? el.pw : -el.pw;
-            const double T0 = s0 + x0, T1 = s1 - x0;  // s - x == s + (-x) bit for bit
-            const int P0 = m.k2_np[d] + dp0, P1 = m.k2_np[16 + d] - dp0;
-            const int W0 = m.k2_w[d] + pw0, W1 = m.k2_w[16 + d] - pw0;
+#pragma unroll
+        for (int d = 0; d < DMAX; d++) {
+            const double T0 = tg0[d] + sx[d], T1 = tg1[d] - sx[d];  // s - x == s + (-x) bit for bit
+            const int K0 = pk0[d] + spk[d], K1 = pk1[d] - spk[d];
             const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
-            const int in_use = (pos0 ? P0 : 0) + (pos1 ? P1 : 0);
-            const bool any = (pos0 && W0 > 0) || (pos1 && W1 > 0);
-            if (any && 3 * in_use > m.k2_totp2[d]) sum += (pos0 ? T0 : 0.0) + (pos1 ? T1 : 0.0);
-            pert = pert || (T0 - x0 != s0) || (T1 + x0 != s1);  // flip back (:746) would not restore the sum
+            const int in_use = ((pos0 ? K0 : 0) + (pos1 ? K1 : 0)) & 0xffff;
+            const bool any = (pos0 && K0 > 0xffff) || (pos1 && K1 > 0xffff);
+            const bool used = any && 3 * in_use > tp2[d];
+            sum += ((used && pos0) ? T0 : 0.0) + ((used && pos1) ? T1 : 0.0);
+            pert = pert || (T0 - sx[d] != tg0[d]) || (T1 + sx[d] != tg1[d]);  // flip back (:746) would not restore the sum
         }
-        const uint32_t c0n = a ? c0 + 1 : c0 - 1;
-        const double dA = (m.k2_pair[c0n <= n ? c0n : n] + sum) - lk;
+        const bool a = (lab >> ri) & 1ull;
+        const double dA = ((a ? pair_up : pair_dn) + sum) - lk;
         float thr = 2.0f;
         if (!pert && dA < -1e-3) thr = dA <= -44.5 ? -1.0f : __expf((float)dA) * 1.001f + 3e-7f;
         return thr;
     };
     double max = lk;
     unsigned long long argmax = lab;
-    publish();
     float thr_tab = rebuild();
     const uint32_t total = 2000u * n;
     uint32_t t = 0, p = 0;
     Window wd;
     window_load(wd, rng, rng.pos, n, lane);
-    auto calc_rejm = [&]() -> unsigned long long {
+    // per window position l: nxt[l] in bits 0..5 and, in bit 6, "the proposal starting at l fits in the window and
+    // is certainly rejected" -- one v_readlane per hop yields both
+    auto calc_rejm = [&]() -> uint32_t {
         const float thr = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((wd.idx & 63u) << 2), __float_as_int(thr_tab)));
         const float u = (float)(uint32_t)(wd.v >> 40) * 0x1p-24f;  // the Bernoulli draw / 2^64 within 2^-24
-        return __ballot(wd.nxt != 255u && u > thr);
+        return (wd.nxt & 63u) | ((wd.nxt != 255u && u > thr) ? 64u : 0u);
     };
-    unsigned long long rejm = calc_rejm();
+    auto nxt_at = [&](uint32_t q) -> uint32_t { return uni((uint32_t)__builtin_amdgcn_readlane((int)wd.nxt, (int)q)); };
+    uint32_t hopw = calc_rejm();
     ST_T0();
     while (t < total) {
-        // ---- walk over certainly rejected proposals
-        bool event = false;
-#ifdef JTK_MCMC_STATS
-        const unsigned long long w0 = __builtin_readcyclecounter();
-#endif
-        while (t < total && p < 64) {
-            const uint32_t nx = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.nxt, (int)p));
-            if (nx == 255u) break;
-            if (!((rejm >> p) & 1ull)) {
-                event = true;
-                break;
+        // ---- walk over certainly rejected proposals (nxt < 64 wherever the rejm bit is set)
+        if (total - t >= 24) {  // a window holds at most 21 proposals: no need to watch the step budget
+            // straight-line hops with forward exits: a taken branch costs a lone wave far more than the hop itself
+            uint32_t steps = 22;
+#pragma unroll
+            for (uint32_t k = 0; k < 22; k++) {
+                const uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
+                if (!(hv & 64u)) {
+                    steps = k;
+                    break;
+                }
+                p = hv & 63u;
             }
-            p = nx;
-            t++;
-        }
-#ifdef JTK_MCMC_STATS
-        const unsigned long long w1 = __builtin_readcyclecounter();
-        ST_CNT(1, w1 - w0);
-#endif
-        if (!event) {
+            t += steps;
+        } else {
+            while (t < total) {
+                const uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
+                if (!(hv & 64u)) break;
+                p = hv & 63u;
+                t++;
+            }
             if (t >= total) break;
+        }
+        const uint32_t e_nxt = nxt_at(p);
+        if (e_nxt == 255u) {  // the proposal at p does not fit: move the window there
             window_load(wd, rng, wd.base + p, n, lane);
             p = 0;
-            rejm = calc_rejm();
-#ifdef JTK_MCMC_STATS
-            ST_CNT(2, __builtin_readcyclecounter() - w1);
+            hopw = calc_rejm();
             ST_CNT(6, 1);
-#endif
             continue;
         }
         // ---- the event: one exact step
         const uint32_t e_idx = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.idx, (int)p));
-        const uint32_t e_nxt = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.nxt, (int)p));
         const bool old = (lab >> e_idx) & 1ull;
-        Elem el = {0.0, 0, 0};
-        if (slane) el = m.elem[e_idx * D + sd];
-        const bool leave = sc == (old ? 1u : 0u);
-        const double T = leave ? tg - el.x : tg + el.x;
-        const int P = leave ? np - el.dp : np + el.dp, W = leave ? w - el.pw : w + el.pw;
-        const uint32_t c0n = old ? c0 + 1 : c0 - 1;
-        const double proposed = exact_eval(T, P, W, pair_at(c0n));
+        double x0[DMAX], T0[DMAX], T1[DMAX];  // x0: what cluster 0 gains
+        int K0[DMAX], K1[DMAX];
+#pragma unroll
+        for (int d = 0; d < DMAX; d++) {
+            int k0;
+            if (DMAX <= 2) {  // the read's own lane has its signed row in registers
+                x0[d] = readlane_f64(sx[d], e_idx);
+                k0 = __builtin_amdgcn_readlane(spk[d], (int)e_idx);
+            } else {
+                Elem el = {0.0, 0, 0};
+                if ((uint32_t)d < D) el = m.elem[e_idx * D + d];
+                x0[d] = old ? el.x : -el.x;
+                k0 = old ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
+            }
+            T0[d] = tg0[d] + x0[d];
+            T1[d] = tg1[d] - x0[d];
+            K0[d] = pk0[d] + k0;
+            K1[d] = pk1[d] - k0;
+        }
+#ifdef JTK_MCMC_STATS
+        {
+            bool nz = false;
+            for (int d = 0; d < DMAX; d++) nz = nz || x0[d] != 0.0;
+            ST_CNT(2, nz ? 0 : 1);
+        }
+#endif
+        const double proposed = exact_eval(T0, T1, K0, K1, old ? pair_up : pair_dn);
         const double diff = proposed - lk;
         // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
         // exactly when diff >= -2^-54
@@ -892,9 +929,221 @@ __device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint3
         }
         bool changed = true;
         if (accept) {
-            tg = T;
-            np = P;
-            w = W;
+#pragma unroll
+            for (int d = 0; d < DMAX; d++) {
+                tg0[d] = T0[d];
+                tg1[d] = T1[d];
+                pk0[d] = K0[d];
+                pk1[d] = K1[d];
+            }
+            c0 = old ? c0 + 1 : c0 - 1;
+            pair_up = pair_at(c0 + 1);
+            pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
+            lab ^= 1ull << e_idx;
+            lk = proposed;
+            if (ubool(max < lk)) {
+                max = proposed;
+                argmax = lab;
+            }
+            if (lane == e_idx) {  // the read now flips the other way
+#pragma unroll
+                for (int d = 0; d < DMAX; d++) {
+                    sx[d] = -sx[d];
+                    spk[d] = -spk[d];
+                }
+            }
+        } else {
+            bool ch = false;
+#pragma unroll
+            for (int d = 0; d < DMAX; d++) {
+                const double b0 = T0[d] - x0[d], b1 = T1[d] + x0[d];  // flip back (:746), keeping the rounding residue
+                ch = ch || b0 != tg0[d] || b1 != tg1[d];
+                tg0[d] = b0;
+                tg1[d] = b1;
+            }
+            changed = ubool(ch);
+        }
+        t++;
+        p = no_draw ? e_nxt - 1 : e_nxt;
+        ST_CNT(7, 1);
+        ST_CNT(8, accept ? 1 : 0);
+        ST_CNT(9, changed ? 1 : 0);
+        if (changed) {
+            thr_tab = rebuild();
+            hopw = calc_rejm();
+        }
+    }
+    ST_CNT(5, total);
+    ST_ADD(0);
+    rng.pos = wd.base + p;
+    rng_release(rng, lane);
+    if (lane < n) m.assign[lane] = (uint8_t)((argmax >> lane) & 1ull);
+    wsync();
+    return max;
+}
+
+// The same chain for 5..8 columns: replicating 8 columns of state in every lane does not fit the register budget,
+// so here lane d holds column d of the state and the table rebuild / exact sum fetch it with v_readlane.
+template <int DMAX>
+__device__ __forceinline__ double mcmc_chain_k2w(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng,
+                                                 uint32_t lane) {
+    double pair_v;
+    {
+        auto size_lk = [&](uint32_t x) {
+            double mx = -__builtin_inf();
+            for (int c = 1; c <= 2; c++) {
+                const double lam = cov * (double)c;
+                mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
+            }
+            return mx;
+        };
+        const uint32_t c0 = lane <= n ? lane : n;
+        pair_v = (0.0 + size_lk(c0)) + size_lk(n - c0);
+    }
+    const bool slane = lane < D;
+    double tg0 = 0.0, tg1 = 0.0;
+    int pk0 = 0, pk1 = 0, np_all = 0;
+    uint32_t c0 = 0;
+    unsigned long long lab = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t c = uni(m.assign[i]);
+        Elem el = {0.0, 0, 0};
+        if (slane) el = m.elem[i * D + lane];
+        np_all += el.dp;
+        if (c == 0) {
+            tg0 += el.x;
+            pk0 += el.dp + 65536 * el.pw;
+            c0++;
+        } else {
+            tg1 += el.x;
+            pk1 += el.dp + 65536 * el.pw;
+            lab |= 1ull << i;
+        }
+    }
+    const int totp2 = 2 * np_all;
+    const uint32_t ri = lane < n ? lane : 0;
+    double sx[DMAX];
+    int spk[DMAX];
+    {
+        const bool a = (lab >> ri) & 1ull;
+#pragma unroll
+        for (int d = 0; d < DMAX; d++) {
+            Elem el = {0.0, 0, 0};
+            if ((uint32_t)d < D) el = m.elem[ri * D + d];
+            sx[d] = a ? el.x : -el.x;
+            spk[d] = a ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
+        }
+    }
+    wsync();
+    auto pair_at = [&](uint32_t c) -> double { return readlane_f64(pair_v, c <= n ? c : n); };
+    auto exact_eval = [&](double T0, double T1, int K0, int K1, double base) -> double {
+        const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
+        const int in_use = ((pos0 ? K0 : 0) + (pos1 ? K1 : 0)) & 0xffff;
+        const bool any = (pos0 && K0 > 0xffff) || (pos1 && K1 > 0xffff);
+        const bool used = any && 3 * in_use > totp2;
+        const double term0 = (used && pos0) ? T0 : 0.0, term1 = (used && pos1) ? T1 : 0.0;
+        double S = base;
+#pragma unroll
+        for (int q = 0; q < DMAX; q++) S += readlane_f64(term0, q);
+#pragma unroll
+        for (int q = 0; q < DMAX; q++) S += readlane_f64(term1, q);
+        return S;
+    };
+    double lk = exact_eval(tg0, tg1, pk0, pk1, pair_at(c0));
+    auto rebuild = [&]() -> float {
+        double sum = 0.0;
+        bool pert = false;
+#pragma unroll
+        for (int d = 0; d < DMAX; d++) {
+            const double s0 = readlane_f64(tg0, d), s1 = readlane_f64(tg1, d);
+            const int k0 = __builtin_amdgcn_readlane(pk0, d), k1 = __builtin_amdgcn_readlane(pk1, d);
+            const int tp = __builtin_amdgcn_readlane(totp2, d);
+            const double T0 = s0 + sx[d], T1 = s1 - sx[d];
+            const int K0 = k0 + spk[d], K1 = k1 - spk[d];
+            const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
+            const int in_use = ((pos0 ? K0 : 0) + (pos1 ? K1 : 0)) & 0xffff;
+            const bool any = (pos0 && K0 > 0xffff) || (pos1 && K1 > 0xffff);
+            const bool used = any && 3 * in_use > tp;
+            sum += ((used && pos0) ? T0 : 0.0) + ((used && pos1) ? T1 : 0.0);
+            pert = pert || (T0 - sx[d] != s0) || (T1 + sx[d] != s1);
+        }
+        const bool a = (lab >> ri) & 1ull;
+        const double base = a ? pair_at(c0 + 1) : pair_at(c0 > 0 ? c0 - 1 : 0);
+        const double dA = (base + sum) - lk;
+        float thr = 2.0f;
+        if (!pert && dA < -1e-3) thr = dA <= -44.5 ? -1.0f : __expf((float)dA) * 1.001f + 3e-7f;
+        return thr;
+    };
+    double max = lk;
+    unsigned long long argmax = lab;
+    float thr_tab = rebuild();
+    const uint32_t total = 2000u * n;
+    uint32_t t = 0, p = 0;
+    Window wd;
+    window_load(wd, rng, rng.pos, n, lane);
+    auto calc_rejm = [&]() -> uint32_t {
+        const float thr = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((wd.idx & 63u) << 2), __float_as_int(thr_tab)));
+        const float u = (float)(uint32_t)(wd.v >> 40) * 0x1p-24f;
+        return (wd.nxt & 63u) | ((wd.nxt != 255u && u > thr) ? 64u : 0u);
+    };
+    auto nxt_at = [&](uint32_t q) -> uint32_t { return uni((uint32_t)__builtin_amdgcn_readlane((int)wd.nxt, (int)q)); };
+    uint32_t hopw = calc_rejm();
+    while (t < total) {
+        if (total - t >= 24) {
+            uint32_t steps = 22;
+#pragma unroll
+            for (uint32_t k = 0; k < 22; k++) {
+                const uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
+                if (!(hv & 64u)) {
+                    steps = k;
+                    break;
+                }
+                p = hv & 63u;
+            }
+            t += steps;
+        } else {
+            while (t < total) {
+                const uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
+                if (!(hv & 64u)) break;
+                p = hv & 63u;
+                t++;
+            }
+            if (t >= total) break;
+        }
+        const uint32_t e_nxt = nxt_at(p);
+        if (e_nxt == 255u) {
+            window_load(wd, rng, wd.base + p, n, lane);
+            p = 0;
+            hopw = calc_rejm();
+            continue;
+        }
+        const uint32_t e_idx = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.idx, (int)p));
+        const bool old = (lab >> e_idx) & 1ull;
+        double x0 = 0.0;
+        int k0 = 0;
+        if (slane) {
+            const Elem el = m.elem[e_idx * D + lane];
+            x0 = old ? el.x : -el.x;
+            k0 = old ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
+        }
+        const double T0 = tg0 + x0, T1 = tg1 - x0;
+        const int K0 = pk0 + k0, K1 = pk1 - k0;
+        const uint32_t c0n = old ? c0 + 1 : c0 - 1;
+        const double proposed = exact_eval(T0, T1, K0, K1, pair_at(c0n));
+        const double diff = proposed - lk;
+        const bool no_draw = ubool(diff >= -0x1p-54);
+        bool accept = true;
+        if (!no_draw) {
+            const uint64_t e_v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wd.v >> 32), (int)p) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wd.v, (int)p);
+            accept = bernoulli_exact(uni64(e_v), diff);
+        }
+        bool changed = true;
+        if (accept) {
+            tg0 = T0;
+            tg1 = T1;
+            pk0 = K0;
+            pk1 = K1;
             c0 = c0n;
             lab ^= 1ull << e_idx;
             lk = proposed;
@@ -902,31 +1151,26 @@ __device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint3
                 max = proposed;
                 argmax = lab;
             }
+            if (lane == e_idx) {
+#pragma unroll
+                for (int d = 0; d < DMAX; d++) {
+                    sx[d] = -sx[d];
+                    spk[d] = -spk[d];
+                }
+            }
         } else {
-            const double back = leave ? T + el.x : T - el.x;  // flip back (:746), keeping the rounding residue
-            changed = __ballot(slane && back != tg) != 0ull;
-            tg = back;
+            const double b0 = T0 - x0, b1 = T1 + x0;
+            changed = __ballot(b0 != tg0 || b1 != tg1) != 0ull;
+            tg0 = b0;
+            tg1 = b1;
         }
         t++;
         p = no_draw ? e_nxt - 1 : e_nxt;
-#ifdef JTK_MCMC_STATS
-        const unsigned long long w2 = __builtin_readcyclecounter();
-        ST_CNT(3, w2 - w1);
-        ST_CNT(7, 1);
-        ST_CNT(8, accept ? 1 : 0);
-        ST_CNT(9, changed ? 1 : 0);
-#endif
         if (changed) {
-            publish();
             thr_tab = rebuild();
-            rejm = calc_rejm();
+            hopw = calc_rejm();
         }
-#ifdef JTK_MCMC_STATS
-        ST_CNT(4, __builtin_readcyclecounter() - w2);
-#endif
     }
-    ST_ADD(0);
-    ST_CNT(5, total);
     rng.pos = wd.base + p;
     rng_release(rng, lane);
     if (lane < n) m.assign[lane] = (uint8_t)((argmax >> lane) & 1ull);
@@ -936,7 +1180,10 @@ __device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint3
 
 template <int K>
 __device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
-    if (K == 2 && n <= 63 && D >= 1 && D <= 16) return mcmc_chain_k2t(m, n, D, cov, rng, lane);
+    if (K == 2 && n <= 63 && D == 1) return mcmc_chain_k2t<1>(m, n, D, cov, rng, lane);
+    if (K == 2 && n <= 63 && D == 2) return mcmc_chain_k2t<2>(m, n, D, cov, rng, lane);
+    if (K == 2 && n <= 63 && D >= 1 && D <= 4) return mcmc_chain_k2t<4>(m, n, D, cov, rng, lane);
+    if (K == 2 && n <= 63 && D >= 1 && D <= 8) return mcmc_chain_k2w<8>(m, n, D, cov, rng, lane);
     if (n <= 63) return mcmc_chain<K, true>(m, n, D, cov, rng, lane);
     return mcmc_chain<K, false>(m, n, D, cov, rng, lane);
 }
@@ -1102,11 +1349,6 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         };
         m.ctl = (RCtl *)take(sizeof(RCtl));
         m.ring = (uint64_t *)take(sizeof(uint64_t) * RN);
-        m.k2_pair = (double *)take(64 * 8);
-        m.k2_tg = (double *)take(32 * 8);
-        m.k2_np = (int *)take(32 * 4);
-        m.k2_w = (int *)take(32 * 4);
-        m.k2_totp2 = (int *)take(16 * 4);
         m.k2_stats = (unsigned long long *)take(16 * 8);
         m.elem = (Elem *)take((size_t)lds_n * lds_d * sizeof(Elem));
         m.data = (double *)take((size_t)lds_n * lds_d * 8);
@@ -1271,7 +1513,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
     size_t b = al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
-               al(64 * 8) + al(32 * 8) + 2 * al(32 * 4) + al(16 * 4) + al(16 * 8) +
+               al(16 * 8) +
                al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) + 2 * al((size_t)JTK_MAX_COPY * lds_d * 8) +
                2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d);
     return b;

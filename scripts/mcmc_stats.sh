@@ -4,6 +4,20 @@ set -u
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_STATS" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i error
 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/stats_raw.txt 2>&1
-grep K2STAT gpurun_out/stats_raw.txt | sort -k8 -n -r | head -12
-grep K2STAT gpurun_out/stats_raw.txt | awk '{c+=$8; w+=$10; wi+=$12; e+=$14; r+=$16; s+=$18; nw+=$20; ne+=$22; na+=$24; nc+=$26} END {print "TOTAL cyc",c,"walk",w,"win",wi,"event",e,"rebuild",r,"steps",s,"windows",nw,"events",ne,"accepts",na,"changed",nc}'
+python3 - <<'PY'
+import re, numpy as np
+rows=[]
+for line in open("gpurun_out/stats_raw.txt"):
+    for m in re.finditer(r"K2STAT chunk (\d+) n (\d+) D (\d+) cyc (\d+) walk \d+ win (\d+) event \d+ rebuild \d+ steps (\d+) windows (\d+) events (\d+) accepts (\d+) changed (\d+)", line):
+        rows.append([int(x) for x in m.groups()])
+a=np.array(rows,dtype=float)   # chunk n D cyc nullev steps windows events accepts changed
+print("chunks with stats:",len(a))
+for D in sorted(set(a[:,2])):
+    s=a[a[:,2]==D]
+    X=np.stack([np.ones(len(s)),s[:,7]],1); y=s[:,3]
+    coef,*_=np.linalg.lstsq(X,y,rcond=None)
+    print("D=%d n=%d: cycles ~ %.4g (%.1f/step) + %.0f/event; mean events %.0f null-row fraction %.3f max cyc %.3g"%(D,len(s),coef[0],coef[0]/s[:,5].mean(),coef[1],s[:,7].mean(),s[:,4].sum()/max(1,s[:,7].sum()),y.max()))
+i=np.argsort(-a[:,3])[:5]
+for r in a[i]: print("slow chunk %d D %d cyc %.4g events %d null %d windows %d"%(r[0],r[2],r[3],r[7],r[4],r[6]))
+PY
 python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i error
