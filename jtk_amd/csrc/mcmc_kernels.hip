@@ -54,15 +54,22 @@ __device__ __forceinline__ uint32_t ring_slot(uint32_t pos) {
 }
 struct RCtl {
     uint32_t rd, quit;  // written by the consumer (read together, 8-byte aligned)
-    uint32_t wr, pad;   // written by the producer
+    uint32_t wr, wp;    // written by the producer: draws produced / stream positions whose proposal record exists
+    uint32_t parse_n;   // written once by the consumer before the producer starts: n of the diploid chain, 0 = no records
+    uint32_t pad[3];
 };
 // The consumer's view of the generator: a position in the stream of Xoshiro256StarStar::seed_from_u64(id * 3490)
 // (local_clustering/mod.rs:97).  next_u64 == rand_xoshiro's next_u64, one stream position later.
 struct Rng {
     uint32_t pos;      // next draw to take (absolute stream position)
     uint32_t wr_seen;  // producer progress last observed
+    uint32_t wp_seen;  // record progress last observed
+#ifdef JTK_MCMC_STATS
+    uint32_t waits;    // polls of the producer's counters that found nothing new
+#endif
     RCtl *ctl;
     const uint64_t *ring;
+    const uint32_t *rec;  // proposal records, one per stream position (see producer_parse)
 };
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 __device__ __forceinline__ uint64_t splitmix64(uint64_t &x) {
@@ -76,6 +83,15 @@ __device__ __forceinline__ void rng_wait(Rng &r, uint32_t upto) {  // until draw
     while ((int32_t)(r.wr_seen - upto) < 0) {
         r.wr_seen = uni(lds_ld32(&r.ctl->wr));
         if ((int32_t)(r.wr_seen - upto) < 0) __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void rng_wait_rec(Rng &r, uint32_t upto) {  // until records [.., upto) exist
+    while ((int32_t)(r.wp_seen - upto) < 0) {
+        r.wp_seen = uni(lds_ld32(&r.ctl->wp));
+#ifdef JTK_MCMC_STATS
+        if ((int32_t)(r.wp_seen - upto) < 0) r.waits++;
+#endif
+        if ((int32_t)(r.wp_seen - upto) < 0) __builtin_amdgcn_s_sleep(1);
     }
 }
 __device__ __forceinline__ void rng_release(Rng &r, uint32_t lane) {  // draws before r.pos may be overwritten
@@ -143,6 +159,7 @@ struct Elem {  // one (read, column) cell as the chain needs it
 struct Lds {
     RCtl *ctl;
     uint64_t *ring;      // RN raw draws
+    uint32_t *rec;       // RN proposal records of the diploid chain
     unsigned long long *k2_stats;  // 16 debug counters (JTK_MCMC_STATS builds only)
     Elem *elem;          // n x D
     double *data;        // n x D
@@ -461,7 +478,31 @@ __device__ __forceinline__ void xo_jump(Xo &x) {
     x.s2 = a2;
     x.s3 = a3;
 }
-__device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint64_t seed, uint32_t lane) {
+// Proposal records.  For the diploid chain a proposal is: gen_range(0..n) takes the first draw at or after its start
+// whose widening multiply is accepted, gen_index(1) (the single candidate of K == 2, pseudo_mcmc.rs:732) then takes
+// draws until one has a clear top bit, and the next draw is the one a Bernoulli test would compare.  None of this
+// depends on the chain, so the producer parses the proposal that WOULD start at every stream position q:
+//   rec[q] = idx | len << 6 | (top 20 bits of the Bernoulli draw) << 12      (len = draws used incl. that draw)
+// rec == 0: not parsed (needs more than the 32..63 draws of look-ahead; the consumer then steps with scalar draws).
+// 64 positions are parsed at once -- acceptance masks by ballot, "next accepted draw at or after p" by s_ff1 -- and
+// the first 32 are kept, so every kept start had at least 32 draws of look-ahead.
+__device__ __forceinline__ void producer_parse(const uint64_t *ring, uint32_t *rec, uint32_t base, uint32_t n, uint32_t lane) {
+    const uint64_t draw = lds_ld64(&ring[ring_slot(base + lane)]);
+    const uint64_t zone = ((uint64_t)n << __clzll((long long)n)) - 1;
+    const uint32_t hi = (uint32_t)__umul64hi(draw, (uint64_t)n);
+    const unsigned long long okm = __ballot(draw * (uint64_t)n <= zone);  // gen_range(0..n) accepts this draw
+    const unsigned long long topm = __ballot((int64_t)draw >= 0);          // gen_index(1) accepts this draw
+    const unsigned long long m1 = okm >> lane;
+    const uint32_t pi = lane + (uint32_t)__builtin_ctzll(m1 | (1ull << 63));
+    const unsigned long long m2 = pi < 63 ? topm >> (pi + 1) : 0ull;
+    const uint32_t pv = pi + 1 + (uint32_t)__builtin_ctzll(m2 | (1ull << 63)) + 1;  // the Bernoulli draw
+    const bool ok = m1 != 0 && m2 != 0 && pv < 64;
+    const uint32_t idx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pi & 63) << 2), (int)hi);
+    const uint32_t vhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pv & 63) << 2), (int)(uint32_t)(draw >> 32));
+    const uint32_t r = ok ? (idx | ((pv + 1 - lane) << 6) | (vhi & 0xfffff000u)) : 0u;
+    if (lane < 32) lds_st32(&rec[(base + lane) & (RN - 1)], r);
+}
+__device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_t *rec, uint64_t seed, uint32_t lane) {
     uint64_t z = seed;
     Xo x;
     x.s0 = splitmix64(z);
@@ -469,7 +510,8 @@ __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint64_
     x.s2 = splitmix64(z);
     x.s3 = splitmix64(z);
     for (uint32_t j = 0; j < lane * SEG; j++) xo_step(x);  // lane l starts at stream position l * SEG
-    uint32_t wr = 0;
+    const uint32_t parse_n = uni(lds_ld32(&ctl->parse_n));
+    uint32_t wr = 0, wp = 0;
     for (;;) {
         const uint64_t c = uni64(lds_ld64((const uint64_t *)&ctl->rd));  // rd, quit
         if ((uint32_t)(c >> 32)) return;
@@ -487,6 +529,25 @@ __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint64_
         wr += SBLK;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_st32(&ctl->wr, wr);
+        if (parse_n) {
+            // a start at q needs draws up to q + 63: the last 32 positions wait for the next superblock
+            while ((int32_t)(wr - (wp + 64)) >= 0) {
+                if ((int32_t)(wr - (wp + 160)) >= 0) {  // four independent rounds: their instruction streams interleave
+                    producer_parse(ring, rec, wp, parse_n, lane);
+                    producer_parse(ring, rec, wp + 32, parse_n, lane);
+                    producer_parse(ring, rec, wp + 64, parse_n, lane);
+                    producer_parse(ring, rec, wp + 96, parse_n, lane);
+                    wp += 128;
+                } else {
+                    producer_parse(ring, rec, wp, parse_n, lane);
+                    wp += 32;
+                }
+                if ((wp & 255u) == 0 || (int32_t)(wr - (wp + 64)) < 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) lds_st32(&ctl->wp, wp);
+                }
+            }
+        }
         xo_jump(x);
     }
 }
@@ -689,37 +750,71 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
 // proposal that WOULD start at its draw and whether it is certainly rejected; the walk then follows nxt[] through
 // the window with one v_readlane per step.
 // Bit-identical to the one-step-at-a-time chain by construction; checked against the oracle.
-// The parser's view of 64 consecutive raw draws (lane l holds the draw at stream position base + l).  Every lane
-// also holds the proposal that WOULD start at its draw: gen_range(0..n) takes the first draw at or after it whose
-// widening multiply is accepted, gen_index(1) (the single candidate of K == 2, pseudo_mcmc.rs:732) then takes
-// draws until one has a clear top bit, and the next draw is the one a Bernoulli test would compare.
+// The consumer's view of 64 consecutive stream positions (lane l = position base + l): the producer's record of
+// the proposal that WOULD start there.
 struct Window {
     uint32_t base;
-    uint32_t nxt;   // per lane: window offset of the following proposal (Bernoulli draw taken), 255 = does not fit
-    uint32_t idx;   // per lane: the read index the proposal starting here picks
-    uint64_t v;     // per lane: the draw its Bernoulli test compares
+    uint32_t nxt;  // per lane: window offset of the following proposal (Bernoulli draw taken), 255 = not in this window
+    uint32_t idx;  // per lane: the read index the proposal starting here picks
+    float u;       // per lane: the draw its Bernoulli test compares, / 2^64, truncated to 20 bits
 };
-__device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t base, uint32_t n, uint32_t lane) {
+__device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t base, uint32_t lane) {
     rng.pos = base;
     rng_release(rng, lane);
-    rng_wait(rng, base + 64);
+    rng_wait_rec(rng, base + 64);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     wd.base = base;
-    const uint64_t draw = lds_ld64(&rng.ring[ring_slot(base + lane)]);
-    const uint64_t zone = ((uint64_t)n << __clzll((long long)n)) - 1;
-    const uint32_t hi = (uint32_t)__umul64hi(draw, (uint64_t)n);
-    const unsigned long long okm = __ballot(draw * (uint64_t)n <= zone);  // gen_range(0..n) accepts this draw
-    const unsigned long long topm = __ballot((int64_t)draw >= 0);          // gen_index(1) accepts this draw
-    const unsigned long long m1 = okm >> lane;
-    const uint32_t pi = lane + (uint32_t)__builtin_ctzll(m1 | (1ull << 63));
-    const unsigned long long m2 = pi < 63 ? topm >> (pi + 1) : 0ull;
-    const uint32_t pv = pi + 1 + (uint32_t)__builtin_ctzll(m2 | (1ull << 63)) + 1;
-    const bool fits = m1 != 0 && m2 != 0 && pv < 63;  // nxt = pv + 1 stays inside the window
-    wd.idx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pi & 63) << 2), (int)hi);
-    const uint32_t vlo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pv & 63) << 2), (int)(uint32_t)draw);
-    const uint32_t vhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pv & 63) << 2), (int)(uint32_t)(draw >> 32));
-    wd.v = ((uint64_t)vhi << 32) | vlo;
-    wd.nxt = fits ? pv + 1 : 255u;
+    const uint32_t r = lds_ld32(&rng.rec[(base + lane) & (RN - 1)]);
+    const uint32_t len = (r >> 6) & 63u;
+    wd.idx = r & 63u;
+    wd.nxt = (len != 0 && lane + len < 64) ? lane + len : 255u;
+    wd.u = (float)(r >> 12) * 0x1p-20f;
+}
+// per window position l: nxt[l] in bits 0..5 and, in bit 6, "the proposal starting at l lies inside the window and
+// is certainly rejected" -- one v_readlane per hop yields both.  thr_tab: lane i = rejection threshold of read i.
+__device__ __forceinline__ uint32_t hop_words(const Window &wd, float thr_tab) {
+    const float thr = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(wd.idx << 2), __float_as_int(thr_tab)));
+    return (wd.nxt & 63u) | ((wd.nxt != 255u && wd.u > thr) ? 64u : 0u);
+}
+// The rejection threshold from the order-free estimate dA of proposed - lk.  u is the Bernoulli draw truncated to
+// 20 bits (so the true uniform is < u + 2^-20); exp in f32 is good to ~1e-5 relative: 1.001 and 1.3e-6 cover both.
+__device__ __forceinline__ float reject_threshold(double dA, bool pert) {
+    float thr = 2.0f;  // cannot tell: the proposal becomes an event
+    if (!pert && dA < -1e-3) thr = dA <= -44.5 ? -1.0f : __expf((float)dA) * 1.001f + 1.3e-6f;
+    return thr;
+}
+// Walks from window position p over certainly rejected proposals; returns the number of steps taken (<= limit).
+// Straight-line hops with forward exits: a taken branch costs a lone wave far more than the hop itself.
+__device__ __forceinline__ uint32_t walk_rejected(uint32_t hopw, uint32_t &p, uint32_t limit) {
+    if (limit >= 24) {  // a window holds at most 21 proposals: no need to watch the step budget
+        uint32_t steps = 22;
+#pragma unroll
+        for (uint32_t k = 0; k < 22; k++) {
+            const uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
+            if (!(hv & 64u)) {
+                steps = k;
+                break;
+            }
+            p = hv & 63u;
+        }
+        return steps;
+    }
+    uint32_t steps = 0;
+    while (steps < limit) {
+        const uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
+        if (!(hv & 64u)) break;
+        p = hv & 63u;
+        steps++;
+    }
+    return steps;
+}
+// One proposal taken with scalar draws (a start the producer could not parse): the read index and the stream
+// position of the draw a Bernoulli test would compare.
+__device__ __forceinline__ void scalar_proposal(Rng &rng, uint32_t start, uint32_t n, uint32_t &idx, uint32_t &pos_v) {
+    rng.pos = start;
+    idx = (uint32_t)gen_range_usize(rng, n);
+    (void)gen_index(rng, 1);  // choose() over the single other cluster (pseudo_mcmc.rs:732)
+    pos_v = rng.pos;
 }
 
 #ifdef JTK_MCMC_STATS
@@ -732,9 +827,14 @@ __device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t base,
 #define ST_ADD(k)
 #define ST_CNT(k, v)
 #endif
-template <int DMAX>
-__device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng,
-                                                 uint32_t lane) {
+
+// REPL: the state is replicated in every lane (wave-uniform values in vector registers; neither the exact step nor
+// the table rebuild needs a cross-lane operation) -- used up to 4 columns.  Otherwise lane d holds column d and
+// the rebuild / the ordered sum fetch it with v_readlane (8 replicated columns do not fit the register budget).
+template <int DMAX, bool REPL>
+__device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng,
+                                                uint32_t lane) {
+    constexpr int NS = REPL ? DMAX : 1;  // state registers per lane
     // pair table: lane c0 holds (0.0 + size_to_lk[c0]) + size_to_lk[n - c0]   (get_lk :788)
     double pair_v;
     {
@@ -749,14 +849,12 @@ __device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint3
         const uint32_t c0 = lane <= n ? lane : n;
         pair_v = (0.0 + size_lk(c0)) + size_lk(n - c0);
     }
-    // ---- exact state, REPLICATED in every lane (wave-uniform values in vector registers, so neither the exact
-    //      step nor the table rebuild needs a cross-lane operation): LKCount[c][d] for d < DMAX; columns >= D are
-    //      all-zero, never used and add +0.0.  The two counters travel packed:
-    //      pk = num_pos + 65536 * (3*num_pos - 7*num_neg), so pk > 0xffff <=> the second one is positive.
-    double tg0[DMAX], tg1[DMAX];
-    int pk0[DMAX], pk1[DMAX], tp2[DMAX];
+    // ---- exact state LKCount[c][d]; columns >= D are all-zero, never used and add +0.0.  The two counters travel
+    //      packed: pk = num_pos + 65536 * (3*num_pos - 7*num_neg), so pk > 0xffff <=> the second one is positive.
+    double tg0[NS], tg1[NS];
+    int pk0[NS], pk1[NS], tp2[NS];
 #pragma unroll
-    for (int d = 0; d < DMAX; d++) {
+    for (int d = 0; d < NS; d++) {
         tg0[d] = tg1[d] = 0.0;
         pk0[d] = pk1[d] = tp2[d] = 0;
     }
@@ -765,9 +863,10 @@ __device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint3
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t c = uni(m.assign[i]);
 #pragma unroll
-        for (int d = 0; d < DMAX; d++) {
+        for (int d = 0; d < NS; d++) {
+            const uint32_t col = REPL ? (uint32_t)d : lane;
             Elem el = {0.0, 0, 0};
-            if ((uint32_t)d < D) el = m.elem[i * D + d];
+            if (col < D) el = m.elem[i * D + col];
             tp2[d] += 2 * el.dp;  // 2 x reads with a positive value in this column: constant along the chain
             if (c == 0) {
                 tg0[d] += el.x;
@@ -800,122 +899,117 @@ __device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint3
     auto pair_at = [&](uint32_t c) -> double { return readlane_f64(pair_v, c <= n ? c : n); };
     // get_lk (:785-795) of a tentative state, exactly: size terms, then clusters outer / columns inner, left to right
     auto exact_eval = [&](const double *T0, const double *T1, const int *K0, const int *K1, double base) -> double {
-        bool used[DMAX];
+        double t0[NS], t1[NS];
 #pragma unroll
-        for (int d = 0; d < DMAX; d++) {
+        for (int d = 0; d < NS; d++) {
             const bool pos0 = 0.0 < T0[d], pos1 = 0.0 < T1[d];
             const int in_use = ((pos0 ? K0[d] : 0) + (pos1 ? K1[d] : 0)) & 0xffff;
             const bool any = (pos0 && K0[d] > 0xffff) || (pos1 && K1[d] > 0xffff);
-            used[d] = any && 3 * in_use > tp2[d];  // get_used_columns (:847-869)
+            const bool used = any && 3 * in_use > tp2[d];  // get_used_columns (:847-869)
+            t0[d] = (used && pos0) ? T0[d] : 0.0;
+            t1[d] = (used && pos1) ? T1[d] : 0.0;
         }
         double S = base;
+        if (REPL) {
 #pragma unroll
-        for (int d = 0; d < DMAX; d++) S += (used[d] && 0.0 < T0[d]) ? T0[d] : 0.0;
+            for (int d = 0; d < DMAX; d++) S += t0[d];
 #pragma unroll
-        for (int d = 0; d < DMAX; d++) S += (used[d] && 0.0 < T1[d]) ? T1[d] : 0.0;
+            for (int d = 0; d < DMAX; d++) S += t1[d];
+        } else {
+#pragma unroll
+            for (int q = 0; q < DMAX; q++) S += readlane_f64(t0[0], q);
+#pragma unroll
+            for (int q = 0; q < DMAX; q++) S += readlane_f64(t1[0], q);
+        }
         return S;
     };
     double lk = exact_eval(tg0, tg1, pk0, pk1, pair_at(c0));
     double pair_up = pair_at(c0 + 1), pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
-    // the rejection threshold of "flip read `lane`" in the current state (order-free sum; see the header)
-    auto rebuild = [&]() -> float {
+    // ---- the table: for "flip read `lane`" in the current state, the order-free sum of its column terms and
+    //      whether flip + flip-back would leave a rounding residue; thresholds follow from those and the size terms
+    double sum_l = 0.0;
+    bool pert_l = false;
+    auto rebuild_sums = [&]() {
         double sum = 0.0;
         bool pert = false;
 #pragma unroll
         for (int d = 0; d < DMAX; d++) {
-            const double T0 = tg0[d] + sx[d], T1 = tg1[d] - sx[d];  // s - x == s + (-x) bit for bit
-            const int K0 = pk0[d] + spk[d], K1 = pk1[d] - spk[d];
+            const double s0 = REPL ? tg0[REPL ? d : 0] : readlane_f64(tg0[0], d);
+            const double s1 = REPL ? tg1[REPL ? d : 0] : readlane_f64(tg1[0], d);
+            const int k0 = REPL ? pk0[REPL ? d : 0] : __builtin_amdgcn_readlane(pk0[0], d);
+            const int k1 = REPL ? pk1[REPL ? d : 0] : __builtin_amdgcn_readlane(pk1[0], d);
+            const int tp = REPL ? tp2[REPL ? d : 0] : __builtin_amdgcn_readlane(tp2[0], d);
+            const double T0 = s0 + sx[d], T1 = s1 - sx[d];  // s - x == s + (-x) bit for bit
+            const int K0 = k0 + spk[d], K1 = k1 - spk[d];
             const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
             const int in_use = ((pos0 ? K0 : 0) + (pos1 ? K1 : 0)) & 0xffff;
             const bool any = (pos0 && K0 > 0xffff) || (pos1 && K1 > 0xffff);
-            const bool used = any && 3 * in_use > tp2[d];
+            const bool used = any && 3 * in_use > tp;
             sum += ((used && pos0) ? T0 : 0.0) + ((used && pos1) ? T1 : 0.0);
-            pert = pert || (T0 - sx[d] != tg0[d]) || (T1 + sx[d] != tg1[d]);  // flip back (:746) would not restore the sum
+            pert = pert || (T0 - sx[d] != s0) || (T1 + sx[d] != s1);  // flip back (:746) would not restore the sum
         }
+        sum_l = sum;
+        pert_l = pert;
+    };
+    auto thresholds = [&]() -> float {
         const bool a = (lab >> ri) & 1ull;
-        const double dA = ((a ? pair_up : pair_dn) + sum) - lk;
-        float thr = 2.0f;
-        if (!pert && dA < -1e-3) thr = dA <= -44.5 ? -1.0f : __expf((float)dA) * 1.001f + 3e-7f;
-        return thr;
+        return reject_threshold(((a ? pair_up : pair_dn) + sum_l) - lk, pert_l);
     };
     double max = lk;
     unsigned long long argmax = lab;
-    float thr_tab = rebuild();
+    rebuild_sums();
+    float thr_tab = thresholds();
     const uint32_t total = 2000u * n;
     uint32_t t = 0, p = 0;
     Window wd;
-    window_load(wd, rng, rng.pos, n, lane);
-    // per window position l: nxt[l] in bits 0..5 and, in bit 6, "the proposal starting at l fits in the window and
-    // is certainly rejected" -- one v_readlane per hop yields both
-    auto calc_rejm = [&]() -> uint32_t {
-        const float thr = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((wd.idx & 63u) << 2), __float_as_int(thr_tab)));
-        const float u = (float)(uint32_t)(wd.v >> 40) * 0x1p-24f;  // the Bernoulli draw / 2^64 within 2^-24
-        return (wd.nxt & 63u) | ((wd.nxt != 255u && u > thr) ? 64u : 0u);
-    };
-    auto nxt_at = [&](uint32_t q) -> uint32_t { return uni((uint32_t)__builtin_amdgcn_readlane((int)wd.nxt, (int)q)); };
-    uint32_t hopw = calc_rejm();
+    window_load(wd, rng, rng.pos, lane);
+    uint32_t hopw = hop_words(wd, thr_tab);
     ST_T0();
     while (t < total) {
-        // ---- walk over certainly rejected proposals (nxt < 64 wherever the rejm bit is set)
-        if (total - t >= 24) {  // a window holds at most 21 proposals: no need to watch the step budget
-            // straight-line hops with forward exits: a taken branch costs a lone wave far more than the hop itself
-            uint32_t steps = 22;
-#pragma unroll
-            for (uint32_t k = 0; k < 22; k++) {
-                const uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
-                if (!(hv & 64u)) {
-                    steps = k;
-                    break;
-                }
-                p = hv & 63u;
-            }
-            t += steps;
-        } else {
-            while (t < total) {
-                const uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
-                if (!(hv & 64u)) break;
-                p = hv & 63u;
-                t++;
-            }
-            if (t >= total) break;
-        }
-        const uint32_t e_nxt = nxt_at(p);
-        if (e_nxt == 255u) {  // the proposal at p does not fit: move the window there
-            window_load(wd, rng, wd.base + p, n, lane);
+        t += walk_rejected(hopw, p, total - t);
+        if (t >= total) break;
+        // ---- p is a proposal that is not certainly rejected, or one this window cannot serve
+        uint32_t e_idx, pos_v;  // the read it picks; stream position of the draw a Bernoulli test would compare
+        const uint32_t e_nxt = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.nxt, (int)p));
+        bool reload = false;
+        if (e_nxt != 255u) {
+            e_idx = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.idx, (int)p));
+            pos_v = wd.base + e_nxt - 1;
+        } else if (p != 0) {  // move the window there
+            window_load(wd, rng, wd.base + p, lane);
             p = 0;
-            hopw = calc_rejm();
+            hopw = hop_words(wd, thr_tab);
             ST_CNT(6, 1);
             continue;
+        } else {  // not even at the window start: the producer could not parse this one
+            scalar_proposal(rng, wd.base, n, e_idx, pos_v);
+            reload = true;
         }
         // ---- the event: one exact step
-        const uint32_t e_idx = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.idx, (int)p));
         const bool old = (lab >> e_idx) & 1ull;
-        double x0[DMAX], T0[DMAX], T1[DMAX];  // x0: what cluster 0 gains
-        int K0[DMAX], K1[DMAX];
+        double x0[NS], T0[NS], T1[NS];  // x0: what cluster 0 gains
+        int K0[NS], K1[NS];
+        bool nz = false;
 #pragma unroll
-        for (int d = 0; d < DMAX; d++) {
+        for (int d = 0; d < NS; d++) {
             int k0;
-            if (DMAX <= 2) {  // the read's own lane has its signed row in registers
+            if (REPL && DMAX <= 2) {  // the read's own lane has its signed row in registers
                 x0[d] = readlane_f64(sx[d], e_idx);
                 k0 = __builtin_amdgcn_readlane(spk[d], (int)e_idx);
             } else {
+                const uint32_t col = REPL ? (uint32_t)d : lane;
                 Elem el = {0.0, 0, 0};
-                if ((uint32_t)d < D) el = m.elem[e_idx * D + d];
+                if (col < D) el = m.elem[e_idx * D + col];
                 x0[d] = old ? el.x : -el.x;
                 k0 = old ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
             }
+            nz = nz || x0[d] != 0.0 || k0 != 0;
             T0[d] = tg0[d] + x0[d];
             T1[d] = tg1[d] - x0[d];
             K0[d] = pk0[d] + k0;
             K1[d] = pk1[d] - k0;
         }
-#ifdef JTK_MCMC_STATS
-        {
-            bool nz = false;
-            for (int d = 0; d < DMAX; d++) nz = nz || x0[d] != 0.0;
-            ST_CNT(2, nz ? 0 : 1);
-        }
-#endif
+        const bool null_row = !ubool(nz);  // the read is 0.0 in every column: only the cluster sizes move
         const double proposed = exact_eval(T0, T1, K0, K1, old ? pair_up : pair_dn);
         const double diff = proposed - lk;
         // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
@@ -923,14 +1017,13 @@ __device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint3
         const bool no_draw = ubool(diff >= -0x1p-54);
         bool accept = true;
         if (!no_draw) {
-            const uint64_t e_v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wd.v >> 32), (int)p) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wd.v, (int)p);
-            accept = bernoulli_exact(uni64(e_v), diff);
+            rng_wait(rng, pos_v + 1);
+            accept = bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff);
         }
-        bool changed = true;
+        int changed = 2;  // 0: nothing moved, 1: only sizes / lk moved, 2: sums moved
         if (accept) {
 #pragma unroll
-            for (int d = 0; d < DMAX; d++) {
+            for (int d = 0; d < NS; d++) {
                 tg0[d] = T0[d];
                 tg1[d] = T1[d];
                 pk0[d] = K0[d];
@@ -945,7 +1038,9 @@ __device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint3
                 max = proposed;
                 argmax = lab;
             }
-            if (lane == e_idx) {  // the read now flips the other way
+            if (null_row) {
+                changed = 1;
+            } else if (lane == e_idx) {  // the read now flips the other way
 #pragma unroll
                 for (int d = 0; d < DMAX; d++) {
                     sx[d] = -sx[d];
@@ -955,22 +1050,30 @@ __device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint3
         } else {
             bool ch = false;
 #pragma unroll
-            for (int d = 0; d < DMAX; d++) {
+            for (int d = 0; d < NS; d++) {
                 const double b0 = T0[d] - x0[d], b1 = T1[d] + x0[d];  // flip back (:746), keeping the rounding residue
                 ch = ch || b0 != tg0[d] || b1 != tg1[d];
                 tg0[d] = b0;
                 tg1[d] = b1;
             }
-            changed = ubool(ch);
+            changed = ubool(ch) ? 2 : 0;
         }
         t++;
-        p = no_draw ? e_nxt - 1 : e_nxt;
+        const uint32_t pos_next = no_draw ? pos_v : pos_v + 1;
         ST_CNT(7, 1);
         ST_CNT(8, accept ? 1 : 0);
-        ST_CNT(9, changed ? 1 : 0);
-        if (changed) {
-            thr_tab = rebuild();
-            hopw = calc_rejm();
+        ST_CNT(9, changed == 2 ? 1 : 0);
+        ST_CNT(2, null_row ? 1 : 0);
+        if (changed == 2) rebuild_sums();
+        if (changed) thr_tab = thresholds();
+        if (reload || pos_next - wd.base >= 64) {
+            window_load(wd, rng, pos_next, lane);
+            p = 0;
+            hopw = hop_words(wd, thr_tab);
+            ST_CNT(6, 1);
+        } else {
+            p = pos_next - wd.base;
+            if (changed) hopw = hop_words(wd, thr_tab);
         }
     }
     ST_CNT(5, total);
@@ -982,208 +1085,12 @@ __device__ __forceinline__ double mcmc_chain_k2t(const Lds &m, uint32_t n, uint3
     return max;
 }
 
-// The same chain for 5..8 columns: replicating 8 columns of state in every lane does not fit the register budget,
-// so here lane d holds column d of the state and the table rebuild / exact sum fetch it with v_readlane.
-template <int DMAX>
-__device__ __forceinline__ double mcmc_chain_k2w(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng,
-                                                 uint32_t lane) {
-    double pair_v;
-    {
-        auto size_lk = [&](uint32_t x) {
-            double mx = -__builtin_inf();
-            for (int c = 1; c <= 2; c++) {
-                const double lam = cov * (double)c;
-                mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
-            }
-            return mx;
-        };
-        const uint32_t c0 = lane <= n ? lane : n;
-        pair_v = (0.0 + size_lk(c0)) + size_lk(n - c0);
-    }
-    const bool slane = lane < D;
-    double tg0 = 0.0, tg1 = 0.0;
-    int pk0 = 0, pk1 = 0, np_all = 0;
-    uint32_t c0 = 0;
-    unsigned long long lab = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t c = uni(m.assign[i]);
-        Elem el = {0.0, 0, 0};
-        if (slane) el = m.elem[i * D + lane];
-        np_all += el.dp;
-        if (c == 0) {
-            tg0 += el.x;
-            pk0 += el.dp + 65536 * el.pw;
-            c0++;
-        } else {
-            tg1 += el.x;
-            pk1 += el.dp + 65536 * el.pw;
-            lab |= 1ull << i;
-        }
-    }
-    const int totp2 = 2 * np_all;
-    const uint32_t ri = lane < n ? lane : 0;
-    double sx[DMAX];
-    int spk[DMAX];
-    {
-        const bool a = (lab >> ri) & 1ull;
-#pragma unroll
-        for (int d = 0; d < DMAX; d++) {
-            Elem el = {0.0, 0, 0};
-            if ((uint32_t)d < D) el = m.elem[ri * D + d];
-            sx[d] = a ? el.x : -el.x;
-            spk[d] = a ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
-        }
-    }
-    wsync();
-    auto pair_at = [&](uint32_t c) -> double { return readlane_f64(pair_v, c <= n ? c : n); };
-    auto exact_eval = [&](double T0, double T1, int K0, int K1, double base) -> double {
-        const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
-        const int in_use = ((pos0 ? K0 : 0) + (pos1 ? K1 : 0)) & 0xffff;
-        const bool any = (pos0 && K0 > 0xffff) || (pos1 && K1 > 0xffff);
-        const bool used = any && 3 * in_use > totp2;
-        const double term0 = (used && pos0) ? T0 : 0.0, term1 = (used && pos1) ? T1 : 0.0;
-        double S = base;
-#pragma unroll
-        for (int q = 0; q < DMAX; q++) S += readlane_f64(term0, q);
-#pragma unroll
-        for (int q = 0; q < DMAX; q++) S += readlane_f64(term1, q);
-        return S;
-    };
-    double lk = exact_eval(tg0, tg1, pk0, pk1, pair_at(c0));
-    auto rebuild = [&]() -> float {
-        double sum = 0.0;
-        bool pert = false;
-#pragma unroll
-        for (int d = 0; d < DMAX; d++) {
-            const double s0 = readlane_f64(tg0, d), s1 = readlane_f64(tg1, d);
-            const int k0 = __builtin_amdgcn_readlane(pk0, d), k1 = __builtin_amdgcn_readlane(pk1, d);
-            const int tp = __builtin_amdgcn_readlane(totp2, d);
-            const double T0 = s0 + sx[d], T1 = s1 - sx[d];
-            const int K0 = k0 + spk[d], K1 = k1 - spk[d];
-            const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
-            const int in_use = ((pos0 ? K0 : 0) + (pos1 ? K1 : 0)) & 0xffff;
-            const bool any = (pos0 && K0 > 0xffff) || (pos1 && K1 > 0xffff);
-            const bool used = any && 3 * in_use > tp;
-            sum += ((used && pos0) ? T0 : 0.0) + ((used && pos1) ? T1 : 0.0);
-            pert = pert || (T0 - sx[d] != s0) || (T1 + sx[d] != s1);
-        }
-        const bool a = (lab >> ri) & 1ull;
-        const double base = a ? pair_at(c0 + 1) : pair_at(c0 > 0 ? c0 - 1 : 0);
-        const double dA = (base + sum) - lk;
-        float thr = 2.0f;
-        if (!pert && dA < -1e-3) thr = dA <= -44.5 ? -1.0f : __expf((float)dA) * 1.001f + 3e-7f;
-        return thr;
-    };
-    double max = lk;
-    unsigned long long argmax = lab;
-    float thr_tab = rebuild();
-    const uint32_t total = 2000u * n;
-    uint32_t t = 0, p = 0;
-    Window wd;
-    window_load(wd, rng, rng.pos, n, lane);
-    auto calc_rejm = [&]() -> uint32_t {
-        const float thr = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((wd.idx & 63u) << 2), __float_as_int(thr_tab)));
-        const float u = (float)(uint32_t)(wd.v >> 40) * 0x1p-24f;
-        return (wd.nxt & 63u) | ((wd.nxt != 255u && u > thr) ? 64u : 0u);
-    };
-    auto nxt_at = [&](uint32_t q) -> uint32_t { return uni((uint32_t)__builtin_amdgcn_readlane((int)wd.nxt, (int)q)); };
-    uint32_t hopw = calc_rejm();
-    while (t < total) {
-        if (total - t >= 24) {
-            uint32_t steps = 22;
-#pragma unroll
-            for (uint32_t k = 0; k < 22; k++) {
-                const uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
-                if (!(hv & 64u)) {
-                    steps = k;
-                    break;
-                }
-                p = hv & 63u;
-            }
-            t += steps;
-        } else {
-            while (t < total) {
-                const uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
-                if (!(hv & 64u)) break;
-                p = hv & 63u;
-                t++;
-            }
-            if (t >= total) break;
-        }
-        const uint32_t e_nxt = nxt_at(p);
-        if (e_nxt == 255u) {
-            window_load(wd, rng, wd.base + p, n, lane);
-            p = 0;
-            hopw = calc_rejm();
-            continue;
-        }
-        const uint32_t e_idx = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.idx, (int)p));
-        const bool old = (lab >> e_idx) & 1ull;
-        double x0 = 0.0;
-        int k0 = 0;
-        if (slane) {
-            const Elem el = m.elem[e_idx * D + lane];
-            x0 = old ? el.x : -el.x;
-            k0 = old ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
-        }
-        const double T0 = tg0 + x0, T1 = tg1 - x0;
-        const int K0 = pk0 + k0, K1 = pk1 - k0;
-        const uint32_t c0n = old ? c0 + 1 : c0 - 1;
-        const double proposed = exact_eval(T0, T1, K0, K1, pair_at(c0n));
-        const double diff = proposed - lk;
-        const bool no_draw = ubool(diff >= -0x1p-54);
-        bool accept = true;
-        if (!no_draw) {
-            const uint64_t e_v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wd.v >> 32), (int)p) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wd.v, (int)p);
-            accept = bernoulli_exact(uni64(e_v), diff);
-        }
-        bool changed = true;
-        if (accept) {
-            tg0 = T0;
-            tg1 = T1;
-            pk0 = K0;
-            pk1 = K1;
-            c0 = c0n;
-            lab ^= 1ull << e_idx;
-            lk = proposed;
-            if (ubool(max < lk)) {
-                max = proposed;
-                argmax = lab;
-            }
-            if (lane == e_idx) {
-#pragma unroll
-                for (int d = 0; d < DMAX; d++) {
-                    sx[d] = -sx[d];
-                    spk[d] = -spk[d];
-                }
-            }
-        } else {
-            const double b0 = T0 - x0, b1 = T1 + x0;
-            changed = __ballot(b0 != tg0 || b1 != tg1) != 0ull;
-            tg0 = b0;
-            tg1 = b1;
-        }
-        t++;
-        p = no_draw ? e_nxt - 1 : e_nxt;
-        if (changed) {
-            thr_tab = rebuild();
-            hopw = calc_rejm();
-        }
-    }
-    rng.pos = wd.base + p;
-    rng_release(rng, lane);
-    if (lane < n) m.assign[lane] = (uint8_t)((argmax >> lane) & 1ull);
-    wsync();
-    return max;
-}
-
 template <int K>
 __device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
-    if (K == 2 && n <= 63 && D == 1) return mcmc_chain_k2t<1>(m, n, D, cov, rng, lane);
-    if (K == 2 && n <= 63 && D == 2) return mcmc_chain_k2t<2>(m, n, D, cov, rng, lane);
-    if (K == 2 && n <= 63 && D >= 1 && D <= 4) return mcmc_chain_k2t<4>(m, n, D, cov, rng, lane);
-    if (K == 2 && n <= 63 && D >= 1 && D <= 8) return mcmc_chain_k2w<8>(m, n, D, cov, rng, lane);
+    if (K == 2 && n <= 63 && D == 1) return mcmc_chain_k2<1, true>(m, n, D, cov, rng, lane);
+    if (K == 2 && n <= 63 && D == 2) return mcmc_chain_k2<2, true>(m, n, D, cov, rng, lane);
+    if (K == 2 && n <= 63 && D >= 1 && D <= 4) return mcmc_chain_k2<4, true>(m, n, D, cov, rng, lane);
+    if (K == 2 && n <= 63 && D >= 1 && D <= 8) return mcmc_chain_k2<8, false>(m, n, D, cov, rng, lane);
     if (n <= 63) return mcmc_chain<K, true>(m, n, D, cov, rng, lane);
     return mcmc_chain<K, false>(m, n, D, cov, rng, lane);
 }
@@ -1349,6 +1256,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         };
         m.ctl = (RCtl *)take(sizeof(RCtl));
         m.ring = (uint64_t *)take(sizeof(uint64_t) * RN);
+        m.rec = (uint32_t *)take(sizeof(uint32_t) * RN);
         m.k2_stats = (unsigned long long *)take(16 * 8);
         m.elem = (Elem *)take((size_t)lds_n * lds_d * sizeof(Elem));
         m.data = (double *)take((size_t)lds_n * lds_d * 8);
@@ -1371,11 +1279,13 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         lds_st32(&m.ctl->rd, 0);
         lds_st32(&m.ctl->quit, 0);
         lds_st32(&m.ctl->wr, 0);
+        lds_st32(&m.ctl->wp, 0);
+        lds_st32(&m.ctl->parse_n, n <= 63 ? n : 0);  // the diploid chain (and its records) exists for n <= 63
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (wave == 1) {  // Xoshiro256StarStar::seed_from_u64(chunk.id * 3490)  (local_clustering/mod.rs:97)
-        producer_main(m.ctl, m.ring, uni64(cm.chunk_id) * 3490ULL, lane);
+        producer_main(m.ctl, m.ring, m.rec, uni64(cm.chunk_id) * 3490ULL, lane);
         return;
     }
     const double *feat = feat_all + cm.feat_off;
@@ -1407,8 +1317,13 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
     Rng rng;
     rng.pos = 0;
     rng.wr_seen = 0;
+    rng.wp_seen = 0;
+#ifdef JTK_MCMC_STATS
+    rng.waits = 0;
+#endif
     rng.ctl = m.ctl;
     rng.ring = m.ring;
+    rng.rec = m.rec;
     // ---- cluster_filtered_variants (:213-274)
     const double per_cluster_cov = unif64(cm.local_coverage);
     double max = 0.0;
@@ -1473,6 +1388,8 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
     if (lane == 0) lds_st32(&m.ctl->quit, 1);
 #ifdef JTK_MCMC_STATS
     if (lane == 0)
+        printf("K2WAIT chunk %u waits %u\n", ci, rng.waits);
+    if (lane == 0)
         printf("K2STAT chunk %u n %u D %u cyc %llu walk %llu win %llu event %llu rebuild %llu steps %llu windows %llu events %llu accepts %llu changed %llu\n",
                ci, n, D, m.k2_stats[0], m.k2_stats[1], m.k2_stats[2], m.k2_stats[3], m.k2_stats[4], m.k2_stats[5],
                m.k2_stats[6], m.k2_stats[7], m.k2_stats[8], m.k2_stats[9]);
@@ -1512,7 +1429,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
 
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    size_t b = al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
+    size_t b = al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
                al(16 * 8) +
                al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) + 2 * al((size_t)JTK_MAX_COPY * lds_d * 8) +
                2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d);

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "device_common.h"
@@ -89,7 +90,7 @@ struct jtk_lc_session {
     hipStream_t stream = nullptr;
     jtk_lc_params_t params;
     uint32_t n_chunks = 0, n_reads = 0, post_stride = 1;
-    uint32_t max_tmpl = 0, max_read = 0, max_n = 0, n_waves = 0;
+    uint32_t max_tmpl = 0, max_read = 0, max_n = 0, max_copy = 0, n_waves = 0;
     uint64_t scratch_stride = 0;
     bool features_only = false;
     std::vector<ChunkMeta> h_chunks;
@@ -269,6 +270,7 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
         }
         if (cap > s->max_tmpl) s->max_tmpl = cap;
         if (ch.n_reads > s->max_n) s->max_n = ch.n_reads;
+        if (ch.copy_num > s->max_copy) s->max_copy = ch.copy_num;
         rcount += ch.n_reads;
         tmpl_off += cap;
         total_off += (uint64_t)JTK_NUM_ROW * (cap + 1);
@@ -420,7 +422,10 @@ int jtk_lc_session_run(jtk_lc_session_t *s, int skip_polish) {
     tstart(s, JTK_K_MCMC);
     launch_mcmc(st, s->n_chunks, chunks, state, s->d_params.as<jtk_lc_params_t>(), s->d_feat.as<double>(),
                 s->d_vtype.as<uint32_t>(), nullptr, 0, s->d_label.as<uint32_t>(), s->d_post.as<double>(),
-                s->post_stride, s->d_lg.as<double>(), s->d_lg_off.as<uint64_t>(), s->max_n, JTK_MAX_DIM);
+                s->post_stride, s->d_lg.as<double>(), s->d_lg_off.as<uint64_t>(), s->max_n,
+                // a chunk picks at most ROUND * max(copy_num, 2) columns (pseudo_mcmc.rs:421,527,532): size the
+                // LDS work area for the batch, so that two chunks share a CU whenever they can
+                std::min<uint32_t>(JTK_MAX_DIM, 3u * std::max<uint32_t>(s->max_copy, 2u)));
     tstop(s);
     HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));

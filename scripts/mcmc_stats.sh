@@ -18,6 +18,9 @@ for D in sorted(set(a[:,2])):
     coef,*_=np.linalg.lstsq(X,y,rcond=None)
     print("D=%d n=%d: cycles ~ %.4g (%.1f/step) + %.0f/event; mean events %.0f null-row fraction %.3f max cyc %.3g"%(D,len(s),coef[0],coef[0]/s[:,5].mean(),coef[1],s[:,7].mean(),s[:,4].sum()/max(1,s[:,7].sum()),y.max()))
 i=np.argsort(-a[:,3])[:5]
+import collections
+w=[int(m.group(2)) for line in open('gpurun_out/stats_raw.txt') for m in re.finditer(r'K2WAIT chunk (\d+) waits (\d+)', line)]
+print('record-wait polls per chunk: mean %.0f max %d'%(np.mean(w) if w else 0, max(w) if w else 0))
 for r in a[i]: print("slow chunk %d D %d cyc %.4g events %d null %d windows %d"%(r[0],r[2],r[3],r[7],r[4],r[6]))
 PY
 python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i error
