@@ -160,6 +160,7 @@ struct Lds {
     RCtl *ctl;
     uint64_t *ring;      // RN raw draws
     uint32_t *rec;       // RN proposal records of the diploid chain
+    ulonglong2 *jump;    // the producer's jump table (JUMP_TAB_BYTES)
     unsigned long long *k2_stats;  // 16 debug counters (JTK_MCMC_STATS builds only)
     Elem *elem;          // n x D
     double *data;        // n x D
@@ -439,12 +440,13 @@ __device__ __forceinline__ uint32_t choose_pos(Rng &r, uint32_t k) {
 // generator on its own copy of the state with ordinary 64-bit vector arithmetic -- 64 draws per ~20 instructions
 // instead of one draw per ~11 scalar instructions.  After a superblock every lane stands at the start of the NEXT
 // lane's segment and has to skip the other 63 segments: multiplication of the 256-bit state by the constant matrix
-// M^(63*SEG), done as 64 nibble look-ups in a 32 KiB table (g_jump_tab, computed once on the host from the step
-// function itself) XOR-ed together.  The sequence of draws is exactly that of the sequential generator.
+// M^(63*SEG), done as 128 two-bit look-ups in a 16 KiB table (g_jump_tab, computed once on the host from the step
+// function itself, staged in LDS) XOR-ed together.  The sequence of draws is exactly that of the sequential generator.
 #define SEG 32              // draws per lane per superblock
 #define SBLK (64 * SEG)     // draws per superblock
 static_assert(RN == 2 * SBLK, "the ring holds two superblocks");
-__device__ ulonglong2 g_jump_tab[64 * 16 * 2];  // [nibble position][nibble value] -> 256-bit column sum of M^(63*SEG)
+__device__ ulonglong2 g_jump_tab[128 * 4 * 2];  // [2-bit digit position][digit] -> 256-bit column sum of M^(63*SEG)
+#define JUMP_TAB_BYTES (128 * 4 * 32)           // 16 KiB, copied into LDS by every workgroup
 
 struct Xo {
     uint64_t s0, s1, s2, s3;
@@ -458,21 +460,35 @@ __device__ __forceinline__ void xo_step(Xo &x) {
     x.s2 ^= t;
     x.s3 = rotl64(x.s3, 45);
 }
-__device__ __forceinline__ void xo_jump(Xo &x) {
+// The table sits in LDS (a look-up that goes to L2 costs a lone wave microseconds); the loop is compact on purpose:
+// fully unrolled it is kilobytes of straight-line code executed once per superblock, and this kernel is large.
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const u64x2 lds_cu2;
+__device__ __forceinline__ void xo_jump(Xo &x, const ulonglong2 *tab) {
     uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    const uint64_t w[4] = {x.s0, x.s1, x.s2, x.s3};
+#pragma unroll 1
+    for (int q = 0; q < 4; q++) {
+        const uint64_t wq = q == 0 ? x.s0 : (q == 1 ? x.s1 : (q == 2 ? x.s2 : x.s3));
+        lds_cu2 *row = (lds_cu2 *)&tab[(q * 32) * 4 * 2];
+#pragma unroll 1
+        for (int k = 0; k < 32; k += 8) {
+            u64x2 lo[8], hi[8];
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+            for (int u = 0; u < 8; u++) {
+                const uint32_t v = (uint32_t)(wq >> (2 * (k + u))) & 3u;
+                lds_cu2 *e = &row[((k + u) * 4 + v) * 2];
+                lo[u] = e[0];
+                hi[u] = e[1];
+            }
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t v = (uint32_t)(w[q] >> (4 * k)) & 15u;
-            const ulonglong2 *e = &g_jump_tab[((q * 16 + k) * 16 + v) * 2];
-            const ulonglong2 lo = e[0], hi = e[1];
-            a0 ^= lo.x;
-            a1 ^= lo.y;
-            a2 ^= hi.x;
-            a3 ^= hi.y;
+            for (int u = 0; u < 8; u++) {
+                a0 ^= lo[u].x;
+                a1 ^= lo[u].y;
+                a2 ^= hi[u].x;
+                a3 ^= hi[u].y;
+            }
         }
+    }
     x.s0 = a0;
     x.s1 = a1;
     x.s2 = a2;
@@ -483,26 +499,43 @@ __device__ __forceinline__ void xo_jump(Xo &x) {
 // draws until one has a clear top bit, and the next draw is the one a Bernoulli test would compare.  None of this
 // depends on the chain, so the producer parses the proposal that WOULD start at every stream position q:
 //   rec[q] = idx | len << 6 | (top 20 bits of the Bernoulli draw) << 12      (len = draws used incl. that draw)
-// rec == 0: not parsed (needs more than the 32..63 draws of look-ahead; the consumer then steps with scalar draws).
+// rec == 0: not parsed (needs more than the 16..63 draws of look-ahead; the consumer then steps with scalar draws).
 // 64 positions are parsed at once -- acceptance masks by ballot, "next accepted draw at or after p" by s_ff1 -- and
-// the first 32 are kept, so every kept start had at least 32 draws of look-ahead.
+// the first PKEEP are kept, so every kept start had at least 64 - PKEEP draws of look-ahead (a proposal needs more
+// with probability 2^-14).  R rounds are written stage by stage so that their instruction streams interleave:
+// a lone wave pays ~8 cycles for a dependent instruction and ~4 for an independent one.
+#define PKEEP 48
+template <int R>
 __device__ __forceinline__ void producer_parse(const uint64_t *ring, uint32_t *rec, uint32_t base, uint32_t n, uint32_t lane) {
-    const uint64_t draw = lds_ld64(&ring[ring_slot(base + lane)]);
     const uint64_t zone = ((uint64_t)n << __clzll((long long)n)) - 1;
-    const uint32_t hi = (uint32_t)__umul64hi(draw, (uint64_t)n);
-    const unsigned long long okm = __ballot(draw * (uint64_t)n <= zone);  // gen_range(0..n) accepts this draw
-    const unsigned long long topm = __ballot((int64_t)draw >= 0);          // gen_index(1) accepts this draw
-    const unsigned long long m1 = okm >> lane;
-    const uint32_t pi = lane + (uint32_t)__builtin_ctzll(m1 | (1ull << 63));
-    const unsigned long long m2 = pi < 63 ? topm >> (pi + 1) : 0ull;
-    const uint32_t pv = pi + 1 + (uint32_t)__builtin_ctzll(m2 | (1ull << 63)) + 1;  // the Bernoulli draw
-    const bool ok = m1 != 0 && m2 != 0 && pv < 64;
-    const uint32_t idx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pi & 63) << 2), (int)hi);
-    const uint32_t vhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pv & 63) << 2), (int)(uint32_t)(draw >> 32));
-    const uint32_t r = ok ? (idx | ((pv + 1 - lane) << 6) | (vhi & 0xfffff000u)) : 0u;
-    if (lane < 32) lds_st32(&rec[(base + lane) & (RN - 1)], r);
+    uint64_t draw[R];
+    uint32_t hi[R], pi[R], pv[R], idx[R], vhi[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) draw[r] = lds_ld64(&ring[ring_slot(base + r * PKEEP + lane)]);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        hi[r] = (uint32_t)__umul64hi(draw[r], (uint64_t)n);
+        const unsigned long long okm = __ballot(draw[r] * (uint64_t)n <= zone);  // gen_range(0..n) accepts this draw
+        const unsigned long long topm = __ballot((int64_t)draw[r] >= 0);          // gen_index(1) accepts this draw
+        const unsigned long long m1 = okm >> lane;
+        pi[r] = lane + (uint32_t)__builtin_ctzll(m1 | (1ull << 63));
+        const unsigned long long m2 = pi[r] < 63 ? topm >> (pi[r] + 1) : 0ull;
+        pv[r] = pi[r] + 1 + (uint32_t)__builtin_ctzll(m2 | (1ull << 63)) + 1;  // the Bernoulli draw
+        ok[r] = m1 != 0 && m2 != 0 && pv[r] < 64;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        idx[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pi[r] & 63) << 2), (int)hi[r]);
+        vhi[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pv[r] & 63) << 2), (int)(uint32_t)(draw[r] >> 32));
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t v = ok[r] ? (idx[r] | ((pv[r] + 1 - lane) << 6) | (vhi[r] & 0xfffff000u)) : 0u;
+        if (lane < PKEEP) lds_st32(&rec[(base + r * PKEEP + lane) & (RN - 1)], v);
+    }
 }
-__device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_t *rec, uint64_t seed, uint32_t lane) {
+__device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_t *rec, const ulonglong2 *jump, uint64_t seed, uint32_t lane) {
     uint64_t z = seed;
     Xo x;
     x.s0 = splitmix64(z);
@@ -512,13 +545,28 @@ __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_
     for (uint32_t j = 0; j < lane * SEG; j++) xo_step(x);  // lane l starts at stream position l * SEG
     const uint32_t parse_n = uni(lds_ld32(&ctl->parse_n));
     uint32_t wr = 0, wp = 0;
+#ifdef JTK_MCMC_STATS
+    uint32_t st_sleeps = 0;
+    unsigned long long st_gen = 0, st_parse = 0, st_jump = 0;
+#endif
     for (;;) {
         const uint64_t c = uni64(lds_ld64((const uint64_t *)&ctl->rd));  // rd, quit
-        if ((uint32_t)(c >> 32)) return;
+        if ((uint32_t)(c >> 32)) {
+#ifdef JTK_MCMC_STATS
+            if (lane == 0) printf("K2PROD wr %u sleeps %u cyc_gen %llu cyc_parse %llu cyc_jump %llu\n", wr, st_sleeps, st_gen, st_parse, st_jump);
+#endif
+            return;
+        }
         if ((int32_t)(wr + SBLK - (uint32_t)c) > RN) {
+#ifdef JTK_MCMC_STATS
+            st_sleeps++;
+#endif
             __builtin_amdgcn_s_sleep(2);
             continue;
         }
+#ifdef JTK_MCMC_STATS
+        const unsigned long long tp0 = __builtin_readcyclecounter();
+#endif
         uint64_t *blk = ring + (wr & (RN - 1));
 #pragma unroll 8
         for (uint32_t j = 0; j < SEG; j++) {
@@ -529,26 +577,32 @@ __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_
         wr += SBLK;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_st32(&ctl->wr, wr);
+#ifdef JTK_MCMC_STATS
+        const unsigned long long tp1 = __builtin_readcyclecounter();
+        st_gen += tp1 - tp0;
+#endif
         if (parse_n) {
-            // a start at q needs draws up to q + 63: the last 32 positions wait for the next superblock
+            // a start at q needs draws up to q + 63: the last positions wait for the next superblock
             while ((int32_t)(wr - (wp + 64)) >= 0) {
-                if ((int32_t)(wr - (wp + 160)) >= 0) {  // four independent rounds: their instruction streams interleave
-                    producer_parse(ring, rec, wp, parse_n, lane);
-                    producer_parse(ring, rec, wp + 32, parse_n, lane);
-                    producer_parse(ring, rec, wp + 64, parse_n, lane);
-                    producer_parse(ring, rec, wp + 96, parse_n, lane);
-                    wp += 128;
+                if ((int32_t)(wr - (wp + 3 * PKEEP + 64)) >= 0) {
+                    producer_parse<4>(ring, rec, wp, parse_n, lane);
+                    wp += 4 * PKEEP;
                 } else {
-                    producer_parse(ring, rec, wp, parse_n, lane);
-                    wp += 32;
+                    producer_parse<1>(ring, rec, wp, parse_n, lane);
+                    wp += PKEEP;
                 }
-                if ((wp & 255u) == 0 || (int32_t)(wr - (wp + 64)) < 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0) lds_st32(&ctl->wp, wp);
-                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) lds_st32(&ctl->wp, wp);
             }
         }
-        xo_jump(x);
+#ifdef JTK_MCMC_STATS
+        const unsigned long long tp2 = __builtin_readcyclecounter();
+        st_parse += tp2 - tp1;
+#endif
+        xo_jump(x, jump);
+#ifdef JTK_MCMC_STATS
+        st_jump += __builtin_readcyclecounter() - tp2;
+#endif
     }
 }
 
@@ -828,6 +882,13 @@ __device__ __forceinline__ void scalar_proposal(Rng &rng, uint32_t start, uint32
 #define ST_CNT(k, v)
 #endif
 
+// gen_bool's p_int for p = exp(diff) < 1 (rand 0.8.5 Bernoulli: (p * 2^64) as u64).  Kept out of line: two inlined
+// copies of exp in the table builder cost more registers than the whole chain.
+__device__ __attribute__((noinline)) uint64_t gen_bool_threshold(double diff) {
+    const double scaled = jtk_exp(diff) * 18446744073709551616.0;
+    return !(scaled > 0.0) ? 0ull : __double2ull_rz(scaled);
+}
+
 // REPL: the state is replicated in every lane (wave-uniform values in vector registers; neither the exact step nor
 // the table rebuild needs a cross-lane operation) -- used up to 4 columns.  Otherwise lane d holds column d and
 // the rebuild / the ordered sum fetch it with v_readlane (8 replicated columns do not fit the register budget).
@@ -895,11 +956,18 @@ __device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32
             spk[d] = a ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
         }
     }
+    // reads whose row is 0.0 in every column: flipping one moves nothing but the cluster sizes
+    unsigned long long nullm;
+    {
+        bool nzr = false;
+#pragma unroll
+        for (int d = 0; d < DMAX; d++) nzr = nzr || sx[d] != 0.0 || spk[d] != 0;
+        nullm = ~__ballot(nzr) & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+    }
     wsync();
     auto pair_at = [&](uint32_t c) -> double { return readlane_f64(pair_v, c <= n ? c : n); };
-    // get_lk (:785-795) of a tentative state, exactly: size terms, then clusters outer / columns inner, left to right
-    auto exact_eval = [&](const double *T0, const double *T1, const int *K0, const int *K1, double base) -> double {
-        double t0[NS], t1[NS];
+    // the per-column terms of get_lk (:785-795) for a (tentative) state
+    auto column_terms = [&](const double *T0, const double *T1, const int *K0, const int *K1, double *t0, double *t1) {
 #pragma unroll
         for (int d = 0; d < NS; d++) {
             const bool pos0 = 0.0 < T0[d], pos1 = 0.0 < T1[d];
@@ -909,6 +977,11 @@ __device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32
             t0[d] = (used && pos0) ? T0[d] : 0.0;
             t1[d] = (used && pos1) ? T1[d] : 0.0;
         }
+    };
+    // get_lk of a tentative state, exactly: size terms, then clusters outer / columns inner, left to right
+    auto exact_eval = [&](const double *T0, const double *T1, const int *K0, const int *K1, double base) -> double {
+        double t0[NS], t1[NS];
+        column_terms(T0, T1, K0, K1, t0, t1);
         double S = base;
         if (REPL) {
 #pragma unroll
@@ -955,6 +1028,37 @@ __device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32
         const bool a = (lab >> ri) & 1ull;
         return reject_threshold(((a ? pair_up : pair_dn) + sum_l) - lk, pert_l);
     };
+    // ---- size-only moves (a read with an all-zero row): with the column sums fixed, get_lk is a function of the
+    //      cluster-0 size alone.  Lane c holds G[c] = get_lk at size c (the same left-to-right sum), and for the
+    //      moves c -> c+1 / c -> c-1 the exact gen_bool threshold p_int = (exp(diff) * 2^64) as u64; ndm_*: moves
+    //      that draw nothing (diff >= -2^-54).  Built on demand, stale once a column sum moves.
+    double Gtab = 0.0;
+    uint64_t pint_up = 0, pint_dn = 0;
+    unsigned long long ndm_up = 0, ndm_dn = 0;
+    bool gtab_ok = false;
+    auto build_gtab = [&]() {
+        double t0[NS], t1[NS];
+        column_terms(tg0, tg1, pk0, pk1, t0, t1);
+        double G = pair_v;
+        if (REPL) {
+#pragma unroll
+            for (int d = 0; d < DMAX; d++) G += t0[d];
+#pragma unroll
+            for (int d = 0; d < DMAX; d++) G += t1[d];
+        } else {
+#pragma unroll
+            for (int q = 0; q < DMAX; q++) G += readlane_f64(t0[0], q);
+#pragma unroll
+            for (int q = 0; q < DMAX; q++) G += readlane_f64(t1[0], q);
+        }
+        Gtab = G;
+        const double du = __shfl_down(G, 1, 64) - G, dd = __shfl_up(G, 1, 64) - G;
+        pint_up = gen_bool_threshold(du);
+        pint_dn = gen_bool_threshold(dd);
+        ndm_up = __ballot(du >= -0x1p-54);
+        ndm_dn = __ballot(dd >= -0x1p-54);
+        gtab_ok = true;
+    };
     double max = lk;
     unsigned long long argmax = lab;
     rebuild_sums();
@@ -985,11 +1089,60 @@ __device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32
             scalar_proposal(rng, wd.base, n, e_idx, pos_v);
             reload = true;
         }
-        // ---- the event: one exact step
         const bool old = (lab >> e_idx) & 1ull;
+        if ((nullm >> e_idx) & 1ull) {
+            // ---- a size-only move: the decision and the new likelihood come from the size tables
+#ifdef JTK_MCMC_STATS
+            const unsigned long long n0c = __builtin_readcyclecounter();
+#endif
+            if (!gtab_ok) build_gtab();
+            const bool nd = ((old ? ndm_up : ndm_dn) >> c0) & 1ull;
+            bool acc = true;
+            if (!nd) {
+                rng_wait(rng, pos_v + 1);
+                const uint64_t v = uni64(lds_ld64(&rng.ring[ring_slot(pos_v)]));
+                const uint64_t pi = old ? pint_up : pint_dn;
+                const uint64_t pint = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pi >> 32), (int)c0) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pi, (int)c0);
+                acc = v < pint;
+            }
+            if (acc) {
+                c0 = old ? c0 + 1 : c0 - 1;
+                lab ^= 1ull << e_idx;
+                lk = readlane_f64(Gtab, c0);
+                pair_up = pair_at(c0 + 1);
+                pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
+                if (ubool(max < lk)) {
+                    max = lk;
+                    argmax = lab;
+                }
+                thr_tab = thresholds();
+            }
+            t++;
+            const uint32_t pos_next = nd ? pos_v : pos_v + 1;
+            ST_CNT(7, 1);
+            ST_CNT(8, acc ? 1 : 0);
+            ST_CNT(2, 1);
+            if (reload || pos_next - wd.base >= 64) {
+                window_load(wd, rng, pos_next, lane);
+                p = 0;
+                hopw = hop_words(wd, thr_tab);
+                ST_CNT(6, 1);
+            } else {
+                p = pos_next - wd.base;
+                if (acc) hopw = hop_words(wd, thr_tab);
+            }
+#ifdef JTK_MCMC_STATS
+            ST_CNT(3, __builtin_readcyclecounter() - n0c);
+#endif
+            continue;
+        }
+        // ---- the event: one exact step
+#ifdef JTK_MCMC_STATS
+        const unsigned long long g0c = __builtin_readcyclecounter();
+#endif
         double x0[NS], T0[NS], T1[NS];  // x0: what cluster 0 gains
         int K0[NS], K1[NS];
-        bool nz = false;
 #pragma unroll
         for (int d = 0; d < NS; d++) {
             int k0;
@@ -1003,13 +1156,11 @@ __device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32
                 x0[d] = old ? el.x : -el.x;
                 k0 = old ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
             }
-            nz = nz || x0[d] != 0.0 || k0 != 0;
             T0[d] = tg0[d] + x0[d];
             T1[d] = tg1[d] - x0[d];
             K0[d] = pk0[d] + k0;
             K1[d] = pk1[d] - k0;
         }
-        const bool null_row = !ubool(nz);  // the read is 0.0 in every column: only the cluster sizes move
         const double proposed = exact_eval(T0, T1, K0, K1, old ? pair_up : pair_dn);
         const double diff = proposed - lk;
         // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
@@ -1020,7 +1171,7 @@ __device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32
             rng_wait(rng, pos_v + 1);
             accept = bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff);
         }
-        int changed = 2;  // 0: nothing moved, 1: only sizes / lk moved, 2: sums moved
+        int changed = 2;  // 0: nothing moved, 2: sums moved
         if (accept) {
 #pragma unroll
             for (int d = 0; d < NS; d++) {
@@ -1038,9 +1189,7 @@ __device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32
                 max = proposed;
                 argmax = lab;
             }
-            if (null_row) {
-                changed = 1;
-            } else if (lane == e_idx) {  // the read now flips the other way
+            if (lane == e_idx) {  // the read now flips the other way
 #pragma unroll
                 for (int d = 0; d < DMAX; d++) {
                     sx[d] = -sx[d];
@@ -1063,9 +1212,11 @@ __device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32
         ST_CNT(7, 1);
         ST_CNT(8, accept ? 1 : 0);
         ST_CNT(9, changed == 2 ? 1 : 0);
-        ST_CNT(2, null_row ? 1 : 0);
-        if (changed == 2) rebuild_sums();
-        if (changed) thr_tab = thresholds();
+        if (changed) {
+            gtab_ok = false;
+            rebuild_sums();
+            thr_tab = thresholds();
+        }
         if (reload || pos_next - wd.base >= 64) {
             window_load(wd, rng, pos_next, lane);
             p = 0;
@@ -1075,6 +1226,9 @@ __device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32
             p = pos_next - wd.base;
             if (changed) hopw = hop_words(wd, thr_tab);
         }
+#ifdef JTK_MCMC_STATS
+        ST_CNT(4, __builtin_readcyclecounter() - g0c);
+#endif
     }
     ST_CNT(5, total);
     ST_ADD(0);
@@ -1257,6 +1411,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         m.ctl = (RCtl *)take(sizeof(RCtl));
         m.ring = (uint64_t *)take(sizeof(uint64_t) * RN);
         m.rec = (uint32_t *)take(sizeof(uint32_t) * RN);
+        m.jump = (ulonglong2 *)take(JUMP_TAB_BYTES);
         m.k2_stats = (unsigned long long *)take(16 * 8);
         m.elem = (Elem *)take((size_t)lds_n * lds_d * sizeof(Elem));
         m.data = (double *)take((size_t)lds_n * lds_d * 8);
@@ -1275,6 +1430,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         m.prev_used = (uint8_t *)take(lds_d);
         m.tmp_used = (uint8_t *)take(lds_d);
     }
+    for (uint32_t e = threadIdx.x; e < JUMP_TAB_BYTES / 16; e += blockDim.x) m.jump[e] = g_jump_tab[e];
     if (threadIdx.x == 0) {
         lds_st32(&m.ctl->rd, 0);
         lds_st32(&m.ctl->quit, 0);
@@ -1285,7 +1441,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (wave == 1) {  // Xoshiro256StarStar::seed_from_u64(chunk.id * 3490)  (local_clustering/mod.rs:97)
-        producer_main(m.ctl, m.ring, m.rec, uni64(cm.chunk_id) * 3490ULL, lane);
+        producer_main(m.ctl, m.ring, m.rec, m.jump, uni64(cm.chunk_id) * 3490ULL, lane);
         return;
     }
     const double *feat = feat_all + cm.feat_off;
@@ -1429,14 +1585,14 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
 
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    size_t b = al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
+    size_t b = al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) + al(JUMP_TAB_BYTES) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
                al(16 * 8) +
                al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) + 2 * al((size_t)JTK_MAX_COPY * lds_d * 8) +
                2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d);
     return b;
 }
 
-// ---- host: the nibble table of M^(63*SEG), from nothing but the generator's own step function
+// ---- host: the two-bit-digit table of M^(63*SEG), from nothing but the generator's own step function
 namespace {
 struct V256 {
     uint64_t w[4];
@@ -1483,13 +1639,13 @@ const std::vector<uint64_t> &jump_table_host() {
         m_mul(*m, *m, *tmp);
         *m = *tmp;
     }
-    tab.resize(64 * 16 * 4);
-    for (int k = 0; k < 64; k++)
-        for (int v = 0; v < 16; v++) {
+    tab.resize(128 * 4 * 4);
+    for (int k = 0; k < 128; k++)
+        for (int v = 0; v < 4; v++) {
             V256 x{{0, 0, 0, 0}};
-            x.w[k >> 4] = (uint64_t)v << (4 * (k & 15));
+            x.w[k >> 5] = (uint64_t)v << (2 * (k & 31));
             const V256 r = m_apply(*acc, x);
-            for (int q = 0; q < 4; q++) tab[((size_t)k * 16 + v) * 4 + q] = r.w[q];
+            for (int q = 0; q < 4; q++) tab[((size_t)k * 4 + v) * 4 + q] = r.w[q];
         }
     delete m;
     delete acc;
@@ -1509,7 +1665,7 @@ void launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, Chun
                  const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d) {
     if (n_chunks == 0) return;
     const size_t lds = mcmc_lds_bytes(lds_n, lds_d);
-    if (mcmc_upload_jump_table(s) != 0) return;  // 32 KiB, stream-ordered before the kernel; the launch then fails loudly
+    if (mcmc_upload_jump_table(s) != 0) return;  // 16 KiB, stream-ordered before the kernel; the launch then fails loudly
     mcmc_kernel<<<n_chunks, 128, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
                                           post_stride, lg, lg_off, lds_n, lds_d);
 }

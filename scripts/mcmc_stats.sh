@@ -10,7 +10,9 @@ rows=[]
 for line in open("gpurun_out/stats_raw.txt"):
     for m in re.finditer(r"K2STAT chunk (\d+) n (\d+) D (\d+) cyc (\d+) walk \d+ win (\d+) event \d+ rebuild \d+ steps (\d+) windows (\d+) events (\d+) accepts (\d+) changed (\d+)", line):
         rows.append([int(x) for x in m.groups()])
-a=np.array(rows,dtype=float)   # chunk n D cyc nullev steps windows events accepts changed
+a=np.array(rows,dtype=float)   # chunk n D cyc nullev cyc_null cyc_gen steps windows events accepts changed
+print('null-path cycles/event %.0f ; general-path cycles/event %.0f (each incl. ~100 of timer)'%(a[:,5].sum()/max(1,a[:,4].sum()), a[:,6].sum()/max(1,(a[:,9]-a[:,4]).sum())))
+a=np.delete(a,[5,6],axis=1)
 print("chunks with stats:",len(a))
 for D in sorted(set(a[:,2])):
     s=a[a[:,2]==D]
@@ -21,6 +23,10 @@ i=np.argsort(-a[:,3])[:5]
 import collections
 w=[int(m.group(2)) for line in open('gpurun_out/stats_raw.txt') for m in re.finditer(r'K2WAIT chunk (\d+) waits (\d+)', line)]
 print('record-wait polls per chunk: mean %.0f max %d'%(np.mean(w) if w else 0, max(w) if w else 0))
+pr=[[int(x) for x in m.groups()] for line in open('gpurun_out/stats_raw.txt') for m in re.finditer(r'K2PROD wr (\d+) sleeps (\d+) cyc_gen (\d+) cyc_parse (\d+) cyc_jump (\d+)', line)]
+if pr:
+    q=np.array(pr,dtype=float); sb=q[:,0]/2048
+    print('producer per superblock (2048 draws): gen %.0f parse %.0f jump %.0f cycles; sleeps/chunk %.0f; draws %.3g'%((q[:,2]/sb).mean(),(q[:,3]/sb).mean(),(q[:,4]/sb).mean(),q[:,1].mean(),q[:,0].mean()))
 for r in a[i]: print("slow chunk %d D %d cyc %.4g events %d null %d windows %d"%(r[0],r[2],r[3],r[7],r[4],r[6]))
 PY
 python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i error
