@@ -12,10 +12,10 @@
 //    cells, the 3 spare lanes always hold zeros, so "value of row i-1" is a plain wave rotate by one lane
 //    (v_mov_b32 dpp wave_ror:1 / wave_rol:1) and no per-step frame shift exists;
 //  * template codes, the read (as emission indices) and both emission tables sit in LDS;
-//  * the forward sweep streams (toM, toD) of every anti-diagonal to a per-wave scratch stripe in HBM as
-//    one coalesced 1 KiB store (16 B per lane); the backward sweep reads them back through a register
-//    prefetch queue into an 8-slot LDS ring, from which the 16 row-crossing products of a step are read
-//    with the lane offset folded into the LDS address;
+//  * the forward sweep streams, for every anti-diagonal s, the pair P_s = (toM of diagonal s-1, toD of diagonal s)
+//    to a per-wave scratch stripe in HBM as one coalesced 1 KiB store (16 B per lane); the backward sweep reads
+//    the pairs back through a register prefetch queue into an 8-slot LDS ring, from which the 16 row-crossing
+//    products of a step take their operands as 7 ds_read_b128 at immediate offsets from one base register;
 //  * each lane accumulates the 16 partial sums of ITS template row over time (no cross-lane reduction);
 //    a row that leaves the band is flushed as 8 x 16 B stores; logs are taken later by finalize_kernel
 //    with every lane busy;
@@ -109,24 +109,30 @@ __global__ void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const 
 
 // ------------------------------------------------------------------------------------------------------
 // The per-read forward/backward sweep.
+//
+// Written for instruction count (with 11 waves per CU the kernel is bound by VALU/SALU issue, not by latency):
+//  * a cell outside the band or outside the DP matrix holds exact zeros in every array, so neighbour terms need no
+//    predicates of their own -- the only per-lane predicate of a step is "this cell exists" (`active`), plus the
+//    one source row of the del-3 entry that the 3 spare lanes of the lane ring cannot disambiguate;
+//    accumulator entries that finalize never reads (e.g. the sub/copy entries of row 0) may hold anything finite;
+//  * the forward sweep stores, per anti-diagonal s, the pair P_s = (toM of diagonal s-1, toD of diagonal s) of the
+//    lane's row: every one of the 16 row-crossing products of the backward sweep reads its (toM, toD) operands from
+//    ONE such pair, so a step does 7 ds_read_b128 instead of 16 ds_read_b64;
+//  * template / read codes are staged pre-multiplied into byte offsets of the emission tables and padded on both
+//    sides, so the lookups need no clamping;
+//  * the backward sweep is unrolled by 8 diagonals: ring slots and prefetch registers are compile-time, and a group
+//    of 8 in which no source diagonal lies in another scaling block (6 of 8 groups) carries no scale factors.
 // ------------------------------------------------------------------------------------------------------
-#define PF 4  // prefetch queue depth of the backward sweep (register staged, compiler-managed vmcnt)
+#define PAD 64  // padding (bytes) in front of the staged code arrays; 64 more behind
+#ifndef JTK_PHMM_PF
+#define JTK_PHMM_PF 4  // pairs in flight from HBM per wave during the backward sweep (4 or 8)
+#endif
+#ifndef JTK_PHMM_WAVES
+#define JTK_PHMM_WAVES 2  // resident waves per SIMD the register budget is set for (3 spills inside the backward loop)
+#endif
+#define RW 72   // entries per ring slot: 64 lanes + 4 wrapped copies in front + 2 behind (rounded up)
 
-struct Lane {
-    int i, j;
-    bool active;
-};
-__device__ __forceinline__ Lane lane_cell(int lane, int c, int r, int t, int L, int n) {
-    Lane x;
-    const int lo = c - r;
-    const int off = (lane - lo) & 63;
-    x.i = lo + off;
-    x.j = t - x.i;
-    x.active = off <= 2 * r && x.i >= 0 && x.i <= L && x.j >= 0 && x.j <= n;
-    return x;
-}
-
-__global__ __launch_bounds__(64, 3) void phmm_kernel(uint32_t n_reads, const ReadMeta *reads,
+__global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_reads, const ReadMeta *reads,
                                                   const ChunkMeta *chunks, const ChunkState *state,
                                                   DevBufs bufs, const uint8_t *ey_all, const uint64_t *delta_all,
                                                   const HmmDev *hmm2, double *scratch_all,
@@ -134,15 +140,17 @@ __global__ __launch_bounds__(64, 3) void phmm_kernel(uint32_t n_reads, const Rea
                                                   int *rawG_all, double *lk_all, uint32_t lds_tmpl,
                                                   uint32_t lds_read, int only_active) {
     extern __shared__ __align__(16) unsigned char smem[];
-    // LDS carve: ring [8][64] double2 | eM[16] | eI[20] | expo[ (Tmax>>6)+2 ] int | tmpl codes | ey
+    // LDS carve: ring [8][RW] double2 | eM[16] | eI[20] | delta words | block exponents | template codes | read codes
+    // A ring slot holds the 64 lanes at entries 4..67 plus copies of lanes 60..63 in front and of lanes 0..1 behind,
+    // so "the pair of row i+k" (k = -4..+2) is entry lane+4+k: one base register and immediate offsets.
     double2 *ring = reinterpret_cast<double2 *>(smem);
-    double *s_eM = reinterpret_cast<double *>(smem + 8 * 64 * 16);
-    double *s_eI = s_eM + 16;
+    unsigned char *s_eM = smem + 8 * RW * 16;  // doubles, addressed by byte offset
+    unsigned char *s_eI = s_eM + 16 * 8;
     const uint32_t n_blk = ((lds_tmpl + lds_read) >> 6) + 4;
-    uint64_t *s_delta = reinterpret_cast<uint64_t *>(s_eI + 20);  // band deltas of this read, one bit per diagonal
+    uint64_t *s_delta = reinterpret_cast<uint64_t *>(s_eI + 20 * 8);  // band deltas of this read, one bit per diagonal
     int *s_EF = reinterpret_cast<int *>(s_delta + n_blk);
-    uint8_t *s_x = reinterpret_cast<uint8_t *>(s_EF + n_blk);
-    uint8_t *s_ey = s_x + ((lds_tmpl + 16) & ~15u);
+    uint8_t *s_xs = reinterpret_cast<uint8_t *>(s_EF + n_blk);  // s_xs[PAD + i - 1] = 32 * code(x[i-1]): row of eM in bytes
+    uint8_t *s_ey = s_xs + ((lds_tmpl + 2 * PAD + 15) & ~15u);    // s_ey[PAD + j] = 8 * ey[j]: entry of eI in bytes
     const int lane = threadIdx.x;
     double2 *scratch = reinterpret_cast<double2 *>(scratch_all + (uint64_t)blockIdx.x * scratch_stride);
 
@@ -160,62 +168,75 @@ __global__ __launch_bounds__(64, 3) void phmm_kernel(uint32_t n_reads, const Rea
         const HmmDev *h = hmm2 + (rm.strand ? 0 : 1);
         const uint64_t *delta = delta_all + rm.delta_off;
         __syncthreads();
-        // ---- stage the template codes, the read's emission indices and the emission tables in LDS
+        // ---- stage the codes (as byte offsets, zero padded), the emission tables and the band deltas in LDS
         {
             const uint8_t *gx = bufs.tmpl[st.buf] + cm.tmpl_off;
-            for (int p = lane; p < L; p += 64) s_x[p] = gx[p];
+            for (int p = lane; p < L + 2 * PAD; p += 64) {
+                const int q = p - PAD;
+                s_xs[p] = (q >= 0 && q < L) ? (uint8_t)(gx[q] << 5) : (uint8_t)0;
+            }
             const uint8_t *gy = ey_all + rm.ey_off;
-            for (int p = lane; p <= n; p += 64) s_ey[p] = gy[p];
-            if (lane < 16) s_eM[lane] = h->eM[lane];
-            if (lane < 20) s_eI[lane] = h->eI[lane];
+            for (int p = lane; p < n + 1 + 2 * PAD; p += 64) {
+                const int q = p - PAD;
+                s_ey[p] = (q >= 1 && q <= n) ? (uint8_t)(gy[q] << 3) : (uint8_t)0;
+            }
+            if (lane < 16) reinterpret_cast<double *>(s_eM)[lane] = h->eM[lane];
+            if (lane < 20) reinterpret_cast<double *>(s_eI)[lane] = h->eI[lane];
             for (int wdx = lane; wdx < (T >> 6) + 2; wdx += 64) s_delta[wdx] = delta[wdx];
         }
         __syncthreads();
         const double aMM = h->a[0], aMI = h->a[1], aMD = h->a[2], aIM = h->a[3], aII = h->a[4], aID = h->a[5],
                      aDM = h->a[6], aDI = h->a[7], aDD = h->a[8];
+        const uint8_t *xs0 = s_xs + PAD - 1;  // xs0[i] = row offset of x[i-1]
+        const uint8_t *ey0 = s_ey + PAD;      // ey0[j] = entry offset of read base j
 
         // =========================== forward ===========================
         int c = 0, EF = 0;
         double toM_1 = 0, toM_2 = 0, toI_1 = 0, toD_1 = 0;  // combos of diagonals t-1 / t-2, lane frame
         double endM = 0, endI = 0, endD = 0;
-        for (int t = 0; t <= T; t++) {
-            if (t > 0) c += delta_bit(s_delta, t);
-            const Lane x = lane_cell(lane, c, r, t, L, n);
-            double fm = 0, fi = 0, fd = 0;
-            if (t == 0) {
-                fm = (x.active && x.i == 0) ? 1.0 : 0.0;
-            } else {
-                const double pM = rot_from_prev(toM_2), pD = rot_from_prev(toD_1), pI = toI_1;
-                const int jj = x.j < 1 ? 1 : (x.j > n ? n : x.j);
-                const int ii = x.i < 1 ? 1 : (x.i > L ? L : x.i);
-                const int eyv = s_ey[jj];
-                const int xc = s_x[ii - 1];
-                const double eMv = s_eM[4 * xc + (eyv & 3)], eIv = s_eI[eyv];
-                if (x.active && x.j >= 1) {
-                    fi = eIv * pI;
-                    if (x.i >= 1) fm = eMv * pM;
-                }
-                if (x.active && x.i >= 1) fd = pD;
-            }
-            if (t > 0 && (t & (JTK_SCALE_BLOCK - 1)) == 0) {
-                double m = fm > fi ? fm : fi;
-                m = fd > m ? fd : m;
-                m = wave_max(m);
-                if (m > 0.0) {
-                    const int e = jtk_ilogb_pos(m);
-                    const double s = pow2i(-e);
-                    fm *= s;
-                    fi *= s;
-                    fd *= s;
-                    toM_1 *= s;
+        {  // t == 0: the only cell is (0, 0), on lane 0
+            const double fm = lane == 0 ? 1.0 : 0.0;
+            toM_1 = fm * aMM;
+            toI_1 = fm * aMI;
+            toD_1 = fm * aMD;
+            scratch[lane] = make_double2(0.0, toD_1);
+            if (lane == 0) s_EF[0] = 0;
+            if (T == 0) endM = fm;
+        }
+        uint64_t dw = 0;
+        for (int t = 1; t <= T; t++) {
+            if ((t & 63) == 0 || t == 1) dw = s_delta[t >> 6];
+            c += (int)(__builtin_amdgcn_readfirstlane((uint32_t)(dw >> (t & 32))) >> (t & 31)) & 1;
+            const int lo = c - r, off = (lane - lo) & 63, i = lo + off, j = t - i;
+            const bool active = off <= 2 * r && (unsigned)i <= (unsigned)L && (unsigned)j <= (unsigned)n;
+            const double pM = rot_from_prev(toM_2), pD = rot_from_prev(toD_1);
+            const int ey8 = ey0[j], xs = xs0[i];
+            const double eMv = *reinterpret_cast<const double *>(s_eM + xs + (ey8 & 24));
+            const double eIv = *reinterpret_cast<const double *>(s_eI + ey8);
+            double fm = eMv * pM, fi = eIv * toI_1, fd = pD;
+            if (!active) fm = fi = fd = 0.0;
+            const double toM_prev = toM_1;  // toM of diagonal t-1 in its own block's scale: what the pair stores
+            if ((t & (JTK_SCALE_BLOCK - 1)) == 0) {
+                double mx = fm > fi ? fm : fi;
+                mx = fd > mx ? fd : mx;
+                mx = wave_max(mx);
+                if (mx > 0.0) {
+                    const int e = jtk_ilogb_pos(mx);
+                    const double sc = pow2i(-e);
+                    fm *= sc;
+                    fi *= sc;
+                    fd *= sc;
+                    toM_1 *= sc;
                     EF += e;
                 }
+                if (lane == 0) s_EF[t >> 6] = EF;
             }
-            if ((t & (JTK_SCALE_BLOCK - 1)) == 0 && lane == 0) s_EF[t >> 6] = EF;
             const double toM = fma(fd, aDM, fma(fi, aIM, fm * aMM));
             const double toI = fma(fd, aDI, fma(fi, aII, fm * aMI));
             const double toD = fma(fd, aDD, fma(fi, aID, fm * aMD));
-            scratch[(uint64_t)t * 64 + lane] = make_double2(toM, toD);
+#ifndef JTK_PHMM_EXPERIMENT_NOSTORE
+            scratch[(uint64_t)t * 64 + lane] = make_double2(toM_prev, toD);
+#endif
             toM_2 = toM_1;
             toM_1 = toM;
             toI_1 = toI;
@@ -226,6 +247,7 @@ __global__ __launch_bounds__(64, 3) void phmm_kernel(uint32_t n_reads, const Rea
                 endD = fd;
             }
         }
+        scratch[(uint64_t)(T + 1) * 64 + lane] = make_double2(toM_1, 0.0);  // P_{T+1} = (toM of diagonal T, nothing)
         // cell (L, n) sits on the lane that owns row L
         const int lane_end = L & 63;
         double tot = (endM + endI) + endD;
@@ -242,195 +264,180 @@ __global__ __launch_bounds__(64, 3) void phmm_kernel(uint32_t n_reads, const Rea
         for (int k = 0; k < JTK_ACC_N; k++) acc[k] = 0.0;
         double hM_1 = 0, hM_2 = 0, hI_1 = 0, bD_1 = 0;  // hatM(t+1), hatM(t+2), hatI(t+1), b_D(t+1)
         int EB = 0, Gprev = 0;
-        // c currently == c[T]; centres of the del-3 source diagonals t-5 / t-4 are tracked separately
-        int c5 = c, c4 = c;  // will be set below
+        // c == c[T]; centres of the del-3 source diagonals t-5 / t-4 are tracked separately
+        int c5 = c, c4 = c;
         {
-            int cc = c;
-            // c[T-4], c[T-5] by walking back
-            int tt = T;
-            for (int s = 0; s < 4 && tt >= 1; s++, tt--) cc -= delta_bit(s_delta, tt);
+            int cc = c, tt = T;
+            for (int k = 0; k < 4 && tt >= 1; k++, tt--) cc -= delta_bit(s_delta, tt);
             c4 = cc;
             if (tt >= 1) cc -= delta_bit(s_delta, tt);
             c5 = cc;
         }
-        // ring preload: diagonals T+2 .. T-5 (those > T are zero)
-        for (int tt = T + 2; tt >= T - 5; tt--) {
-            double2 v = make_double2(0.0, 0.0);
-            if (tt >= 0 && tt <= T) v = scratch[(uint64_t)tt * 64 + lane];
-            ring[(tt & 7) * 64 + lane] = v;
-        }
-        // prefetch queue: pf[u] holds diagonal (t - 5 - 1) for the step that will consume it
-        double2 pf[PF];
+        auto load_pair = [&](int ss) -> double2 {
+#ifdef JTK_PHMM_EXPERIMENT_NOLOAD
+            return make_double2(1e-3 * ss, 0.5);
+#else
+            return ss >= 0 ? scratch[(uint64_t)ss * 64 + lane] : make_double2(0.0, 0.0);
+#endif
+        };
+        // ring: P_{T+2} (nothing) .. P_{T-4}; queue: pq[s & (PF-1)] = P_s for the next PF below
+        auto ring_put = [&](int slot, double2 v) __attribute__((always_inline)) {
+            double2 *e = ring + slot * RW + lane + 4;
+            e[0] = v;
+            if (lane < 2) e[64] = v;
+            if (lane >= 60) e[-64] = v;
+        };
+        ring_put((T + 2) & 7, make_double2(0.0, 0.0));
+        for (int ss = T + 1; ss >= T - 4; ss--) ring_put(ss & 7, load_pair(ss));
+        double2 pq[JTK_PHMM_PF];
 #pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int tt = T - 6 - u;
-            pf[u] = tt >= 0 ? scratch[(uint64_t)tt * 64 + lane] : make_double2(0.0, 0.0);
-        }
-        __syncthreads();
+        for (int q = 0; q < JTK_PHMM_PF; q++) pq[q] = load_pair((T - 5) - (((T - 5) - q) & (JTK_PHMM_PF - 1)));
         int delta_next = 0;  // c[t+1] - c[t]
-        for (int tbase = T; tbase >= 0; tbase -= PF) {
+        const double2 *ring_me = ring + lane + 4;  // source row i+k: entry ring_me[k] of its slot
+
+        // one backward step; SLOT(x) = ring slot of pair P_x; ST: some source diagonal lies in another scaling block
+        auto step = [&](int t, auto slot_of, auto straddle_tag, auto pq_tag) __attribute__((always_inline)) {
+            constexpr int pq_idx = decltype(pq_tag)::value;
+            constexpr bool ST = decltype(straddle_tag)::value;
+            if (t < T) c -= delta_next;  // centres: c == c[t+1] on entry
+            const int lo = c - r, off = (lane - lo) & 63, i = lo + off, j = t - i;
+            const bool active = off <= 2 * r && (unsigned)i <= (unsigned)L && (unsigned)j <= (unsigned)n;
+            // (0) a row that left the band at this step is final (exponent of the previous step)
+            if (t < T && delta_next == 1) {
+                if (off == 2 * r + 1 && (unsigned)i <= (unsigned)L) {
+                    double2 *dst = reinterpret_cast<double2 *>(raw + (uint64_t)i * JTK_ACC_N);
 #pragma unroll
-            for (int u = 0; u < PF; u++) {
-                const int t = tbase - u;
-                if (t < 0) break;
-                // centres: c == c[t+1] on entry (or c[T] when t == T)
-                if (t < T) c -= delta_next;
-                const Lane x = lane_cell(lane, c, r, t, L, n);
-                // (0) a row that left the band at this step is final (exponent of the previous step)
-                {
-                    const int lo = c - r;
-                    const int off = (lane - lo) & 63;
-                    const bool flush = t < T && delta_next == 1 && off == 2 * r + 1 && x.i >= 0 && x.i <= L;
-                    if (flush) {
-                        double2 *dst = reinterpret_cast<double2 *>(raw + (uint64_t)x.i * JTK_ACC_N);
+                    for (int k = 0; k < JTK_ACC_N / 2; k++) dst[k] = make_double2(acc[2 * k], acc[2 * k + 1]);
+                    rawG[i] = Gprev;
 #pragma unroll
-                        for (int k = 0; k < JTK_ACC_N / 2; k++) dst[k] = make_double2(acc[2 * k], acc[2 * k + 1]);
-                        rawG[x.i] = Gprev;
-#pragma unroll
-                        for (int k = 0; k < JTK_ACC_N; k++) acc[k] = 0.0;
-                    }
+                    for (int k = 0; k < JTK_ACC_N; k++) acc[k] = 0.0;
                 }
-                // (1) backward values of this diagonal
-                double vm = 0, vi = 0, vd = 0;
-                if (t == T) {
-                    vm = vi = vd = x.active ? 1.0 : 0.0;
-                } else {
-                    const double xm = rot_from_next(hM_2), xd = rot_from_next(bD_1), xi = hI_1;
-                    if (x.active) {
-                        vm = fma(aMD, xd, fma(aMI, xi, aMM * xm));
-                        vi = fma(aID, xd, fma(aII, xi, aIM * xm));
-                        vd = fma(aDD, xd, fma(aDI, xi, aDM * xm));
-                    }
-                }
-                if (t < T && (t & (JTK_SCALE_BLOCK - 1)) == JTK_SCALE_BLOCK - 1) {
-                    double m = vm > vi ? vm : vi;
-                    m = vd > m ? vd : m;
-                    m = wave_max(m);
-                    if (m > 0.0) {
-                        const int e = jtk_ilogb_pos(m);
-                        const double s = pow2i(-e);
-                        vm *= s;
-                        vi *= s;
-                        vd *= s;
-                        hM_1 *= s;
-                        EB += e;
-                    }
-                }
-                const int jj = x.j < 1 ? 1 : (x.j > n ? n : x.j);
-                const int ii = x.i < 1 ? 1 : (x.i > L ? L : x.i);
-                const int eyv = s_ey[jj];
-                const int xc = s_x[ii - 1];
-                const int y1 = eyv & 3;
-                double hM = 0, hI = 0;
-                if (x.active && x.j >= 1) {
-                    hI = s_eI[eyv] * vi;
-                    if (x.i >= 1) hM = s_eM[4 * xc + y1] * vm;
-                }
-                // (2) common exponent of this step
-                const int EFt = s_EF[t >> 6];
-                const int G = EFt + EB;
-                if (t < T && G != Gprev) {
-                    const double s = pow2i(Gprev - G);
-#pragma unroll
-                    for (int k = 0; k < JTK_ACC_N; k++) acc[k] *= s;
-                }
-                Gprev = G;
-                // (3) the 16 row-crossing products of this cell; F values come from the LDS ring with the
-                //     lane offset of the source row folded into the address.  A source diagonal in another
-                //     64-diagonal block carries another exponent and is re-expressed by an exact power of two; the
-                //     window t-5 .. t+2 lies inside one block for 57 of 64 steps, and then every factor is 1.
-                const bool straddle = ((t - 5) >> 6) != ((t + 2) >> 6);
-                auto products = [&](auto straddle_tag) {
-                    constexpr bool ST = decltype(straddle_tag)::value;
-                    auto FS = [&](int tt) -> double {  // 2^(EF[tt]-EF[t])
-                        if (!ST) return 1.0;
-                        if (tt < 0 || tt > T) return 1.0;
-                        return fast_pow2(s_EF[tt >> 6] - EFt);
-                    };
-                    const bool jm = x.active && x.j >= 1;  // M terms consume read base y[j-1]
-                    const bool i1 = x.active && x.i >= 1;
-                    // sub (entry i-1): toM(i-1, j-1) on t-2, toD(i-1, j) on t-1
-                    {
-                        const double2 a = ring[((t - 2) & 7) * 64 + ((lane - 1) & 63)];
-                        const double2 b = ring[((t - 1) & 7) * 64 + ((lane - 1) & 63)];
-                        const double fmv = (i1 && jm && t >= 2) ? (ST ? a.x * FS(t - 2) : a.x) : 0.0;
-                        const double fdv = (i1 && t >= 1) ? (ST ? b.y * FS(t - 1) : b.y) : 0.0;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) acc[q] = fma(y1 == q ? fmv : 0.0, vm, acc[q]);
-                        acc[4] = fma(fdv, vd, acc[4]);
-                    }
-                    // ins (entry i): toM(i, j-1) on t-1, toD(i, j) on t
-                    {
-                        const double2 a = ring[((t - 1) & 7) * 64 + lane];
-                        const double2 b = ring[(t & 7) * 64 + lane];
-                        const double fmv = (jm && t >= 1) ? (ST ? a.x * FS(t - 1) : a.x) : 0.0;
-                        const double fdv = x.active ? b.y : 0.0;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) acc[5 + q] = fma(y1 == q ? fmv : 0.0, vm, acc[5 + q]);
-                        acc[9] = fma(fdv, vd, acc[9]);
-                    }
-                    // copy c (entry i-1): toM(i-1+c, j-1) on t+c-2, toD(i-1+c, j) on t+c-1
-#pragma unroll
-                    for (int cc = 1; cc <= 3; cc++) {
-                        const double2 a = ring[((t + cc - 2) & 7) * 64 + ((lane - 1 + cc) & 63)];
-                        const double2 b = ring[((t + cc - 1) & 7) * 64 + ((lane - 1 + cc) & 63)];
-                        const double fmv = (i1 && jm && t + cc - 2 >= 0 && t + cc - 2 <= T) ? (ST ? a.x * FS(t + cc - 2) : a.x) : 0.0;
-                        const double fdv = (i1 && t + cc - 1 <= T) ? (ST ? b.y * FS(t + cc - 1) : b.y) : 0.0;
-                        double v = acc[10 + cc - 1];
-                        v = fma(fmv, hM, v);
-                        v = fma(fdv, vd, v);
-                        acc[10 + cc - 1] = v;
-                    }
-                    // del d (entry i-d-1): toM(i-d-1, j-1) on t-d-2, toD(i-d-1, j) on t-d-1
-#pragma unroll
-                    for (int dd = 1; dd <= 3; dd++) {
-                        const double2 a = ring[((t - dd - 2) & 7) * 64 + ((lane - dd - 1) & 63)];
-                        const double2 b = ring[((t - dd - 1) & 7) * 64 + ((lane - dd - 1) & 63)];
-                        bool okm = i1 && jm && x.i - dd - 1 >= 0 && t - dd - 2 >= 0;
-                        bool okd = i1 && x.i - dd - 1 >= 0 && t - dd - 1 >= 0;
-                        if (dd == 3) {  // the only source row the 3 spare lanes cannot disambiguate
-                            okm = okm && (x.i - 4 >= c5 - r);
-                            okd = okd && (x.i - 4 >= c4 - r);
-                        }
-                        const double fmv = okm ? (ST ? a.x * FS(t - dd - 2) : a.x) : 0.0;
-                        const double fdv = okd ? (ST ? b.y * FS(t - dd - 1) : b.y) : 0.0;
-                        double v = acc[13 + dd - 1];
-                        v = fma(fmv, hM, v);
-                        v = fma(fdv, vd, v);
-                        acc[13 + dd - 1] = v;
-                    }
-                };
-                if (straddle)
-                    products(std::true_type{});
-                else
-                    products(std::false_type{});
-                __syncthreads();
-                // slide: diagonal t-6 replaces diagonal t+2 in the ring; refill the queue slot
-                ring[((t - 6) & 7) * 64 + lane] = pf[u];
-                {
-                    const int tt = t - 6 - PF;
-                    pf[u] = tt >= 0 ? scratch[(uint64_t)tt * 64 + lane] : make_double2(0.0, 0.0);
-                }
-                __syncthreads();
-                hM_2 = hM_1;
-                hM_1 = hM;
-                hI_1 = hI;
-                bD_1 = vd;
-                // centres for the next step (t-1): c[t] -> c[t-1], c5 = c[t-6], c4 = c[t-5]
-                delta_next = t >= 1 ? delta_bit(s_delta, t) : 0;
-                c4 = c5;
-                if (t - 5 >= 1) c5 -= delta_bit(s_delta, t - 5);
             }
+            // the pair five diagonals below enters the ring now (its slot is not read by this step)
+            ring_put(slot_of(t - 5), pq[pq_idx]);
+            pq[pq_idx] = load_pair(t - 5 - JTK_PHMM_PF);
+            // (1) backward values of this diagonal
+            double vm, vi, vd;
+            if (t == T) {
+                vm = vi = vd = 1.0;
+            } else {
+                const double xm = rot_from_next(hM_2), xd = rot_from_next(bD_1), xi = hI_1;
+                vm = fma(aMD, xd, fma(aMI, xi, aMM * xm));
+                vi = fma(aID, xd, fma(aII, xi, aIM * xm));
+                vd = fma(aDD, xd, fma(aDI, xi, aDM * xm));
+            }
+            if (!active) vm = vi = vd = 0.0;
+            if (t < T && (t & (JTK_SCALE_BLOCK - 1)) == JTK_SCALE_BLOCK - 1) {
+                double mx = vm > vi ? vm : vi;
+                mx = vd > mx ? vd : mx;
+                mx = wave_max(mx);
+                if (mx > 0.0) {
+                    const int e = jtk_ilogb_pos(mx);
+                    const double sc = pow2i(-e);
+                    vm *= sc;
+                    vi *= sc;
+                    vd *= sc;
+                    hM_1 *= sc;
+                    EB += e;
+                }
+            }
+            const int ey8 = ey0[j], xs = xs0[i], y8 = ey8 & 24;
+            const double hM = *reinterpret_cast<const double *>(s_eM + xs + y8) * vm;
+            const double hI = *reinterpret_cast<const double *>(s_eI + ey8) * vi;
+            // (2) common exponent of this step
+            const int EFt = s_EF[t >> 6];
+            const int G = EFt + EB;
+            if (t < T && G != Gprev) {
+                const double sc = pow2i(Gprev - G);
+#pragma unroll
+                for (int k = 0; k < JTK_ACC_N; k++) acc[k] *= sc;
+            }
+            Gprev = G;
+            // (3) the 16 row-crossing products of this cell.  Pair P_x holds toM of diagonal x-1 and toD of diagonal x;
+            //     a source diagonal in another 64-diagonal block is re-expressed by an exact power of two.
+            auto FS = [&](int tt) -> double {  // 2^(EF[tt]-EF[t])
+                if (tt < 0 || tt > T) return 1.0;
+                return fast_pow2(s_EF[tt >> 6] - EFt);
+            };
+            auto pair = [&](int x, int k) -> double2 {
+                double2 v = ring_me[slot_of(x) * RW + k];
+                if (ST) {
+                    v.x *= FS(x - 1);
+                    v.y *= FS(x);
+                }
+                return v;
+            };
+            {  // sub (entry i-1): toM(i-1, j-1), toD(i-1, j)
+                const double2 a = pair(t - 1, -1);
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[q] = fma(y8 == 8 * q ? a.x : 0.0, vm, acc[q]);
+                acc[4] = fma(a.y, vd, acc[4]);
+            }
+            {  // ins (entry i): toM(i, j-1), toD(i, j);   copy 1 (entry i-1): the same pair against hatM
+                const double2 a = pair(t, 0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[5 + q] = fma(y8 == 8 * q ? a.x : 0.0, vm, acc[5 + q]);
+                acc[9] = fma(a.y, vd, acc[9]);
+                acc[10] = fma(a.y, vd, fma(a.x, hM, acc[10]));
+            }
+#pragma unroll
+            for (int cc = 2; cc <= 3; cc++) {  // copy c (entry i-1): toM(i-1+c, j-1), toD(i-1+c, j)
+                const double2 a = pair(t + cc - 1, cc - 1);
+                acc[10 + cc - 1] = fma(a.y, vd, fma(a.x, hM, acc[10 + cc - 1]));
+            }
+#pragma unroll
+            for (int dd = 1; dd <= 3; dd++) {  // del d (entry i-d-1): toM(i-d-1, j-1), toD(i-d-1, j)
+                double2 a = pair(t - dd - 1, -dd - 1);
+                if (dd == 3) {  // the only source row the 3 spare lanes cannot disambiguate
+                    if (!(i - 4 >= c5 - r)) a.x = 0.0;
+                    if (!(i - 4 >= c4 - r)) a.y = 0.0;
+                }
+                acc[13 + dd - 1] = fma(a.y, vd, fma(a.x, hM, acc[13 + dd - 1]));
+            }
+            hM_2 = hM_1;
+            hM_1 = hM;
+            hI_1 = hI;
+            bD_1 = vd;
+            // centres for the next step (t-1): c[t] -> c[t-1], c5 = c[t-6], c4 = c[t-5]
+            delta_next = t >= 1 ? delta_bit(s_delta, t) : 0;
+            c4 = c5;
+            if (t - 5 >= 1) c5 -= delta_bit(s_delta, t - 5);
+        };
+        // groups of 8 diagonals, tb == 7 (mod 8): slots and queue registers are compile-time inside a group
+        for (int tb = T | 7; tb >= 7; tb -= 8) {
+            const int g = tb & 63;
+            // steps whose source window t-5 .. t+2 straddles a block boundary: t & 63 in {62, 63, 0, .., 4}
+            const bool grpA = g == 63, grpB = g == 7;
+#define GROUP_STEP(u)                                                                                     \
+    {                                                                                                     \
+        const int t = tb - (u);                                                                           \
+        if (t <= T) {                                                                                     \
+            auto slot_of = [&](int x) -> int { return (x - t + (7 - (u)) + 64) & 7; }; /* == x & 7 */     \
+            const bool st_u = ((u) <= 1 && grpA) || ((u) >= 3 && grpB);                                    \
+            if (((u) <= 1 || (u) >= 3) && st_u)                                                           \
+                step(t, slot_of, std::true_type{}, std::integral_constant<int, (2 - (u)) & (JTK_PHMM_PF - 1)>{});         \
+            else                                                                                          \
+                step(t, slot_of, std::false_type{}, std::integral_constant<int, (2 - (u)) & (JTK_PHMM_PF - 1)>{});        \
+        }                                                                                                 \
+    }
+            GROUP_STEP(0)
+            GROUP_STEP(1)
+            GROUP_STEP(2)
+            GROUP_STEP(3)
+            GROUP_STEP(4)
+            GROUP_STEP(5)
+            GROUP_STEP(6)
+            GROUP_STEP(7)
+#undef GROUP_STEP
         }
         // rows still in the band after t == 0
         {
-            const Lane x = lane_cell(lane, c, r, 0, L, n);
-            const int off = (lane - (c - r)) & 63;
-            if (off <= 2 * r && x.i >= 0 && x.i <= L) {
-                double2 *dst = reinterpret_cast<double2 *>(raw + (uint64_t)x.i * JTK_ACC_N);
+            const int lo = c - r, off = (lane - lo) & 63, i = lo + off;
+            if (off <= 2 * r && (unsigned)i <= (unsigned)L) {
+                double2 *dst = reinterpret_cast<double2 *>(raw + (uint64_t)i * JTK_ACC_N);
 #pragma unroll
                 for (int k = 0; k < JTK_ACC_N / 2; k++) dst[k] = make_double2(acc[2 * k], acc[2 * k + 1]);
-                rawG[x.i] = Gprev;
+                rawG[i] = Gprev;
             }
         }
     }
@@ -516,8 +523,8 @@ void launch_band_prep(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, co
 
 size_t phmm_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
     const uint32_t n_blk = ((max_tmpl + max_read) >> 6) + 4;
-    size_t b = 8 * 64 * 16 + 36 * 8 + (size_t)n_blk * 12;
-    b += ((max_tmpl + 16) & ~15u) + max_read + 16;
+    size_t b = 8 * RW * 16 + 36 * 8 + (size_t)n_blk * 12;
+    b += ((max_tmpl + 2 * PAD + 15) & ~15u) + max_read + 1 + 2 * PAD;
     return (b + 15) & ~(size_t)15;
 }
 

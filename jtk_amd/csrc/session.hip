@@ -11,6 +11,7 @@
 // :112, pseudo_mcmc.rs:117), so it is reused instead of recomputed.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -331,7 +332,9 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         // resident waves of phmm_kernel: 3 per SIMD by registers, 11 per CU by its ~14 KB of LDS
-        const uint32_t want = (uint32_t)prop.multiProcessorCount * 11;
+        uint32_t per_cu = 8;  // resident waves per CU: 2 per SIMD (register budget of phmm_kernel, JTK_PHMM_WAVES)
+        if (const char *e = getenv("JTK_PHMM_WAVES_PER_CU")) per_cu = (uint32_t)atoi(e);  // tuning experiments only
+        const uint32_t want = (uint32_t)prop.multiProcessorCount * per_cu;
         s->n_waves = n_reads < want ? (uint32_t)n_reads : want;
         if (s->n_waves == 0) s->n_waves = 1;
         s->scratch_stride = (uint64_t)(s->max_tmpl + s->max_read + 8) * 64 * 2;  // doubles
