@@ -5,8 +5,13 @@ gfx950 reports half of the bytes of a wide coalesced streaming read, so the corr
 import collections
 import csv
 import glob
+import json
 import re
 import sys
+
+FAMILY = {"mcmc": ["mcmc_kernel"], "phmm": ["phmm_kernel", "finalize_kernel"],
+          "polish": ["sum_tables_kernel", "select_edits_kernel", "rethread_kernel", "commit_kernel", "band_prep_kernel"],
+          "filter": ["homop_kernel", "chunk_tables_kernel", "column_filter_kernel", "pick_kernel"]}
 
 
 def short(name):
@@ -14,8 +19,9 @@ def short(name):
     return m.group(1) if m else name.split("(")[0]
 
 
-def main(root):
+def main(root, json_path=None):
     out = []
+    pmc = {}
     stats = glob.glob(f"{root}/prof_stats/*/*_kernel_stats.csv")
     out.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline ==")
     out.append("(3 hot-path passes over the 500-chunk batch: 1 warm-up + 2 timed)")
@@ -36,8 +42,17 @@ def main(root):
         out.append(f"{'kernel':28s} {'launches':>8s} {'sum_KiB':>16s} {'per_launch_KiB':>16s}")
         for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             out.append(f"{k:28s} {n:8d} {v:16.1f} {v / n:16.1f}")
+            pmc.setdefault(k, {})[f"{label}_KiB_per_launch"] = v / n
+            pmc[k]["launches_in_profile"] = n
     print("\n".join(out))
+    if json_path:  # what bench.py reads back as roofline.traffic
+        json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py "
+                              "--steps 2 --warmup 1 --no-cpu-baseline",
+                   "workload": "cfg2_ont_diploid_500x60x2kbp",
+                   "note": "KiB per launch; FETCH_SIZE on gfx950 reports half of the bytes of wide coalesced reads "
+                           "(MI355X_MICROARCH.md HBM): hbm_bytes = (2*FETCH + WRITE)*1024",
+                   "kernel_family": FAMILY, "kernels": pmc}, open(json_path, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out")
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else None)
