@@ -1,4 +1,4 @@
-// mcmc_kernels.hip -- the read-clustering loop on the device: one wavefront per chunk.
+// mcmc_kernels.hip -- the read-clustering loop on the device: one workgroup of two wavefronts per chunk.
 //
 // Follows, statement by statement, haplotyper/src/local_clustering/pseudo_mcmc.rs
 //   cluster_filtered_variants :213-274   mcmc_clustering :649-670   mcmc_with_filter :704-762
@@ -9,19 +9,19 @@
 // with the rand 0.8.5 / rand_xoshiro 0.6.0 sampling restated exactly as in oracle/rng.c.
 //
 // The chain is strictly sequential per chunk (one RNG stream threads through k-means, 20 restarts and every
-// candidate k, local_clustering/mod.rs:97).  A lone wavefront on CDNA4 issues roughly one dependent
-// instruction every 5-7 cycles, so the chain is bound by the instruction count of a step, not by bandwidth.
-// Two things buy speed without changing a single bit of the result:
-//  * PIPELINE: a workgroup is two wavefronts.  Wave 1 ("producer") does nothing but run xoshiro256** and
-//    append its raw u64 outputs to an LDS ring; wave 0 ("consumer") runs the algorithm and takes every random
-//    draw -- k-means initialisation, proposals, Bernoulli tests -- from that ring, in stream order.  The stream
-//    itself never depends on the chain, so nothing is ever speculated or rolled back on the producer side.
-//  * A SLIM STEP: lane d keeps LKCount[c][d] of every cluster c in registers (K is a template parameter, so
-//    the cluster index is a static register index); counts are kept as integers (num_pos and 3*num_pos -
-//    7*num_neg, which decides is_informative exactly); a proposal is evaluated on tentative values and then
-//    committed or undone with the reference's own arithmetic ((tg - x) + x, not a restore); labels, cluster
-//    sizes and the >0 masks are wave-uniform scalars; the left-to-right sum of get_lk visits only the non-zero
-//    terms (ballot + v_readlane).
+// candidate k, local_clustering/mod.rs:97).  A lone wavefront on CDNA4 issues a dependent instruction every
+// ~8 cycles and pays ~30 for a value that crosses from the vector to the scalar side, so the chain is bound by the
+// length of the dependent chain of a step, not by bandwidth.  What buys speed without changing a bit of the result:
+//  * PIPELINE: wave 1 ("producer") runs xoshiro256** lane-parallel (GF(2) jump-ahead) into an LDS ring and, for the
+//    diploid chain, parses the proposal that would start at every stream position into a 32-bit record; wave 0
+//    ("consumer") runs the algorithm and takes every random draw -- k-means initialisation, proposals, Bernoulli
+//    tests -- from that ring, in stream order.  The stream never depends on the chain, so nothing is speculated.
+//  * THE DIPLOID CHAIN (K == 2, n <= 63, D <= 8) is a table-driven walk over certainly rejected proposals with
+//    exact single steps for everything else (mcmc_chain_k2).
+//  * THE GENERIC CHAIN keeps LKCount[c][d] in registers (lane = column, K a template parameter), the counts as
+//    integers (num_pos and 3*num_pos - 7*num_neg, which decides is_informative exactly), labels / sizes / >0 masks
+//    as wave-uniform scalars, and commits or undoes a proposal with the reference's own arithmetic
+//    ((tg - x) + x, not a restore); get_lk's left-to-right sum visits only the non-zero terms.
 // Sums that the reference evaluates left to right are evaluated left to right here -- integer labels only
 // match if every f64 rounding matches.
 #include <vector>
