@@ -199,3 +199,118 @@ def test_session_is_repeatable_and_matches_one_shot(lib):
         assert np.array_equal(a[k], c[k]) and np.array_equal(a[k], one[k])
     t = api.last_timing()
     assert t["kernel_launches"]["phmm"] >= 1
+
+
+def test_chain_variants_match_oracle(lib):
+    """every code path of the diploid chain and its neighbours: replicated state (1, 2, 3-4 columns), the
+    lane-distributed state (5-8), more columns / more reads than the table-driven chain takes (generic chain on
+    the same stream), all-zero rows (size-only moves), tiny pile-ups"""
+    p = jb.default_params(haploid_coverage=15.0)
+    specs = [(60, 1, 2, 2), (60, 2, 2, 2), (45, 4, 2, 2), (63, 8, 2, 2), (40, 7, 2, 2), (50, 9, 2, 2),
+             (64, 3, 2, 2), (12, 4, 2, 2), (5, 2, 2, 2), (33, 5, 1, 2)]
+    dev, ora, truth = run_features_both(p, specs, seed=7)
+    assert np.array_equal(dev["label"], ora["label"])
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(ora["log_post"]))
+    assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(ora["result"]["score"]))
+
+
+def test_size_only_moves_match_oracle(lib):
+    """a third of the reads carry no signal at all (all-zero rows): hundreds of thousands of accepted moves that
+    change nothing but the cluster sizes, decided from the per-size tables"""
+    import ctypes as C
+    p = jb.default_params(haploid_coverage=20.0)
+    rng = np.random.default_rng(11)
+    specs = [(60, 1), (48, 2), (60, 3)]
+    chunks = np.zeros(len(specs), dtype=ffi.FEATURE_CHUNK_DT)
+    var, vts = [], []
+    voff = vtoff = rfirst = 0
+    for i, (n, dim) in enumerate(specs):
+        x, vt, _ = random_feature_problem(rng, n, dim, 2, i, 2)
+        x[rng.random(n) < 0.35] = 0.0
+        chunks[i] = (77 + 5 * i, 2, n, dim, 0, voff, vtoff, rfirst, n / 2)
+        var.append(x.ravel())
+        vts.append(vt.ravel())
+        voff += n * dim
+        vtoff += dim
+        rfirst += n
+    var = np.concatenate(var)
+    vts = np.concatenate(vts).astype(np.uint32)
+    dev = api.cluster_features(p, chunks, var, vts, 2)
+    po = helpers.oracle_params(p)
+    lab = np.zeros(rfirst, np.uint32)
+    post = np.zeros((rfirst, 2))
+    res = np.zeros(len(specs), dtype=ffi.RESULT_DT)
+    assert O.lib().jo_cluster_features(C.byref(po), len(specs), chunks.ctypes.data, O.f64p(var), O.u32p(vts),
+                                       O.u32p(lab), O.f64p(post), 2, res.ctypes.data, 0) == 0
+    assert np.array_equal(dev["label"], lab)
+    assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(post))
+    assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(res["score"]))
+
+
+# ---- BASELINE.json's full sizes (60 reads x 2 kbp per chunk): properties that need no oracle run
+
+@pytest.fixture(scope="module")
+def full_size(lib):
+    cfg = dict(synth.CONFIGS["ont_diploid"])
+    b, cfg = synth.make_batch(cfg, 24)
+    p = jb.default_params(cfg["coverage"], cfg["band_frac"])
+    return b, p, api.cluster_chunks(p, b)
+
+
+def test_full_size_results_do_not_depend_on_batch_order(lib, full_size):
+    """chunks are independent (own RNG stream from the chunk id): any sub-batch, in any order, reproduces them"""
+    b, p, out = full_size
+    idx = [17, 3, 11, 0, 23]
+    sub = b.subset(idx)
+    o2 = api.cluster_chunks(p, sub)
+    for k, c in enumerate(idx):
+        ra, rb_ = list(b.chunk_reads(c)), list(sub.chunk_reads(k))
+        assert np.array_equal(out["label"][ra], o2["label"][rb_])
+        assert np.array_equal(helpers.bits(out["log_post"][ra]), helpers.bits(o2["log_post"][rb_]))
+        assert out["result"][c]["cluster_num"] == o2["result"][k]["cluster_num"]
+        assert out["result"][c]["polish_rounds"] == o2["result"][k]["polish_rounds"]
+        ca = out["cons"][int(out["cons_off"][c]):int(out["cons_off"][c + 1])]
+        cb = o2["cons"][int(o2["cons_off"][k]):int(o2["cons_off"][k + 1])]
+        assert bytes(ca) == bytes(cb)
+
+
+def test_full_size_polish_is_a_fixed_point(lib, full_size):
+    """feeding the polished consensus and the re-threaded alignments back in changes nothing: no edit is found,
+    and the clustering (tables -> variants -> chain) is reproduced bit for bit"""
+    b, p, out = full_size
+    pile = []
+    for c in range(8):
+        reads = list(b.chunk_reads(c))
+        cons = out["cons"][int(out["cons_off"][c]):int(out["cons_off"][c + 1])]
+        ops = [out["ops_out"][int(out["ops_out_off"][r]):int(out["ops_out_off"][r + 1])] for r in reads]
+        pile.append((int(b.chunks[c]["chunk_id"]), int(b.chunks[c]["copy_num"]), cons, [b.read(r) for r in reads], ops,
+                     [int(b.strand[r]) for r in reads], None))
+    again = api.cluster_chunks(p, jb.pack(pile))
+    n8 = int(b.chunks[8]["read_first"])
+    assert np.all(again["result"]["polish_rounds"] <= 1)
+    assert bytes(again["cons"][:int(again["cons_off"][8])]) == bytes(out["cons"][:int(out["cons_off"][8])])
+    # the band radius follows the template length (mod.rs:96), so only chunks whose length did not move are
+    # guaranteed the same band; for those the whole downstream path must repeat exactly
+    for c in range(8):
+        L0, L1 = int(b.chunks[c]["tmpl_len"]), int(out["cons_off"][c + 1] - out["cons_off"][c])
+        if int(np.ceil(L0 * p.band_frac)) == int(np.ceil(L1 * p.band_frac)):
+            ra = list(b.chunk_reads(c))
+            assert np.array_equal(again["label"][ra], out["label"][ra])
+            assert np.array_equal(helpers.bits(again["log_post"][ra]), helpers.bits(out["log_post"][ra]))
+    assert n8 == len(again["label"])
+
+
+def test_full_size_posteriors_are_normalised_and_labels_recover_truth(lib, full_size):
+    b, p, out = full_size
+    agree = []
+    for c in range(b.n_chunks):
+        rr = list(b.chunk_reads(c))
+        k = int(out["result"][c]["cluster_num"])
+        rows = out["log_post"][rr][:, :k]
+        assert np.abs(np.log(np.exp(rows).sum(axis=1))).max() < 1e-4   # mod.rs:184-185
+        assert out["label"][rr].max() < k
+        if k == 2:
+            lab, tr = out["label"][rr], b.truth[rr]
+            agree.append(max((lab == tr).mean(), (lab != tr).mean()))
+    assert len(agree) >= 6 and np.mean(agree) > 0.9
