@@ -892,9 +892,18 @@ __device__ __attribute__((noinline)) uint64_t gen_bool_threshold(double diff) {
 // REPL: the state is replicated in every lane (wave-uniform values in vector registers; neither the exact step nor
 // the table rebuild needs a cross-lane operation) -- used up to 4 columns.  Otherwise lane d holds column d and
 // the rebuild / the ordered sum fetch it with v_readlane (8 replicated columns do not fit the register budget).
+// Out of line on purpose: inlined into the kernel, the chain inherits the register pressure of everything that is
+// live around it and spills scalar registers inside its loop (each reload is a v_readlane on the critical path).
+struct K2Mem {
+    const Elem *elem;
+    const double *lfact;
+    uint8_t *assign;
+    unsigned long long *k2_stats;
+};
 template <int DMAX, bool REPL>
-__device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng,
-                                                uint32_t lane) {
+__device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, uint32_t D, double cov, Rng *rng_io,
+                                                          uint32_t lane) {
+    Rng rng = *rng_io;
     constexpr int NS = REPL ? DMAX : 1;  // state registers per lane
     // pair table: lane c0 holds (0.0 + size_to_lk[c0]) + size_to_lk[n - c0]   (get_lk :788)
     double pair_v;
@@ -1236,15 +1245,19 @@ __device__ __forceinline__ double mcmc_chain_k2(const Lds &m, uint32_t n, uint32
     rng_release(rng, lane);
     if (lane < n) m.assign[lane] = (uint8_t)((argmax >> lane) & 1ull);
     wsync();
+    *rng_io = rng;
     return max;
 }
 
 template <int K>
 __device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
-    if (K == 2 && n <= 63 && D == 1) return mcmc_chain_k2<1, true>(m, n, D, cov, rng, lane);
-    if (K == 2 && n <= 63 && D == 2) return mcmc_chain_k2<2, true>(m, n, D, cov, rng, lane);
-    if (K == 2 && n <= 63 && D >= 1 && D <= 4) return mcmc_chain_k2<4, true>(m, n, D, cov, rng, lane);
-    if (K == 2 && n <= 63 && D >= 1 && D <= 8) return mcmc_chain_k2<8, false>(m, n, D, cov, rng, lane);
+    if (K == 2 && n <= 63 && D >= 1 && D <= 8) {
+        const K2Mem km = {m.elem, m.lfact, m.assign, m.k2_stats};
+        if (D == 1) return mcmc_chain_k2<1, true>(km, n, D, cov, &rng, lane);
+        if (D == 2) return mcmc_chain_k2<2, true>(km, n, D, cov, &rng, lane);
+        if (D <= 4) return mcmc_chain_k2<4, true>(km, n, D, cov, &rng, lane);
+        return mcmc_chain_k2<8, false>(km, n, D, cov, &rng, lane);
+    }
     if (n <= 63) return mcmc_chain<K, true>(m, n, D, cov, rng, lane);
     return mcmc_chain<K, false>(m, n, D, cov, rng, lane);
 }
