@@ -609,7 +609,8 @@ __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_
 // The Bernoulli test of `0f64 < diff || rng.gen_bool(diff.exp())` (:736) for a step that does draw:
 // gen_bool compares the u64 draw v with p_int = floor(exp(diff) * 2^64).  The exact exp is only evaluated
 // when an f32 estimate with a guard band cannot decide, so the decision is always the exact one.
-__device__ __forceinline__ bool bernoulli_exact(uint64_t v, double diff) {
+// (out of line: the exact exp is the rare path and the chain is sensitive to its code size)
+__device__ __attribute__((noinline)) bool bernoulli_exact(uint64_t v, double diff) {
     // f32 estimate first: u = v / 2^64 within 2^-24, pe = exp(diff) within ~1e-5 relative
     const float u = (float)(uint32_t)(v >> 40) * 0x1p-24f;
     const float pe = __expf((float)diff);
@@ -882,12 +883,15 @@ __device__ __forceinline__ void scalar_proposal(Rng &rng, uint32_t start, uint32
 #define ST_CNT(k, v)
 #endif
 
-// gen_bool's p_int for p = exp(diff) < 1 (rand 0.8.5 Bernoulli: (p * 2^64) as u64).  Kept out of line: two inlined
-// copies of exp in the table builder cost more registers than the whole chain.
-__device__ __attribute__((noinline)) uint64_t gen_bool_threshold(double diff) {
-    const double scaled = jtk_exp(diff) * 18446744073709551616.0;
-    return !(scaled > 0.0) ? 0ull : __double2ull_rz(scaled);
+// Neighbour-lane reads that stay off the LDS crossbar (a ds_bpermute round trip costs a lone wave ~100 cycles).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double from_next_lane(double v) { return dpp_f64<0x134>(v); }  // lane l <- lane l+1 (wave_rol:1)
+__device__ __forceinline__ double from_prev_lane(double v) { return dpp_f64<0x13C>(v); }  // lane l <- lane l-1 (wave_ror:1)
 
 // REPL: the state is replicated in every lane (wave-uniform values in vector registers; neither the exact step nor
 // the table rebuild needs a cross-lane operation) -- used up to 4 columns.  Otherwise lane d holds column d and
@@ -1039,10 +1043,11 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
     };
     // ---- size-only moves (a read with an all-zero row): with the column sums fixed, get_lk is a function of the
     //      cluster-0 size alone.  Lane c holds G[c] = get_lk at size c (the same left-to-right sum), and for the
-    //      moves c -> c+1 / c -> c-1 the exact gen_bool threshold p_int = (exp(diff) * 2^64) as u64; ndm_*: moves
-    //      that draw nothing (diff >= -2^-54).  Built on demand, stale once a column sum moves.
+    //      moves c -> c+1 / c -> c-1 an f32 estimate of exp(diff) that decides gen_bool from the 20 known bits of the
+    //      draw whenever those suffice; ndm_*: moves that draw nothing (diff >= -2^-54).  Built on demand, stale once
+    //      a column sum moves.
     double Gtab = 0.0;
-    uint64_t pint_up = 0, pint_dn = 0;
+    float pf_up = 0.0f, pf_dn = 0.0f;
     unsigned long long ndm_up = 0, ndm_dn = 0;
     bool gtab_ok = false;
     auto build_gtab = [&]() {
@@ -1061,9 +1066,9 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
             for (int q = 0; q < DMAX; q++) G += readlane_f64(t1[0], q);
         }
         Gtab = G;
-        const double du = __shfl_down(G, 1, 64) - G, dd = __shfl_up(G, 1, 64) - G;
-        pint_up = gen_bool_threshold(du);
-        pint_dn = gen_bool_threshold(dd);
+        const double du = from_next_lane(G) - G, dd = from_prev_lane(G) - G;
+        pf_up = __expf((float)du);
+        pf_dn = __expf((float)dd);
         ndm_up = __ballot(du >= -0x1p-54);
         ndm_dn = __ballot(dd >= -0x1p-54);
         gtab_ok = true;
@@ -1108,12 +1113,18 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
             const bool nd = ((old ? ndm_up : ndm_dn) >> c0) & 1ull;
             bool acc = true;
             if (!nd) {
-                rng_wait(rng, pos_v + 1);
-                const uint64_t v = uni64(lds_ld64(&rng.ring[ring_slot(pos_v)]));
-                const uint64_t pi = old ? pint_up : pint_dn;
-                const uint64_t pint = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pi >> 32), (int)c0) << 32) |
-                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pi, (int)c0);
-                acc = v < pint;
+                // u: the Bernoulli draw / 2^64 truncated to 20 bits (true value < u + 2^-20); pe within ~1e-5 relative
+                const float pe = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(old ? pf_up : pf_dn), (int)c0));
+                const float u = reload ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd.u), (int)p));
+                if (u >= 0.0f && u > pe * 1.001f + 1.3e-6f) {
+                    acc = false;
+                } else if (u >= 0.0f && u + 0x1p-20f < pe * 0.999f - 3e-7f) {
+                    acc = true;
+                } else {
+                    const double diff = readlane_f64(Gtab, old ? c0 + 1 : c0 - 1) - lk;
+                    rng_wait(rng, pos_v + 1);
+                    acc = bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff);
+                }
             }
             if (acc) {
                 c0 = old ? c0 + 1 : c0 - 1;
@@ -1177,8 +1188,16 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
         const bool no_draw = ubool(diff >= -0x1p-54);
         bool accept = true;
         if (!no_draw) {
-            rng_wait(rng, pos_v + 1);
-            accept = bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff);
+            // the 20 known bits of the draw decide gen_bool unless it is within the guard bands of exp(diff)
+            const float u = reload ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd.u), (int)p));
+            const float pe = __expf((float)diff);
+            const bool in_range = u >= 0.0f && diff < -1e-3 && diff > -44.4;
+            if (ubool(diff <= -44.4 || (in_range && u > pe * 1.001f + 1.3e-6f))) {
+                accept = false;
+            } else if (!ubool(in_range && u + 0x1p-20f < pe * 0.999f - 3e-7f)) {
+                rng_wait(rng, pos_v + 1);
+                accept = bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff);
+            }
         }
         int changed = 2;  // 0: nothing moved, 2: sums moved
         if (accept) {
