@@ -81,8 +81,11 @@ __global__ void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const 
     for (uint32_t w = 0; w < words; w++) d[w] = 0;
     uint32_t i = 0, j = 0, t = 0;
     bool bad = false;
+    // the walk is one thread per read and latency bound: fetch the ops 8 at a time (ops_off is 8-byte aligned)
+    uint64_t chunk8 = 0;
     for (uint32_t k = 0; k < n_ops; k++) {
-        uint8_t op = ops[k];
+        if ((k & 7u) == 0) chunk8 = *reinterpret_cast<const uint64_t *>(ops + k);
+        uint8_t op = (uint8_t)(chunk8 >> (8 * (k & 7u)));
         if (op == JTK_OP_INS) {
             t += 1;
             j++;

@@ -140,6 +140,28 @@ __global__ void rethread_kernel(uint32_t n_reads, const ReadMeta *reads, const C
     uint32_t w = 0, e = 0, ti = 0;
     uint32_t ni = 0, nj = 0;  // positions in the NEW template / the read, for re-tagging
     bool overflow = false;
+    // One thread per read, latency bound: the three input streams (ops, new template, read) are fetched 8 bytes
+    // at a time and the output leaves 8 bytes at a time (slots are 8-byte aligned with >= 8 bytes of slack).
+    uint64_t in8 = 0, t8 = 0, y8 = 0, out8 = 0;
+    uint32_t t8_at = ~0u, y8_at = ~0u;  // 8-byte block currently held of tmpl / ey
+    auto tmpl_at = [&](uint32_t q) -> uint8_t {
+        const uint64_t a = (uint64_t)(cm.tmpl_off + q);  // absolute byte offset: blocks are aligned in the buffer
+        const uint32_t blk = (uint32_t)(a >> 3);
+        if (blk != t8_at) {
+            t8 = *reinterpret_cast<const uint64_t *>(bufs.tmpl[b ^ 1] + ((uint64_t)blk << 3));
+            t8_at = blk;
+        }
+        return (uint8_t)(t8 >> (8 * (a & 7)));
+    };
+    auto ey_at = [&](uint32_t q) -> uint8_t {
+        const uint64_t a = rm.ey_off + q;
+        const uint32_t blk = (uint32_t)(a >> 3);
+        if (blk != y8_at) {
+            y8 = *reinterpret_cast<const uint64_t *>(ey_all + ((uint64_t)blk << 3));
+            y8_at = blk;
+        }
+        return (uint8_t)(y8 >> (8 * (a & 7)));
+    };
     auto emit = [&](uint8_t op) {
         if (w >= rm.ops_cap) {
             overflow = true;
@@ -150,11 +172,16 @@ __global__ void rethread_kernel(uint32_t n_reads, const ReadMeta *reads, const C
         } else if (op == JTK_OP_DEL) {
             ni++;
         } else {
-            op = tmpl[ni] == (ey[nj + 1] & 3) ? JTK_OP_MATCH : JTK_OP_MISMATCH;
+            op = tmpl_at(ni) == (ey_at(nj + 1) & 3) ? JTK_OP_MATCH : JTK_OP_MISMATCH;
             ni++;
             nj++;
         }
-        out[w++] = op;
+        out8 |= (uint64_t)op << (8 * (w & 7u));
+        w++;
+        if ((w & 7u) == 0) {
+            *reinterpret_cast<uint64_t *>(out + w - 8) = out8;
+            out8 = 0;
+        }
     };
     auto pending_inserts = [&]() {
         while (e < ne && edits[e].pos == ti && edits[e].row >= 4 && edits[e].row < 11) {
@@ -165,7 +192,8 @@ __global__ void rethread_kernel(uint32_t n_reads, const ReadMeta *reads, const C
     };
     pending_inserts();
     for (uint32_t k = 0; k < n_ops; k++) {
-        const uint8_t op = ops[k];
+        if ((k & 7u) == 0) in8 = *reinterpret_cast<const uint64_t *>(ops + k);
+        const uint8_t op = (uint8_t)(in8 >> (8 * (k & 7u)));
         if (op == JTK_OP_INS) {
             emit(op);
             continue;
@@ -181,6 +209,7 @@ __global__ void rethread_kernel(uint32_t n_reads, const ReadMeta *reads, const C
         }
         pending_inserts();
     }
+    if ((w & 7u) != 0 && !overflow) *reinterpret_cast<uint64_t *>(out + (w & ~7u)) = out8;  // inside the slot: cap % 8 == 0
     bufs.ops_len[b ^ 1][r] = w;
     if (overflow) atomicMin(&st->status, (int)JTK_ERR_CHUNK_FAILED);
 }

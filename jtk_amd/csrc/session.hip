@@ -240,7 +240,7 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
             rm.read_len = (uint32_t)rl;
             rm.ey_off = ey_off;
             rm.ops_off = ops_cap_off;
-            rm.ops_cap = (uint32_t)ol + tl / 8 + 64;
+            rm.ops_cap = ((uint32_t)ol + tl / 8 + 64 + 7u) & ~7u;  // slots stay 8-byte aligned: the walkers fetch 8 ops at a time
             rm.strand = strand[g] ? 1 : 0;
             rm.delta_off = delta_off;
             rm.table_off = table_off;
@@ -296,12 +296,14 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
     if ((rc = dev_upload(s, s->d_tmpl_init, h_tmpl))) return rc;
     if ((rc = dev_upload(s, s->d_ops_init, h_ops))) return rc;
     if ((rc = dev_upload(s, s->d_opslen_init, h_opslen))) return rc;
-    if ((rc = dev_alloc<uint8_t>(s->d_tmpl0, h_tmpl.size()))) return rc;
-    if ((rc = dev_alloc<uint8_t>(s->d_tmpl1, h_tmpl.size()))) return rc;
+    // (+8: the polish kernels fetch templates / reads in aligned 8-byte blocks)
+    if ((rc = dev_alloc<uint8_t>(s->d_tmpl0, h_tmpl.size() + 8))) return rc;
+    if ((rc = dev_alloc<uint8_t>(s->d_tmpl1, h_tmpl.size() + 8))) return rc;
     if ((rc = dev_alloc<uint8_t>(s->d_ops0, h_ops.size()))) return rc;
     if ((rc = dev_alloc<uint8_t>(s->d_ops1, h_ops.size()))) return rc;
     if ((rc = dev_alloc<uint32_t>(s->d_opslen0, n_reads))) return rc;
     if ((rc = dev_alloc<uint32_t>(s->d_opslen1, n_reads))) return rc;
+    h_ey.resize(h_ey.size() + 8, 0);
     if ((rc = dev_upload(s, s->d_ey, h_ey))) return rc;
     if ((rc = dev_alloc<uint64_t>(s->d_delta, delta_off))) return rc;
     if ((rc = dev_alloc<double>(s->d_raw, raw_off))) return rc;
