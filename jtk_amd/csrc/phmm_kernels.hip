@@ -206,16 +206,33 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
             if (lane == 0) s_EF[0] = 0;
             if (T == 0) endM = fm;
         }
-        uint64_t dw = 0;
-        for (int t = 1; t <= T; t++) {
-            if ((t & 63) == 0 || t == 1) dw = s_delta[t >> 6];
-            c += (int)(__builtin_amdgcn_readfirstlane((uint32_t)(dw >> (t & 32))) >> (t & 31)) & 1;
-            const int lo = c - r, off = (lane - lo) & 63, i = lo + off, j = t - i;
-            const bool active = off <= 2 * r && (unsigned)i <= (unsigned)L && (unsigned)j <= (unsigned)n;
-            const double pM = rot_from_prev(toM_2), pD = rot_from_prev(toD_1);
+        // The emission look-ups of a cell (two dependent LDS reads) do not depend on the recurrence, so they are
+        // issued one anti-diagonal ahead: with two waves per SIMD nothing else would cover their latency.
+        auto sdelta = [&](int w) -> uint64_t {  // a word of band deltas as a scalar
+            const uint64_t v = s_delta[w];
+            return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+        };
+        uint64_t dw = sdelta(0);
+        int c_n = 0;
+        bool act_n = false;
+        double eM_n = 0.0, eI_n = 0.0;
+        auto prefetch_fwd = [&](int tn) {  // the cell of diagonal tn on this lane
+            if ((tn & 63) == 0) dw = sdelta(tn >> 6);
+            c_n += (int)((dw >> (tn & 63)) & 1ull);
+            const int lo = c_n - r, off = (lane - lo) & 63, i = lo + off, j = tn - i;
+            act_n = off <= 2 * r && (unsigned)i <= (unsigned)L && (unsigned)j <= (unsigned)n;
             const int ey8 = ey0[j], xs = xs0[i];
-            const double eMv = *reinterpret_cast<const double *>(s_eM + xs + (ey8 & 24));
-            const double eIv = *reinterpret_cast<const double *>(s_eI + ey8);
+            eM_n = *reinterpret_cast<const double *>(s_eM + xs + (ey8 & 24));
+            eI_n = *reinterpret_cast<const double *>(s_eI + ey8);
+        };
+        if (T >= 1) prefetch_fwd(1);
+        for (int t = 1; t <= T; t++) {
+            c = c_n;
+            const bool active = act_n;
+            const double eMv = eM_n, eIv = eI_n;
+            if (t < T) prefetch_fwd(t + 1);
+            const double pM = rot_from_prev(toM_2), pD = rot_from_prev(toD_1);
             double fm = eMv * pM, fi = eIv * toI_1, fd = pD;
             if (!active) fm = fi = fd = 0.0;
             const double toM_prev = toM_1;  // toM of diagonal t-1 in its own block's scale: what the pair stores
