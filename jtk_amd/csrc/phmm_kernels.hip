@@ -123,8 +123,9 @@ __global__ void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const 
 //    ONE such pair, so a step does 7 ds_read_b128 instead of 16 ds_read_b64;
 //  * template / read codes are staged pre-multiplied into byte offsets of the emission tables and padded on both
 //    sides, so the lookups need no clamping;
-//  * the backward sweep is unrolled by 8 diagonals: ring slots and prefetch registers are compile-time, and a group
-//    of 8 in which no source diagonal lies in another scaling block (6 of 8 groups) carries no scale factors.
+//  * the backward sweep is unrolled by 8 diagonals: ring slots and prefetch registers are compile-time; ring entries
+//    are kept in the scale of the block that reads them, so the products carry no scale factors and the step has one
+//    variant (the kernel is sensitive to its code size: the instruction cache is shared by two CUs).
 // ------------------------------------------------------------------------------------------------------
 #define PAD 64  // padding (bytes) in front of the staged code arrays; 64 more behind
 #ifndef JTK_PHMM_PF
@@ -307,18 +308,41 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
             if (lane < 2) e[64] = v;
             if (lane >= 60) e[-64] = v;
         };
+        // Ring entries are kept in the scale of the block of the step that reads them: a pair enters multiplied by the
+        // exact power of two between its diagonals' blocks and the current one, and when the sweep crosses into the
+        // block below, everything in the ring is re-expressed once.  The products then carry no scale factors (and the
+        // backward step exists in one variant: this kernel is sensitive to its code size).
+        auto rel = [&](int d, int blk) -> double {  // 2^(EF[block of diagonal d] - EF[blk])
+            if (d < 0 || d > T) return 1.0;
+            return fast_pow2(s_EF[d >> 6] - s_EF[blk]);
+        };
         ring_put((T + 2) & 7, make_double2(0.0, 0.0));
-        for (int ss = T + 1; ss >= T - 4; ss--) ring_put(ss & 7, load_pair(ss));
+        for (int ss = T + 1; ss >= T - 4; ss--) {
+            double2 v = load_pair(ss);
+            v.x *= rel(ss - 1, T >> 6);
+            v.y *= rel(ss, T >> 6);
+            ring_put(ss & 7, v);
+        }
         double2 pq[JTK_PHMM_PF];
 #pragma unroll
         for (int q = 0; q < JTK_PHMM_PF; q++) pq[q] = load_pair((T - 5) - (((T - 5) - q) & (JTK_PHMM_PF - 1)));
         int delta_next = 0;  // c[t+1] - c[t]
         const double2 *ring_me = ring + lane + 4;  // source row i+k: entry ring_me[k] of its slot
 
-        // one backward step; SLOT(x) = ring slot of pair P_x; ST: some source diagonal lies in another scaling block
-        auto step = [&](int t, auto slot_of, auto straddle_tag, auto pq_tag) __attribute__((always_inline)) {
+        // one backward step; slot_of(x) = ring slot of pair P_x; U = position inside the group of 8 (t & 7 == 7 - U)
+        auto step = [&](int t, auto slot_of, auto u_tag, auto pq_tag, bool grpA, bool grpB) __attribute__((always_inline)) {
             constexpr int pq_idx = decltype(pq_tag)::value;
-            constexpr bool ST = decltype(straddle_tag)::value;
+            constexpr int U = decltype(u_tag)::value;
+            if (U == 0 && grpA && t < T) {  // t & 63 == 63: the sweep enters the block below
+                const double f = fast_pow2(s_EF[(t + 1) >> 6] - s_EF[t >> 6]);
+#pragma unroll
+                for (int sl = 0; sl < 8; sl++) {
+                    double2 v = ring_me[sl * RW];
+                    v.x *= f;
+                    v.y *= f;
+                    ring_put(sl, v);
+                }
+            }
             if (t < T) c -= delta_next;  // centres: c == c[t+1] on entry
             const int lo = c - r, off = (lane - lo) & 63, i = lo + off, j = t - i;
             const bool active = off <= 2 * r && (unsigned)i <= (unsigned)L && (unsigned)j <= (unsigned)n;
@@ -334,7 +358,14 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
                 }
             }
             // the pair five diagonals below enters the ring now (its slot is not read by this step)
-            ring_put(slot_of(t - 5), pq[pq_idx]);
+            {
+                double2 v = pq[pq_idx];
+                if (U >= 2 && grpB) {  // t & 63 <= 5: its diagonals t-6 / t-5 lie in the block below
+                    v.x *= rel(t - 6, t >> 6);
+                    v.y *= rel(t - 5, t >> 6);
+                }
+                ring_put(slot_of(t - 5), v);
+            }
             pq[pq_idx] = load_pair(t - 5 - JTK_PHMM_PF);
             // (1) backward values of this diagonal
             double vm, vi, vd;
@@ -373,19 +404,14 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
                 for (int k = 0; k < JTK_ACC_N; k++) acc[k] *= sc;
             }
             Gprev = G;
-            // (3) the 16 row-crossing products of this cell.  Pair P_x holds toM of diagonal x-1 and toD of diagonal x;
-            //     a source diagonal in another 64-diagonal block is re-expressed by an exact power of two.
-            auto FS = [&](int tt) -> double {  // 2^(EF[tt]-EF[t])
-                if (tt < 0 || tt > T) return 1.0;
-                return fast_pow2(s_EF[tt >> 6] - EFt);
-            };
+            // (3) the 16 row-crossing products of this cell.  Pair P_x holds toM of diagonal x-1 and toD of diagonal x,
+            //     already in this step's scale.
             auto pair = [&](int x, int k) -> double2 {
-                double2 v = ring_me[slot_of(x) * RW + k];
-                if (ST) {
-                    v.x *= FS(x - 1);
-                    v.y *= FS(x);
-                }
-                return v;
+#ifdef JTK_PHMM_EXPERIMENT_NORING
+                return make_double2(1e-3 * k + hM_1, 0.25 + bD_1);
+#else
+                return ring_me[slot_of(x) * RW + k];
+#endif
             };
             {  // sub (entry i-1): toM(i-1, j-1), toD(i-1, j)
                 const double2 a = pair(t - 1, -1);
@@ -426,18 +452,14 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
         // groups of 8 diagonals, tb == 7 (mod 8): slots and queue registers are compile-time inside a group
         for (int tb = T | 7; tb >= 7; tb -= 8) {
             const int g = tb & 63;
-            // steps whose source window t-5 .. t+2 straddles a block boundary: t & 63 in {62, 63, 0, .., 4}
-            const bool grpA = g == 63, grpB = g == 7;
+            const bool grpA = g == 63, grpB = g == 7;  // the groups that touch a scaling-block boundary
 #define GROUP_STEP(u)                                                                                     \
     {                                                                                                     \
         const int t = tb - (u);                                                                           \
         if (t <= T) {                                                                                     \
             auto slot_of = [&](int x) -> int { return (x - t + (7 - (u)) + 64) & 7; }; /* == x & 7 */     \
-            const bool st_u = ((u) <= 1 && grpA) || ((u) >= 3 && grpB);                                    \
-            if (((u) <= 1 || (u) >= 3) && st_u)                                                           \
-                step(t, slot_of, std::true_type{}, std::integral_constant<int, (2 - (u)) & (JTK_PHMM_PF - 1)>{});         \
-            else                                                                                          \
-                step(t, slot_of, std::false_type{}, std::integral_constant<int, (2 - (u)) & (JTK_PHMM_PF - 1)>{});        \
+            step(t, slot_of, std::integral_constant<int, (u)>{},                                          \
+                 std::integral_constant<int, (2 - (u)) & (JTK_PHMM_PF - 1)>{}, grpA, grpB);               \
         }                                                                                                 \
     }
             GROUP_STEP(0)
