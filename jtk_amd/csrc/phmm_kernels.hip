@@ -123,16 +123,17 @@ __global__ void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const 
 //    ONE such pair, so a step does 7 ds_read_b128 instead of 16 ds_read_b64;
 //  * template / read codes are staged pre-multiplied into byte offsets of the emission tables and padded on both
 //    sides, so the lookups need no clamping;
-//  * the backward sweep is unrolled by 8 diagonals: ring slots and prefetch registers are compile-time; ring entries
+//  * the backward sweep is unrolled by 4 diagonals: prefetch registers and ring slots (up to one swapped base) are
+//    compile-time; ring entries
 //    are kept in the scale of the block that reads them, so the products carry no scale factors and the step has one
 //    variant (the kernel is sensitive to its code size: the instruction cache is shared by two CUs).
 // ------------------------------------------------------------------------------------------------------
 #define PAD 64  // padding (bytes) in front of the staged code arrays; 64 more behind
 #ifndef JTK_PHMM_PF
-#define JTK_PHMM_PF 4  // pairs in flight from HBM per wave during the backward sweep (4 or 8)
+#define JTK_PHMM_PF 4  // pairs in flight from HBM per wave during the backward sweep (the unrolling assumes 4)
 #endif
 #ifndef JTK_PHMM_WAVES
-#define JTK_PHMM_WAVES 2  // resident waves per SIMD the register budget is set for (3 spills inside the backward loop)
+#define JTK_PHMM_WAVES 3  // resident waves per SIMD the register budget is set for
 #endif
 #define RW 72   // entries per ring slot: 64 lanes + 4 wrapped copies in front + 2 behind (rounded up)
 
@@ -302,12 +303,12 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
 #endif
         };
         // ring: P_{T+2} (nothing) .. P_{T-4}; queue: pq[s & (PF-1)] = P_s for the next PF below
-        auto ring_put = [&](int slot, double2 v) __attribute__((always_inline)) {
-            double2 *e = ring + slot * RW + lane + 4;
+        auto ring_put_at = [&](double2 *e, double2 v) __attribute__((always_inline)) {  // e: the lane's entry of a slot
             e[0] = v;
             if (lane < 2) e[64] = v;
             if (lane >= 60) e[-64] = v;
         };
+        auto ring_put = [&](int slot, double2 v) __attribute__((always_inline)) { ring_put_at(ring + slot * RW + lane + 4, v); };
         // Ring entries are kept in the scale of the block of the step that reads them: a pair enters multiplied by the
         // exact power of two between its diagonals' blocks and the current one, and when the sweep crosses into the
         // block below, everything in the ring is re-expressed once.  The products then carry no scale factors (and the
@@ -329,11 +330,19 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
         int delta_next = 0;  // c[t+1] - c[t]
         const double2 *ring_me = ring + lane + 4;  // source row i+k: entry ring_me[k] of its slot
 
-        // one backward step; slot_of(x) = ring slot of pair P_x; U = position inside the group of 8 (t & 7 == 7 - U)
-        auto step = [&](int t, auto slot_of, auto u_tag, auto pq_tag, bool grpA, bool grpB) __attribute__((always_inline)) {
+        // One backward step.  The sweep is unrolled by 4 (t & 3 == 3 - U inside a group), which makes the queue
+        // register and the low two bits of every ring slot compile-time; bit 2 of a slot follows bit 2 of its
+        // diagonal, i.e. (t >> 2) & 1 plus a compile-time carry: half[0] / half[1] are the lane's entries in the
+        // slot halves {0..3} / {4..7} for even / odd carry and swap from group to group.
+        double2 *half[2] = {ring + lane + 4, ring + lane + 4 + 4 * RW};
+        auto step = [&](int t, auto u_tag, auto pq_tag) __attribute__((always_inline)) {
             constexpr int pq_idx = decltype(pq_tag)::value;
             constexpr int U = decltype(u_tag)::value;
-            if (U == 0 && grpA && t < T) {  // t & 63 == 63: the sweep enters the block below
+            auto entry = [&](int dx) -> double2 * {  // the lane's entry of the slot of pair P_{t+dx}; dx is a literal
+                const int lo2 = (3 - U) + dx;         // (t & 3) + dx
+                return half[(lo2 >> 2) & 1] + (lo2 & 3) * RW;
+            };
+            if (U == 0 && (t & 63) == 63 && t < T) {  // the sweep enters the block below
                 const double f = fast_pow2(s_EF[(t + 1) >> 6] - s_EF[t >> 6]);
 #pragma unroll
                 for (int sl = 0; sl < 8; sl++) {
@@ -360,11 +369,11 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
             // the pair five diagonals below enters the ring now (its slot is not read by this step)
             {
                 double2 v = pq[pq_idx];
-                if (U >= 2 && grpB) {  // t & 63 <= 5: its diagonals t-6 / t-5 lie in the block below
+                if ((t & 63) <= 5) {  // its diagonals t-6 / t-5 lie in the block below
                     v.x *= rel(t - 6, t >> 6);
                     v.y *= rel(t - 5, t >> 6);
                 }
-                ring_put(slot_of(t - 5), v);
+                ring_put_at(entry(-5), v);
             }
             pq[pq_idx] = load_pair(t - 5 - JTK_PHMM_PF);
             // (1) backward values of this diagonal
@@ -406,21 +415,21 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
             Gprev = G;
             // (3) the 16 row-crossing products of this cell.  Pair P_x holds toM of diagonal x-1 and toD of diagonal x,
             //     already in this step's scale.
-            auto pair = [&](int x, int k) -> double2 {
+            auto pair = [&](int x, int k) -> double2 {  // x: diagonal offset from t (a literal after unrolling)
 #ifdef JTK_PHMM_EXPERIMENT_NORING
                 return make_double2(1e-3 * k + hM_1, 0.25 + bD_1);
 #else
-                return ring_me[slot_of(x) * RW + k];
+                return entry(x)[k];
 #endif
             };
             {  // sub (entry i-1): toM(i-1, j-1), toD(i-1, j)
-                const double2 a = pair(t - 1, -1);
+                const double2 a = pair(-1, -1);
 #pragma unroll
                 for (int q = 0; q < 4; q++) acc[q] = fma(y8 == 8 * q ? a.x : 0.0, vm, acc[q]);
                 acc[4] = fma(a.y, vd, acc[4]);
             }
             {  // ins (entry i): toM(i, j-1), toD(i, j);   copy 1 (entry i-1): the same pair against hatM
-                const double2 a = pair(t, 0);
+                const double2 a = pair(0, 0);
 #pragma unroll
                 for (int q = 0; q < 4; q++) acc[5 + q] = fma(y8 == 8 * q ? a.x : 0.0, vm, acc[5 + q]);
                 acc[9] = fma(a.y, vd, acc[9]);
@@ -428,12 +437,12 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
             }
 #pragma unroll
             for (int cc = 2; cc <= 3; cc++) {  // copy c (entry i-1): toM(i-1+c, j-1), toD(i-1+c, j)
-                const double2 a = pair(t + cc - 1, cc - 1);
+                const double2 a = pair(cc - 1, cc - 1);
                 acc[10 + cc - 1] = fma(a.y, vd, fma(a.x, hM, acc[10 + cc - 1]));
             }
 #pragma unroll
             for (int dd = 1; dd <= 3; dd++) {  // del d (entry i-d-1): toM(i-d-1, j-1), toD(i-d-1, j)
-                double2 a = pair(t - dd - 1, -dd - 1);
+                double2 a = pair(-dd - 1, -dd - 1);
                 if (dd == 3) {  // the only source row the 3 spare lanes cannot disambiguate
                     if (!(i - 4 >= c5 - r)) a.x = 0.0;
                     if (!(i - 4 >= c4 - r)) a.y = 0.0;
@@ -449,27 +458,23 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
             c4 = c5;
             if (t - 5 >= 1) c5 -= delta_bit(s_delta, t - 5);
         };
-        // groups of 8 diagonals, tb == 7 (mod 8): slots and queue registers are compile-time inside a group
-        for (int tb = T | 7; tb >= 7; tb -= 8) {
-            const int g = tb & 63;
-            const bool grpA = g == 63, grpB = g == 7;  // the groups that touch a scaling-block boundary
-#define GROUP_STEP(u)                                                                                     \
-    {                                                                                                     \
-        const int t = tb - (u);                                                                           \
-        if (t <= T) {                                                                                     \
-            auto slot_of = [&](int x) -> int { return (x - t + (7 - (u)) + 64) & 7; }; /* == x & 7 */     \
-            step(t, slot_of, std::integral_constant<int, (u)>{},                                          \
-                 std::integral_constant<int, (2 - (u)) & (JTK_PHMM_PF - 1)>{}, grpA, grpB);               \
-        }                                                                                                 \
+        // groups of 4 diagonals, tb == 3 (mod 4)
+        for (int tb = T | 3; tb >= 3; tb -= 4) {
+            {
+                double2 *lo_half = ring + lane + 4, *hi_half = lo_half + 4 * RW;
+                const bool hi = (tb >> 2) & 1;
+                half[0] = hi ? hi_half : lo_half;
+                half[1] = hi ? lo_half : hi_half;
+            }
+#define GROUP_STEP(u)                                                                                      \
+    {                                                                                                      \
+        const int t = tb - (u);                                                                            \
+        if (t <= T) step(t, std::integral_constant<int, (u)>{}, std::integral_constant<int, (2 - (u)) & 3>{}); \
     }
             GROUP_STEP(0)
             GROUP_STEP(1)
             GROUP_STEP(2)
             GROUP_STEP(3)
-            GROUP_STEP(4)
-            GROUP_STEP(5)
-            GROUP_STEP(6)
-            GROUP_STEP(7)
 #undef GROUP_STEP
         }
         // rows still in the band after t == 0

@@ -334,7 +334,10 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         // resident waves of phmm_kernel: 3 per SIMD by registers, 11 per CU by its ~14 KB of LDS
-        uint32_t per_cu = 8;  // resident waves per CU: 2 per SIMD (register budget of phmm_kernel, JTK_PHMM_WAVES)
+        // resident waves per CU: 3 per SIMD by registers (JTK_PHMM_WAVES), and what 160 KiB of LDS hold
+        uint32_t per_cu = (uint32_t)((160u * 1024u) / phmm_lds_bytes(s->max_tmpl, s->max_read));
+        if (per_cu > 12) per_cu = 12;
+        if (per_cu < 1) per_cu = 1;
         if (const char *e = getenv("JTK_PHMM_WAVES_PER_CU")) per_cu = (uint32_t)atoi(e);  // tuning experiments only
         const uint32_t want = (uint32_t)prop.multiProcessorCount * per_cu;
         s->n_waves = n_reads < want ? (uint32_t)n_reads : want;
