@@ -621,6 +621,23 @@ __device__ __attribute__((noinline)) bool bernoulli_exact(uint64_t v, double dif
     return v < uni64(__double2ull_rz(scaled));
 }
 
+// Neighbour-lane reads that stay off the LDS crossbar (a ds_bpermute round trip costs a lone wave ~100 cycles).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_next_lane(double v) { return dpp_f64<0x134>(v); }  // lane l <- lane l+1 (wave_rol:1)
+__device__ __forceinline__ double from_prev_lane(double v) { return dpp_f64<0x13C>(v); }  // lane l <- lane l-1 (wave_ror:1)
+__device__ __forceinline__ double wave_sum_f64(double v) {  // order-free: for estimates only
+    v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);  // row_half_mirror
+    v += dpp_f64<0x140>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
 // mcmc_with_filter (:704-762), generic in K.  m.assign holds the k-means labels on entry, the best-seen labels
 // on exit.  One proposal per iteration; used for K > 2 and for pile-ups the batched diploid path does not take.
 template <int K, bool SMALL>
@@ -704,6 +721,28 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
         }
         return S;
     };
+    // The same quantity without the ordering (any order of the same terms: off by ~1e-12 at most).  The ordered sum
+    // costs a v_readlane + a dependent add per term; this costs one cross-lane reduction, and it is enough to see
+    // that a proposal is certainly rejected -- which > 96% of them are.
+    auto approx_lk = [&](const double *T, const int *P, const int *cls, const unsigned long long *pm,
+                         const unsigned long long *im) -> double {
+        double S = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; c++) S += tab_get<SMALL>(size_to_lk, (uint32_t)cls[c]);
+        int in_use = 0;
+        unsigned long long anym = 0;
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            in_use += (0.0 < T[c]) ? P[c] : 0;
+            anym |= pm[c] & im[c];
+        }
+        const unsigned long long usedm = __ballot(3 * in_use > 2 * totp) & anym;
+        const bool used = (usedm >> lane) & 1ull;
+        double loc = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; c++) loc += (used && 0.0 < T[c]) ? T[c] : 0.0;
+        return S + wave_sum_f64(loc);
+    };
     double lk = get_lk(tg, np, cl, posm, infm);
     double max = lk;
     const uint32_t total = 2000u * n;
@@ -744,12 +783,25 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
                 nim[c] = __ballot(W[c] > 0);
             }
         }
-        const double proposed = get_lk(T, P, ncl, npm, nim);
-        const double diff = unif64(proposed - lk);
-        // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
-        // exactly when diff >= -2^-54
-        bool accept = true;
-        if (!ubool(diff >= -0x1p-54)) accept = bernoulli_exact(next_u64(rng), diff);
+        // estimate first: if proposed - lk is below -1e-3 the step certainly draws, and the draw usually settles it
+        double proposed = 0.0;
+        bool accept = false, decided = false, have_v = false;
+        uint64_t v = 0;
+        const double dA = unif64(approx_lk(T, P, ncl, npm, nim) - lk);
+        if (ubool(dA < -1e-3)) {
+            v = next_u64(rng);
+            have_v = true;
+            const float u = (float)(uint32_t)(v >> 40) * 0x1p-24f;  // v / 2^64 within 2^-24
+            decided = ubool(dA <= -44.5 || u > __expf((float)dA) * 1.001f + 3e-7f);  // certainly rejected
+        }
+        if (!decided) {
+            proposed = get_lk(T, P, ncl, npm, nim);
+            const double diff = unif64(proposed - lk);
+            // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
+            // exactly when diff >= -2^-54 (never the case when the estimate was below -1e-3)
+            accept = true;
+            if (!ubool(diff >= -0x1p-54)) accept = bernoulli_exact(have_v ? v : next_u64(rng), diff);
+        }
         if (accept) {
 #pragma unroll
             for (int c = 0; c < K; c++) {
@@ -882,16 +934,6 @@ __device__ __forceinline__ void scalar_proposal(Rng &rng, uint32_t start, uint32
 #define ST_ADD(k)
 #define ST_CNT(k, v)
 #endif
-
-// Neighbour-lane reads that stay off the LDS crossbar (a ds_bpermute round trip costs a lone wave ~100 cycles).
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double from_next_lane(double v) { return dpp_f64<0x134>(v); }  // lane l <- lane l+1 (wave_rol:1)
-__device__ __forceinline__ double from_prev_lane(double v) { return dpp_f64<0x13C>(v); }  // lane l <- lane l-1 (wave_ror:1)
 
 // REPL: the state is replicated in every lane (wave-uniform values in vector registers; neither the exact step nor
 // the table rebuild needs a cross-lane operation) -- used up to 4 columns.  Otherwise lane d holds column d and
