@@ -64,6 +64,8 @@ struct Rng {
     uint32_t pos;      // next draw to take (absolute stream position)
     uint32_t wr_seen;  // producer progress last observed
     uint32_t wp_seen;  // record progress last observed
+    uint32_t win_base; // stream position of the draw held by lane 0 of `win`
+    uint64_t win;      // per lane: the raw draw at win_base + lane (one LDS read serves 64 sequential draws)
 #ifdef JTK_MCMC_STATS
     uint32_t waits;    // polls of the producer's counters that found nothing new
 #endif
@@ -98,10 +100,17 @@ __device__ __forceinline__ void rng_release(Rng &r, uint32_t lane) {  // draws b
     if (lane == 0) lds_st32(&r.ctl->rd, r.pos);
 }
 __device__ __forceinline__ uint64_t next_u64(Rng &r) {
-    rng_wait(r, r.pos + 1);
-    const uint64_t v = uni64(lds_ld64(&r.ring[ring_slot(r.pos)]));
+    if ((uint32_t)(r.pos - r.win_base) >= 64u) {  // refill: 64 draws from r.pos on, one per lane
+        r.win_base = r.pos;
+        lds_st32(&r.ctl->rd, r.pos);  // every lane stores the same value: draws before r.pos may be overwritten
+        rng_wait(r, r.pos + 64);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        r.win = lds_ld64(&r.ring[ring_slot(r.pos + (threadIdx.x & 63u))]);
+    }
+    const uint32_t off = r.pos - r.win_base;
+    const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(r.win >> 32), (int)off) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)r.win, (int)off);
     r.pos++;
-    if ((r.pos & 63) == 0) lds_st32(&r.ctl->rd, r.pos);  // every lane stores the same value
     return v;
 }
 __device__ __forceinline__ uint32_t next_u32(Rng &r) { return (uint32_t)(next_u64(r) >> 32); }
@@ -1548,6 +1557,8 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
     rng.pos = 0;
     rng.wr_seen = 0;
     rng.wp_seen = 0;
+    rng.win_base = 0xffffff00u;  // nothing held yet
+    rng.win = 0;
 #ifdef JTK_MCMC_STATS
     rng.waits = 0;
 #endif
