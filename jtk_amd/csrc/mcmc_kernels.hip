@@ -507,7 +507,7 @@ __device__ __forceinline__ void xo_jump(Xo &x, const ulonglong2 *tab) {
 // whose widening multiply is accepted, gen_index(1) (the single candidate of K == 2, pseudo_mcmc.rs:732) then takes
 // draws until one has a clear top bit, and the next draw is the one a Bernoulli test would compare.  None of this
 // depends on the chain, so the producer parses the proposal that WOULD start at every stream position q:
-//   rec[q] = idx | len << 6 | (top 20 bits of the Bernoulli draw) << 12      (len = draws used incl. that draw)
+//   rec[q] = idx | len << 7 | (top 19 bits of the Bernoulli draw) << 13      (idx < 128; len = draws used incl. that draw)
 // rec == 0: not parsed (needs more than the 16..63 draws of look-ahead; the consumer then steps with scalar draws).
 // 64 positions are parsed at once -- acceptance masks by ballot, "next accepted draw at or after p" by s_ff1 -- and
 // the first PKEEP are kept, so every kept start had at least 64 - PKEEP draws of look-ahead (a proposal needs more
@@ -540,7 +540,7 @@ __device__ __forceinline__ void producer_parse(const uint64_t *ring, uint32_t *r
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const uint32_t v = ok[r] ? (idx[r] | ((pv[r] + 1 - lane) << 6) | (vhi[r] & 0xfffff000u)) : 0u;
+        const uint32_t v = ok[r] ? (idx[r] | ((pv[r] + 1 - lane) << 7) | (vhi[r] & 0xffffe000u)) : 0u;
         if (lane < PKEEP) lds_st32(&rec[(base + r * PKEEP + lane) & (RN - 1)], v);
     }
 }
@@ -847,7 +847,7 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// The diploid chain (K == 2, n <= 63, D <= 8) as a table-driven walk.
+// The diploid chain (K == 2, n <= 127, D <= 8) as a table-driven walk.
 //
 // More than 96% of the proposals are rejected, and in a given state the fate of "flip read i" is the same every
 // time it is proposed: proposed - lk depends on the state only.  So the chain keeps, per read (one lane each), a
@@ -872,7 +872,7 @@ struct Window {
     uint32_t base;
     uint32_t nxt;  // per lane: window offset of the following proposal (Bernoulli draw taken), 255 = not in this window
     uint32_t idx;  // per lane: the read index the proposal starting here picks
-    float u;       // per lane: the draw its Bernoulli test compares, / 2^64, truncated to 20 bits
+    float u;       // per lane: the draw its Bernoulli test compares, / 2^64, truncated to 19 bits
 };
 __device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t base, uint32_t lane) {
     rng.pos = base;
@@ -881,19 +881,24 @@ __device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t base,
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     wd.base = base;
     const uint32_t r = lds_ld32(&rng.rec[(base + lane) & (RN - 1)]);
-    const uint32_t len = (r >> 6) & 63u;
-    wd.idx = r & 63u;
+    const uint32_t len = (r >> 7) & 63u;
+    wd.idx = r & 127u;
     wd.nxt = (len != 0 && lane + len < 64) ? lane + len : 255u;
-    wd.u = (float)(r >> 12) * 0x1p-20f;
+    wd.u = (float)(r >> 13) * 0x1p-19f;
 }
 // per window position l: nxt[l] in bits 0..5 and, in bit 6, "the proposal starting at l lies inside the window and
-// is certainly rejected" -- one v_readlane per hop yields both.  thr_tab: lane i = rejection threshold of read i.
-__device__ __forceinline__ uint32_t hop_words(const Window &wd, float thr_tab) {
-    const float thr = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(wd.idx << 2), __float_as_int(thr_tab)));
+// is certainly rejected" -- one v_readlane per hop yields both.  thr_tab[r]: lane i = rejection threshold of read 64 r + i.
+template <int NR>
+__device__ __forceinline__ uint32_t hop_words(const Window &wd, const float *thr_tab) {
+    float thr = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((wd.idx & 63u) << 2), __float_as_int(thr_tab[0])));
+    if (NR == 2) {
+        const float hi = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((wd.idx & 63u) << 2), __float_as_int(thr_tab[NR - 1])));
+        thr = wd.idx >= 64u ? hi : thr;
+    }
     return (wd.nxt & 63u) | ((wd.nxt != 255u && wd.u > thr) ? 64u : 0u);
 }
 // The rejection threshold from the order-free estimate dA of proposed - lk.  u is the Bernoulli draw truncated to
-// 20 bits (so the true uniform is < u + 2^-20); exp in f32 is good to ~1e-5 relative: 1.001 and 1.3e-6 cover both.
+// 19 bits (so the true uniform is < u + 2^-19); exp in f32 is good to ~1e-5 relative: 1.001 and 1.3e-6 cover both.
 __device__ __forceinline__ float reject_threshold(double dA, bool pert) {
     float thr = 2.0f;  // cannot tell: the proposal becomes an event
     if (!pert && dA < -1e-3) thr = dA <= -44.5 ? -1.0f : __expf((float)dA) * 1.001f + 1.3e-6f;
@@ -955,13 +960,20 @@ struct K2Mem {
     uint8_t *assign;
     unsigned long long *k2_stats;
 };
-template <int DMAX, bool REPL>
+// NR: registers per per-read / per-size table: 1 serves n <= 63, 2 serves n <= 127 (read or size 64 r + lane)
+template <int DMAX, bool REPL, int NR>
 __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, uint32_t D, double cov, Rng *rng_io,
                                                           uint32_t lane) {
     Rng rng = *rng_io;
     constexpr int NS = REPL ? DMAX : 1;  // state registers per lane
     // pair table: lane c0 holds (0.0 + size_to_lk[c0]) + size_to_lk[n - c0]   (get_lk :788)
-    double pair_v;
+    double pair_v[NR];
+    auto tab64 = [&](const double *tab, uint32_t i) -> double {  // entry i of a per-lane table of NR registers
+        return NR == 2 && i >= 64 ? readlane_f64(tab[NR - 1], i & 63u) : readlane_f64(tab[0], i & 63u);
+    };
+    auto bit128 = [&](const unsigned long long *mk, uint32_t i) -> bool {
+        return ((NR == 2 && i >= 64 ? mk[NR - 1] : mk[0]) >> (i & 63u)) & 1ull;
+    };
     {
         auto size_lk = [&](uint32_t x) {
             double mx = -__builtin_inf();
@@ -971,8 +983,11 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
             }
             return mx;
         };
-        const uint32_t c0 = lane <= n ? lane : n;
-        pair_v = (0.0 + size_lk(c0)) + size_lk(n - c0);
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const uint32_t c = lane + 64 * r, cc = c <= n ? c : n;
+            pair_v[r] = (0.0 + size_lk(cc)) + size_lk(n - cc);
+        }
     }
     // ---- exact state LKCount[c][d]; columns >= D are all-zero, never used and add +0.0.  The two counters travel
     //      packed: pk = num_pos + 65536 * (3*num_pos - 7*num_neg), so pk > 0xffff <=> the second one is positive.
@@ -984,7 +999,9 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
         pk0[d] = pk1[d] = tp2[d] = 0;
     }
     uint32_t c0 = 0;
-    unsigned long long lab = 0;
+    unsigned long long lab[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) lab[r] = 0;
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t c = uni(m.assign[i]);
 #pragma unroll
@@ -1003,33 +1020,34 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
         }
         if (c == 0)
             c0++;
+        else if (NR == 2 && i >= 64)
+            lab[NR - 1] |= 1ull << (i & 63u);
         else
-            lab |= 1ull << i;
+            lab[0] |= 1ull << (i & 63u);
     }
-    // ---- read `lane`'s row, signed by the direction of its flip: sx[d] is what cluster 0 would gain
-    const uint32_t ri = lane < n ? lane : 0;
-    double sx[DMAX];
-    int spk[DMAX];
-    {
-        const bool a = (lab >> ri) & 1ull;
+    // ---- the rows of reads lane, 64 + lane, signed by the direction of their flip: sx[r][d] is what cluster 0 would gain
+    uint32_t ri[NR];
+    double sx[NR][DMAX];
+    int spk[NR][DMAX];
+    unsigned long long nullm[NR];  // reads whose row is 0.0 in every column: flipping one moves nothing but the sizes
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        ri[r] = lane + 64 * r < n ? lane + 64 * r : 0;
+        const bool a = bit128(lab, ri[r]);
+        bool nzr = false;
 #pragma unroll
         for (int d = 0; d < DMAX; d++) {
             Elem el = {0.0, 0, 0};
-            if ((uint32_t)d < D) el = m.elem[ri * D + d];
-            sx[d] = a ? el.x : -el.x;
-            spk[d] = a ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
+            if ((uint32_t)d < D) el = m.elem[ri[r] * D + d];
+            sx[r][d] = a ? el.x : -el.x;
+            spk[r][d] = a ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
+            nzr = nzr || sx[r][d] != 0.0 || spk[r][d] != 0;
         }
-    }
-    // reads whose row is 0.0 in every column: flipping one moves nothing but the cluster sizes
-    unsigned long long nullm;
-    {
-        bool nzr = false;
-#pragma unroll
-        for (int d = 0; d < DMAX; d++) nzr = nzr || sx[d] != 0.0 || spk[d] != 0;
-        nullm = ~__ballot(nzr) & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+        const uint32_t live = n > 64u * r ? n - 64u * r : 0u;  // reads held by register r
+        nullm[r] = ~__ballot(nzr) & (live >= 64 ? ~0ull : ((1ull << live) - 1ull));
     }
     wsync();
-    auto pair_at = [&](uint32_t c) -> double { return readlane_f64(pair_v, c <= n ? c : n); };
+    auto pair_at = [&](uint32_t c) -> double { return tab64(pair_v, c <= n ? c : n); };
     // the per-column terms of get_lk (:785-795) for a (tentative) state
     auto column_terms = [&](const double *T0, const double *T1, const int *K0, const int *K1, double *t0, double *t1) {
 #pragma unroll
@@ -1064,75 +1082,78 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
     double pair_up = pair_at(c0 + 1), pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
     // ---- the table: for "flip read `lane`" in the current state, the order-free sum of its column terms and
     //      whether flip + flip-back would leave a rounding residue; thresholds follow from those and the size terms
-    double sum_l = 0.0;
-    bool pert_l = false;
+    double sum_l[NR];
+    bool pert_l[NR];
     auto rebuild_sums = [&]() {
-        double sum = 0.0;
-        bool pert = false;
 #pragma unroll
-        for (int d = 0; d < DMAX; d++) {
-            const double s0 = REPL ? tg0[REPL ? d : 0] : readlane_f64(tg0[0], d);
-            const double s1 = REPL ? tg1[REPL ? d : 0] : readlane_f64(tg1[0], d);
-            const int k0 = REPL ? pk0[REPL ? d : 0] : __builtin_amdgcn_readlane(pk0[0], d);
-            const int k1 = REPL ? pk1[REPL ? d : 0] : __builtin_amdgcn_readlane(pk1[0], d);
-            const int tp = REPL ? tp2[REPL ? d : 0] : __builtin_amdgcn_readlane(tp2[0], d);
-            const double T0 = s0 + sx[d], T1 = s1 - sx[d];  // s - x == s + (-x) bit for bit
-            const int K0 = k0 + spk[d], K1 = k1 - spk[d];
-            const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
-            const int in_use = ((pos0 ? K0 : 0) + (pos1 ? K1 : 0)) & 0xffff;
-            const bool any = (pos0 && K0 > 0xffff) || (pos1 && K1 > 0xffff);
-            const bool used = any && 3 * in_use > tp;
-            sum += ((used && pos0) ? T0 : 0.0) + ((used && pos1) ? T1 : 0.0);
-            pert = pert || (T0 - sx[d] != s0) || (T1 + sx[d] != s1);  // flip back (:746) would not restore the sum
+        for (int r = 0; r < NR; r++) {
+            double sum = 0.0;
+            bool pert = false;
+#pragma unroll
+            for (int d = 0; d < DMAX; d++) {
+                const double s0 = REPL ? tg0[REPL ? d : 0] : readlane_f64(tg0[0], d);
+                const double s1 = REPL ? tg1[REPL ? d : 0] : readlane_f64(tg1[0], d);
+                const int k0 = REPL ? pk0[REPL ? d : 0] : __builtin_amdgcn_readlane(pk0[0], d);
+                const int k1 = REPL ? pk1[REPL ? d : 0] : __builtin_amdgcn_readlane(pk1[0], d);
+                const int tp = REPL ? tp2[REPL ? d : 0] : __builtin_amdgcn_readlane(tp2[0], d);
+                const double T0 = s0 + sx[r][d], T1 = s1 - sx[r][d];  // s - x == s + (-x) bit for bit
+                const int K0 = k0 + spk[r][d], K1 = k1 - spk[r][d];
+                const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
+                const int in_use = ((pos0 ? K0 : 0) + (pos1 ? K1 : 0)) & 0xffff;
+                const bool any = (pos0 && K0 > 0xffff) || (pos1 && K1 > 0xffff);
+                const bool used = any && 3 * in_use > tp;
+                sum += ((used && pos0) ? T0 : 0.0) + ((used && pos1) ? T1 : 0.0);
+                pert = pert || (T0 - sx[r][d] != s0) || (T1 + sx[r][d] != s1);  // flip back (:746) would not restore the sum
+            }
+            sum_l[r] = sum;
+            pert_l[r] = pert;
         }
-        sum_l = sum;
-        pert_l = pert;
     };
-    auto thresholds = [&]() -> float {
-        const bool a = (lab >> ri) & 1ull;
-        return reject_threshold(((a ? pair_up : pair_dn) + sum_l) - lk, pert_l);
+    float thr_tab[NR];
+    auto thresholds = [&]() {
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const bool a = bit128(lab, ri[r]);
+            thr_tab[r] = reject_threshold(((a ? pair_up : pair_dn) + sum_l[r]) - lk, pert_l[r]);
+        }
     };
     // ---- size-only moves (a read with an all-zero row): with the column sums fixed, get_lk is a function of the
     //      cluster-0 size alone.  Lane c holds G[c] = get_lk at size c (the same left-to-right sum), and for the
-    //      moves c -> c+1 / c -> c-1 an f32 estimate of exp(diff) that decides gen_bool from the 20 known bits of the
-    //      draw whenever those suffice; ndm_*: moves that draw nothing (diff >= -2^-54).  Built on demand, stale once
-    //      a column sum moves.
-    double Gtab = 0.0;
-    float pf_up = 0.0f, pf_dn = 0.0f;
-    unsigned long long ndm_up = 0, ndm_dn = 0;
+    //      move to size c' the new likelihood is G[c'] exactly.  Built on demand, stale once a column sum moves.
+    double Gtab[NR];
     bool gtab_ok = false;
     auto build_gtab = [&]() {
         double t0[NS], t1[NS];
         column_terms(tg0, tg1, pk0, pk1, t0, t1);
-        double G = pair_v;
-        if (REPL) {
 #pragma unroll
-            for (int d = 0; d < DMAX; d++) G += t0[d];
+        for (int r = 0; r < NR; r++) {
+            double G = pair_v[r];
+            if (REPL) {
 #pragma unroll
-            for (int d = 0; d < DMAX; d++) G += t1[d];
-        } else {
+                for (int d = 0; d < DMAX; d++) G += t0[d];
 #pragma unroll
-            for (int q = 0; q < DMAX; q++) G += readlane_f64(t0[0], q);
+                for (int d = 0; d < DMAX; d++) G += t1[d];
+            } else {
 #pragma unroll
-            for (int q = 0; q < DMAX; q++) G += readlane_f64(t1[0], q);
+                for (int q = 0; q < DMAX; q++) G += readlane_f64(t0[0], q);
+#pragma unroll
+                for (int q = 0; q < DMAX; q++) G += readlane_f64(t1[0], q);
+            }
+            Gtab[r] = G;
         }
-        Gtab = G;
-        const double du = from_next_lane(G) - G, dd = from_prev_lane(G) - G;
-        pf_up = __expf((float)du);
-        pf_dn = __expf((float)dd);
-        ndm_up = __ballot(du >= -0x1p-54);
-        ndm_dn = __ballot(dd >= -0x1p-54);
         gtab_ok = true;
     };
     double max = lk;
-    unsigned long long argmax = lab;
+    unsigned long long argmax[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) argmax[r] = lab[r];
     rebuild_sums();
-    float thr_tab = thresholds();
+    thresholds();
     const uint32_t total = 2000u * n;
     uint32_t t = 0, p = 0;
     Window wd;
     window_load(wd, rng, rng.pos, lane);
-    uint32_t hopw = hop_words(wd, thr_tab);
+    uint32_t hopw = hop_words<NR>(wd, thr_tab);
     ST_T0();
     while (t < total) {
         t += walk_rejected(hopw, p, total - t);
@@ -1147,47 +1168,56 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
         } else if (p != 0) {  // move the window there
             window_load(wd, rng, wd.base + p, lane);
             p = 0;
-            hopw = hop_words(wd, thr_tab);
+            hopw = hop_words<NR>(wd, thr_tab);
             ST_CNT(6, 1);
             continue;
         } else {  // not even at the window start: the producer could not parse this one
             scalar_proposal(rng, wd.base, n, e_idx, pos_v);
             reload = true;
         }
-        const bool old = (lab >> e_idx) & 1ull;
-        if ((nullm >> e_idx) & 1ull) {
+        const bool old = bit128(lab, e_idx);
+        auto flip_label = [&]() {
+            if (NR == 2 && e_idx >= 64)
+                lab[NR - 1] ^= 1ull << (e_idx & 63u);
+            else
+                lab[0] ^= 1ull << (e_idx & 63u);
+        };
+        auto new_max = [&](double v) {
+            max = v;
+#pragma unroll
+            for (int r = 0; r < NR; r++) argmax[r] = lab[r];
+        };
+        if (bit128(nullm, e_idx)) {
             // ---- a size-only move: the decision and the new likelihood come from the size tables
 #ifdef JTK_MCMC_STATS
             const unsigned long long n0c = __builtin_readcyclecounter();
 #endif
             if (!gtab_ok) build_gtab();
-            const bool nd = ((old ? ndm_up : ndm_dn) >> c0) & 1ull;
+            // proposed - lk with the lk the chain carries (flip-back residues move the sums, not lk: :746), so this
+            // is NOT a difference of two table entries
+            const double diff = tab64(Gtab, old ? c0 + 1 : c0 - 1) - lk;
+            const bool nd = ubool(diff >= -0x1p-54);  // gen_bool(1.0) draws nothing
             bool acc = true;
             if (!nd) {
-                // u: the Bernoulli draw / 2^64 truncated to 20 bits (true value < u + 2^-20); pe within ~1e-5 relative
-                const float pe = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(old ? pf_up : pf_dn), (int)c0));
+                // u: the Bernoulli draw / 2^64 truncated to 19 bits (true value < u + 2^-19); pe within ~1e-5 relative
+                const float pe = __expf((float)diff);
                 const float u = reload ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd.u), (int)p));
-                if (u >= 0.0f && u > pe * 1.001f + 1.3e-6f) {
+                const bool in_range = u >= 0.0f && diff < -1e-3 && diff > -44.4;
+                if (ubool(diff <= -44.4 || (in_range && u > pe * 1.001f + 1.3e-6f))) {
                     acc = false;
-                } else if (u >= 0.0f && u + 0x1p-20f < pe * 0.999f - 3e-7f) {
-                    acc = true;
-                } else {
-                    const double diff = readlane_f64(Gtab, old ? c0 + 1 : c0 - 1) - lk;
+                } else if (!ubool(in_range && u + 0x1p-19f < pe * 0.999f - 3e-7f)) {
                     rng_wait(rng, pos_v + 1);
                     acc = bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff);
                 }
             }
             if (acc) {
                 c0 = old ? c0 + 1 : c0 - 1;
-                lab ^= 1ull << e_idx;
-                lk = readlane_f64(Gtab, c0);
+                flip_label();
+                lk = tab64(Gtab, c0);
                 pair_up = pair_at(c0 + 1);
                 pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
-                if (ubool(max < lk)) {
-                    max = lk;
-                    argmax = lab;
-                }
-                thr_tab = thresholds();
+                if (ubool(max < lk)) new_max(lk);
+                thresholds();
             }
             t++;
             const uint32_t pos_next = nd ? pos_v : pos_v + 1;
@@ -1197,11 +1227,11 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
             if (reload || pos_next - wd.base >= 64) {
                 window_load(wd, rng, pos_next, lane);
                 p = 0;
-                hopw = hop_words(wd, thr_tab);
+                hopw = hop_words<NR>(wd, thr_tab);
                 ST_CNT(6, 1);
             } else {
                 p = pos_next - wd.base;
-                if (acc) hopw = hop_words(wd, thr_tab);
+                if (acc) hopw = hop_words<NR>(wd, thr_tab);
             }
 #ifdef JTK_MCMC_STATS
             ST_CNT(3, __builtin_readcyclecounter() - n0c);
@@ -1217,9 +1247,9 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
 #pragma unroll
         for (int d = 0; d < NS; d++) {
             int k0;
-            if (REPL && DMAX <= 2) {  // the read's own lane has its signed row in registers
-                x0[d] = readlane_f64(sx[d], e_idx);
-                k0 = __builtin_amdgcn_readlane(spk[d], (int)e_idx);
+            if (REPL && DMAX <= 2 && NR == 1) {  // the read's own lane has its signed row in registers
+                x0[d] = readlane_f64(sx[0][d], e_idx);
+                k0 = __builtin_amdgcn_readlane(spk[0][d], (int)e_idx);
             } else {
                 const uint32_t col = REPL ? (uint32_t)d : lane;
                 Elem el = {0.0, 0, 0};
@@ -1245,7 +1275,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
             const bool in_range = u >= 0.0f && diff < -1e-3 && diff > -44.4;
             if (ubool(diff <= -44.4 || (in_range && u > pe * 1.001f + 1.3e-6f))) {
                 accept = false;
-            } else if (!ubool(in_range && u + 0x1p-20f < pe * 0.999f - 3e-7f)) {
+            } else if (!ubool(in_range && u + 0x1p-19f < pe * 0.999f - 3e-7f)) {
                 rng_wait(rng, pos_v + 1);
                 accept = bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff);
             }
@@ -1262,19 +1292,18 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
             c0 = old ? c0 + 1 : c0 - 1;
             pair_up = pair_at(c0 + 1);
             pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
-            lab ^= 1ull << e_idx;
+            flip_label();
             lk = proposed;
-            if (ubool(max < lk)) {
-                max = proposed;
-                argmax = lab;
-            }
-            if (lane == e_idx) {  // the read now flips the other way
+            if (ubool(max < lk)) new_max(proposed);
 #pragma unroll
-                for (int d = 0; d < DMAX; d++) {
-                    sx[d] = -sx[d];
-                    spk[d] = -spk[d];
+            for (int r = 0; r < NR; r++)
+                if (lane + 64 * r == e_idx) {  // the read now flips the other way
+#pragma unroll
+                    for (int d = 0; d < DMAX; d++) {
+                        sx[r][d] = -sx[r][d];
+                        spk[r][d] = -spk[r][d];
+                    }
                 }
-            }
         } else {
             bool ch = false;
 #pragma unroll
@@ -1294,16 +1323,16 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
         if (changed) {
             gtab_ok = false;
             rebuild_sums();
-            thr_tab = thresholds();
+            thresholds();
         }
         if (reload || pos_next - wd.base >= 64) {
             window_load(wd, rng, pos_next, lane);
             p = 0;
-            hopw = hop_words(wd, thr_tab);
+            hopw = hop_words<NR>(wd, thr_tab);
             ST_CNT(6, 1);
         } else {
             p = pos_next - wd.base;
-            if (changed) hopw = hop_words(wd, thr_tab);
+            if (changed) hopw = hop_words<NR>(wd, thr_tab);
         }
 #ifdef JTK_MCMC_STATS
         ST_CNT(4, __builtin_readcyclecounter() - g0c);
@@ -1313,7 +1342,9 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
     ST_ADD(0);
     rng.pos = wd.base + p;
     rng_release(rng, lane);
-    if (lane < n) m.assign[lane] = (uint8_t)((argmax >> lane) & 1ull);
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+        if (lane + 64 * r < n) m.assign[lane + 64 * r] = (uint8_t)((argmax[r] >> lane) & 1ull);
     wsync();
     *rng_io = rng;
     return max;
@@ -1321,12 +1352,16 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
 
 template <int K>
 __device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
-    if (K == 2 && n <= 63 && D >= 1 && D <= 8) {
+    if (K == 2 && n <= 127 && D >= 1 && D <= 8) {
         const K2Mem km = {m.elem, m.lfact, m.assign, m.k2_stats};
-        if (D == 1) return mcmc_chain_k2<1, true>(km, n, D, cov, &rng, lane);
-        if (D == 2) return mcmc_chain_k2<2, true>(km, n, D, cov, &rng, lane);
-        if (D <= 4) return mcmc_chain_k2<4, true>(km, n, D, cov, &rng, lane);
-        return mcmc_chain_k2<8, false>(km, n, D, cov, &rng, lane);
+        if (n <= 63) {
+            if (D == 1) return mcmc_chain_k2<1, true, 1>(km, n, D, cov, &rng, lane);
+            if (D == 2) return mcmc_chain_k2<2, true, 1>(km, n, D, cov, &rng, lane);
+            if (D <= 4) return mcmc_chain_k2<4, true, 1>(km, n, D, cov, &rng, lane);
+            return mcmc_chain_k2<8, false, 1>(km, n, D, cov, &rng, lane);
+        }
+        if (D <= 4) return mcmc_chain_k2<4, true, 2>(km, n, D, cov, &rng, lane);
+        return mcmc_chain_k2<8, false, 2>(km, n, D, cov, &rng, lane);
     }
     if (n <= 63) return mcmc_chain<K, true>(m, n, D, cov, rng, lane);
     return mcmc_chain<K, false>(m, n, D, cov, rng, lane);
@@ -1386,6 +1421,9 @@ __device__ __forceinline__ bool mcmc_clustering(const Lds &m, uint32_t n, uint32
     for (int it = 0; it < 20; it++) {
         if (!kmeans(m, n, D, K, rng, lane)) return false;
         const double lk = mcmc_with_filter<K>(m, n, D, cov, rng, lane);
+#ifdef JTK_DEBUG_LK
+        if (lane == 0 && n == 65) printf("DEVLK n %u D %u it %d lk %.17g pos %u\n", n, D, it, lk, rng.pos);
+#endif
         if (!have || !(lk < best)) {  // max_by: the last maximum wins
             best = lk;
             have = true;
@@ -1519,7 +1557,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         lds_st32(&m.ctl->quit, 0);
         lds_st32(&m.ctl->wr, 0);
         lds_st32(&m.ctl->wp, 0);
-        lds_st32(&m.ctl->parse_n, n <= 63 ? n : 0);  // the diploid chain (and its records) exists for n <= 63
+        lds_st32(&m.ctl->parse_n, n <= 127 ? n : 0);  // the diploid chain (and its records) exists for n <= 127
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();

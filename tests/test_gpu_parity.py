@@ -207,7 +207,9 @@ def test_chain_variants_match_oracle(lib):
     the same stream), all-zero rows (size-only moves), tiny pile-ups"""
     p = jb.default_params(haploid_coverage=15.0)
     specs = [(60, 1, 2, 2), (60, 2, 2, 2), (45, 4, 2, 2), (63, 8, 2, 2), (40, 7, 2, 2), (50, 9, 2, 2),
-             (64, 3, 2, 2), (12, 4, 2, 2), (5, 2, 2, 2), (33, 5, 1, 2)]
+             (64, 3, 2, 2), (12, 4, 2, 2), (5, 2, 2, 2), (33, 5, 1, 2),
+             # more than 63 reads: two table registers per read / per cluster size
+             (65, 1, 2, 2), (100, 6, 2, 2), (127, 2, 2, 2), (90, 4, 2, 2), (128, 3, 2, 2)]
     dev, ora, truth = run_features_both(p, specs, seed=7)
     assert np.array_equal(dev["label"], ora["label"])
     assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
@@ -221,7 +223,7 @@ def test_size_only_moves_match_oracle(lib):
     import ctypes as C
     p = jb.default_params(haploid_coverage=20.0)
     rng = np.random.default_rng(11)
-    specs = [(60, 1), (48, 2), (60, 3)]
+    specs = [(60, 1), (48, 2), (60, 3), (96, 1), (120, 2)]
     chunks = np.zeros(len(specs), dtype=ffi.FEATURE_CHUNK_DT)
     var, vts = [], []
     voff = vtoff = rfirst = 0
@@ -314,3 +316,17 @@ def test_full_size_posteriors_are_normalised_and_labels_recover_truth(lib, full_
             lab, tr = out["label"][rr], b.truth[rr]
             agree.append(max((lab == tr).mean(), (lab != tr).mean()))
     assert len(agree) >= 6 and np.mean(agree) > 0.9
+
+
+@pytest.mark.parametrize("seed", [20, 21, 23])
+def test_size_only_moves_after_residues_match_oracle(lib, seed):
+    """regression: `proposed - lk` of a size-only move uses the lk the chain CARRIES (flip-back residues move the
+    column sums, not lk), not a difference of two table entries; read counts just above a power of two make
+    gen_range reject ~45 % of its draws, which is when one misjudged 'draws nothing' shifts the whole stream"""
+    p = jb.default_params(haploid_coverage=15.0)
+    specs = [(65, 1, 2, 2), (65, 2, 2, 2), (67, 1, 2, 2), (69, 1, 2, 2), (71, 1, 2, 2), (97, 1, 2, 2), (75, 1, 2, 2),
+             (85, 2, 2, 2), (61, 1, 2, 2)]
+    dev, ora, truth = run_features_both(p, specs, seed=seed)
+    assert np.array_equal(dev["label"], ora["label"])
+    assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(ora["log_post"]))
+    assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(ora["result"]["score"]))
