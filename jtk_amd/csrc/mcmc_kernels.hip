@@ -469,23 +469,25 @@ __device__ __forceinline__ void xo_step(Xo &x) {
     x.s2 ^= t;
     x.s3 = rotl64(x.s3, 45);
 }
-// The table sits in LDS (a look-up that goes to L2 costs a lone wave microseconds); the loop is compact on purpose:
-// fully unrolled it is kilobytes of straight-line code executed once per superblock, and this kernel is large.
+// The table sits in LDS whenever two workgroups per CU can afford it (a look-up that goes to L2 costs a lone wave
+// microseconds: 10.8 K vs 32 K cycles per jump); the loop is compact on purpose: fully unrolled it is kilobytes of
+// straight-line code executed once per superblock, and this kernel is large.
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const u64x2 lds_cu2;
-__device__ __forceinline__ void xo_jump(Xo &x, const ulonglong2 *tab) {
+template <typename PTR>
+__device__ __forceinline__ void xo_jump_from(Xo &x, PTR tab) {
     uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll 1
     for (int q = 0; q < 4; q++) {
         const uint64_t wq = q == 0 ? x.s0 : (q == 1 ? x.s1 : (q == 2 ? x.s2 : x.s3));
-        lds_cu2 *row = (lds_cu2 *)&tab[(q * 32) * 4 * 2];
+        PTR row = tab + (q * 32) * 4 * 2;
 #pragma unroll 1
         for (int k = 0; k < 32; k += 8) {
             u64x2 lo[8], hi[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const uint32_t v = (uint32_t)(wq >> (2 * (k + u))) & 3u;
-                lds_cu2 *e = &row[((k + u) * 4 + v) * 2];
+                PTR e = row + ((k + u) * 4 + v) * 2;
                 lo[u] = e[0];
                 hi[u] = e[1];
             }
@@ -502,6 +504,12 @@ __device__ __forceinline__ void xo_jump(Xo &x, const ulonglong2 *tab) {
     x.s1 = a1;
     x.s2 = a2;
     x.s3 = a3;
+}
+__device__ __forceinline__ void xo_jump(Xo &x, const ulonglong2 *lds_tab) {
+    if (lds_tab)
+        xo_jump_from<lds_cu2 *>(x, (lds_cu2 *)lds_tab);
+    else
+        xo_jump_from<const u64x2 *>(x, reinterpret_cast<const u64x2 *>(g_jump_tab));
 }
 // Proposal records.  For the diploid chain a proposal is: gen_range(0..n) takes the first draw at or after its start
 // whose widening multiply is accepted, gen_index(1) (the single candidate of K == 2, pseudo_mcmc.rs:732) then takes
@@ -1492,7 +1500,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
                                                   const uint32_t *vtype_all, const uint64_t *vt_off_all,
                                                   uint32_t vt_stride_mode, uint32_t *label_all, double *post_all,
                                                   uint32_t post_stride, double *lg_all, const uint64_t *lg_off,
-                                                  uint32_t lds_n, uint32_t lds_d) {
+                                                  uint32_t lds_n, uint32_t lds_d, uint32_t jump_in_lds) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t ci = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     ChunkState *st = &state[ci];
@@ -1532,7 +1540,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         m.ctl = (RCtl *)take(sizeof(RCtl));
         m.ring = (uint64_t *)take(sizeof(uint64_t) * RN);
         m.rec = (uint32_t *)take(sizeof(uint32_t) * RN);
-        m.jump = (ulonglong2 *)take(JUMP_TAB_BYTES);
+        m.jump = jump_in_lds ? (ulonglong2 *)take(JUMP_TAB_BYTES) : nullptr;
         m.k2_stats = (unsigned long long *)take(16 * 8);
         m.elem = (Elem *)take((size_t)lds_n * lds_d * sizeof(Elem));
         m.data = (double *)take((size_t)lds_n * lds_d * 8);
@@ -1551,7 +1559,8 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         m.prev_used = (uint8_t *)take(lds_d);
         m.tmp_used = (uint8_t *)take(lds_d);
     }
-    for (uint32_t e = threadIdx.x; e < JUMP_TAB_BYTES / 16; e += blockDim.x) m.jump[e] = g_jump_tab[e];
+    if (jump_in_lds)
+        for (uint32_t e = threadIdx.x; e < JUMP_TAB_BYTES / 16; e += blockDim.x) m.jump[e] = g_jump_tab[e];
     if (threadIdx.x == 0) {
         lds_st32(&m.ctl->rd, 0);
         lds_st32(&m.ctl->quit, 0);
@@ -1706,13 +1715,17 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
 
 }  // namespace
 
-size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d) {
+// LDS work area of one chunk.  Two workgroups share a CU as long as each stays under 80 KiB: the producer's jump
+// table (16 KiB) is staged in LDS only when that still holds, larger pile-ups read it from global memory.
+static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    size_t b = al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) + al(JUMP_TAB_BYTES) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
-               al(16 * 8) +
-               al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) + 2 * al((size_t)JTK_MAX_COPY * lds_d * 8) +
-               2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d);
-    return b;
+    return al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
+           al(16 * 8) + al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) +
+           2 * al((size_t)JTK_MAX_COPY * lds_d * 8) + 2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d);
+}
+static bool mcmc_jump_in_lds(uint32_t lds_n, uint32_t lds_d) { return mcmc_lds_core(lds_n, lds_d) + JUMP_TAB_BYTES <= 80 * 1024; }
+size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d) {
+    return mcmc_lds_core(lds_n, lds_d) + (mcmc_jump_in_lds(lds_n, lds_d) ? JUMP_TAB_BYTES : 0);
 }
 
 // ---- host: the two-bit-digit table of M^(63*SEG), from nothing but the generator's own step function
@@ -1790,5 +1803,5 @@ void launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, Chun
     const size_t lds = mcmc_lds_bytes(lds_n, lds_d);
     if (mcmc_upload_jump_table(s) != 0) return;  // 16 KiB, stream-ordered before the kernel; the launch then fails loudly
     mcmc_kernel<<<n_chunks, 128, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
-                                          post_stride, lg, lg_off, lds_n, lds_d);
+                                          post_stride, lg, lg_off, lds_n, lds_d, mcmc_jump_in_lds(lds_n, lds_d) ? 1u : 0u);
 }
