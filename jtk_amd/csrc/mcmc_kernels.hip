@@ -160,18 +160,24 @@ __device__ __forceinline__ double unif64(double v) { return jtk_bits_f64(uni64(j
 __device__ __forceinline__ bool ubool(bool c) { return __ballot(c) != 0ull; }  // c is the same in every lane
 
 // LDS work area of one chunk
-struct Elem {  // one (read, column) cell as the chain needs it
+struct Elem {  // one (read, column) cell as the chain needs it (derived from the value on the fly: LDS holds only x)
     double x;  // the likelihood gain
     int dp;    // 1 if x >  POS_THR (counts towards num_pos)
     int pw;    // 3*[x > POS_THR] - 7*[x < -POS_THR]: increment of 3*num_pos - 7*num_neg
 };
+__device__ __forceinline__ Elem elem_of(double x) {
+    Elem el;
+    el.x = x;
+    el.dp = JTK_POS_THR < x ? 1 : 0;
+    el.pw = 3 * el.dp - 7 * (x < -JTK_POS_THR ? 1 : 0);
+    return el;
+}
 struct Lds {
     RCtl *ctl;
     uint64_t *ring;      // RN raw draws
     uint32_t *rec;       // RN proposal records of the diploid chain
     ulonglong2 *jump;    // the producer's jump table (JUMP_TAB_BYTES)
     unsigned long long *k2_stats;  // 16 debug counters (JTK_MCMC_STATS builds only)
-    Elem *elem;          // n x D
     double *data;        // n x D
     double *size_to_lk;  // n + 1
     double *lfact;       // n + 1
@@ -685,7 +691,7 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t c = uni(m.assign[i]);
         Elem el = {0.0, 0, 0};
-        if (lane < D) el = m.elem[i * D + lane];
+        if (lane < D) el = elem_of(m.data[i * D + lane]);
 #pragma unroll
         for (int cc = 0; cc < K; cc++)
             if ((uint32_t)cc == c) {
@@ -769,7 +775,7 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
         const uint32_t pos = choose_pos(rng, K);
         const uint32_t nw = pos < old ? pos : pos + 1;
         Elem el = {0.0, 0, 0};
-        if (lane < D) el = m.elem[idx * D + lane];
+        if (lane < D) el = elem_of(m.data[idx * D + lane]);
         // ---- tentative flip (:764-783): only the two touched clusters change
         double T[K];
         int P[K], W[K], ncl[K];
@@ -963,7 +969,7 @@ __device__ __forceinline__ void scalar_proposal(Rng &rng, uint32_t start, uint32
 // Out of line on purpose: inlined into the kernel, the chain inherits the register pressure of everything that is
 // live around it and spills scalar registers inside its loop (each reload is a v_readlane on the critical path).
 struct K2Mem {
-    const Elem *elem;
+    const double *data;  // n x D likelihood gains
     const double *lfact;
     uint8_t *assign;
     unsigned long long *k2_stats;
@@ -1016,7 +1022,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
         for (int d = 0; d < NS; d++) {
             const uint32_t col = REPL ? (uint32_t)d : lane;
             Elem el = {0.0, 0, 0};
-            if (col < D) el = m.elem[i * D + col];
+            if (col < D) el = elem_of(m.data[i * D + col]);
             tp2[d] += 2 * el.dp;  // 2 x reads with a positive value in this column: constant along the chain
             if (c == 0) {
                 tg0[d] += el.x;
@@ -1046,7 +1052,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
 #pragma unroll
         for (int d = 0; d < DMAX; d++) {
             Elem el = {0.0, 0, 0};
-            if ((uint32_t)d < D) el = m.elem[ri[r] * D + d];
+            if ((uint32_t)d < D) el = elem_of(m.data[ri[r] * D + d]);
             sx[r][d] = a ? el.x : -el.x;
             spk[r][d] = a ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
             nzr = nzr || sx[r][d] != 0.0 || spk[r][d] != 0;
@@ -1261,7 +1267,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
             } else {
                 const uint32_t col = REPL ? (uint32_t)d : lane;
                 Elem el = {0.0, 0, 0};
-                if (col < D) el = m.elem[e_idx * D + col];
+                if (col < D) el = elem_of(m.data[e_idx * D + col]);
                 x0[d] = old ? el.x : -el.x;
                 k0 = old ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
             }
@@ -1361,7 +1367,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
 template <int K>
 __device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
     if (K == 2 && n <= 127 && D >= 1 && D <= 8) {
-        const K2Mem km = {m.elem, m.lfact, m.assign, m.k2_stats};
+        const K2Mem km = {m.data, m.lfact, m.assign, m.k2_stats};
         if (n <= 63) {
             if (D == 1) return mcmc_chain_k2<1, true, 1>(km, n, D, cov, &rng, lane);
             if (D == 2) return mcmc_chain_k2<2, true, 1>(km, n, D, cov, &rng, lane);
@@ -1542,7 +1548,6 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         m.rec = (uint32_t *)take(sizeof(uint32_t) * RN);
         m.jump = jump_in_lds ? (ulonglong2 *)take(JUMP_TAB_BYTES) : nullptr;
         m.k2_stats = (unsigned long long *)take(16 * 8);
-        m.elem = (Elem *)take((size_t)lds_n * lds_d * sizeof(Elem));
         m.data = (double *)take((size_t)lds_n * lds_d * 8);
         m.size_to_lk = (double *)take((size_t)(lds_n + 1) * 8);
         m.lfact = (double *)take((size_t)(lds_n + 1) * 8);
@@ -1576,13 +1581,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
     }
     const double *feat = feat_all + cm.feat_off;
     for (uint32_t e = lane; e < n * D; e += 64) {
-        const double x = feat[e];
-        m.data[e] = x;
-        Elem el;
-        el.x = x;
-        el.dp = JTK_POS_THR < x ? 1 : 0;
-        el.pw = 3 * el.dp - 7 * (x < -JTK_POS_THR ? 1 : 0);
-        m.elem[e] = el;
+        m.data[e] = feat[e];
     }
     // lfact[x] = sum_{c=1..x} ln c, summed left to right as poisson_lk does (:636-638)
     if (lane == 0) {
@@ -1719,7 +1718,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
 // table (16 KiB) is staged in LDS only when that still holds, larger pile-ups read it from global memory.
 static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    return al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) + al((size_t)lds_n * lds_d * sizeof(Elem)) +
+    return al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) +
            al(16 * 8) + al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) +
            2 * al((size_t)JTK_MAX_COPY * lds_d * 8) + 2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d);
 }
