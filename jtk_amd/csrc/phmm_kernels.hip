@@ -277,6 +277,9 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
         const double lk = tot > 0.0 ? jtk_log(tot) + (double)EF * JTK_LN2 : JTK_LOG_ZERO;
         if (lane == 0) lk_all[item] = lk;
         __syncthreads();  // s_EF visible; forward stores are read back by this same wave below
+#ifdef JTK_PHMM_EXPERIMENT_FWDONLY
+        continue;
+#endif
 
         // =========================== backward + table accumulation ===========================
         double *raw = raw_all + rm.raw_off;
