@@ -40,7 +40,7 @@ typedef enum jtk_status {
     JTK_OK = 0,
     JTK_ERR_INVALID_ARG = -1,     /* null pointer, inconsistent offsets, non-ACGT base, bad op code    */
     JTK_ERR_NO_DEVICE = -2,       /* no usable MI355X / HIP runtime failure (message via last_error)   */
-    JTK_ERR_UNSUPPORTED = -3,     /* band radius > 31 (one wavefront per anti-diagonal), copy_num >= 8 */
+    JTK_ERR_UNSUPPORTED = -3,     /* band radius > 30 (one wavefront per anti-diagonal), pile-up too large for LDS */
     JTK_ERR_ALLOC = -4,           /* hipMalloc / host allocation failed                                */
     JTK_ERR_OPS_MISMATCH = -5,    /* ops do not consume exactly the template and the read              */
     JTK_ERR_CHUNK_FAILED = -6,    /* >=1 chunk hit a condition on which the reference panics; see      */
@@ -108,8 +108,9 @@ typedef struct jtk_lc_result {
  * Replaces `pileups.into_par_iter()...map(clustering_on_pileup)` (mod.rs:64-72) for a batch of chunks:
  * consensus polishing (mod.rs:105-106), variant search (pseudo_mcmc.rs:109-138), clustering
  * (pseudo_mcmc.rs:213-274, 77-107) and the per-node write-back data of update_by_clusterings
- * (mod.rs:244-260).  copy_num >= 8 (clustering_recursive's split branch, mod.rs:138-189) is not yet on
- * the device: such chunks get status JTK_ERR_UNSUPPORTED.
+ * (mod.rs:244-260).  Chunks with copy_num >= 8 take clustering_recursive's split branch (mod.rs:138-189):
+ * a 4-way clustering, then per group a consensus polish and a clustering with the group's share of the
+ * copies, merged as mod.rs:161-187 does; post_stride must be >= the largest copy_num of the batch.
  *
  * label[r]        : Node.cluster of read r (before normalize_local_clustering).
  * log_post        : row r has post_stride doubles; the first result[c].cluster_num are Node.posterior

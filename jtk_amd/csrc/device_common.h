@@ -15,7 +15,8 @@
 #define JTK_POS_THR 0.00001      // pseudo_mcmc.rs:5
 #define JTK_MASK_LENGTH 7        // pseudo_mcmc.rs:3
 #define JTK_MAX_HOMOP_LENGTH 2   // pseudo_mcmc.rs:4
-#define JTK_MAX_COPY 7           // copy_num < 8 on the device (clustering_recursive's split is host-side work)
+#define JTK_MAX_COPY 7           // one clustering() call sees copy_num < 8 (UPPER_COPY_NUM, mod.rs:85); larger chunks
+                                 // go through clustering_recursive's split, which session.hip drives
 #define JTK_MAX_DIM (3 * JTK_MAX_COPY)  // ROUND * max(copy_num, 2) picked columns (pseudo_mcmc.rs:421,527,532)
 #define JTK_POLISH_MIN_GAIN 0.1
 #define JTK_POLISH_MAX_ROUNDS 20
@@ -62,6 +63,7 @@ struct ChunkState {
     uint32_t dim;        // D selected variant columns
     uint32_t k;          // cluster_num
     double score;
+    uint64_t draws;      // RNG stream positions the clustering consumed
 };
 
 struct HmmDev {

@@ -558,13 +558,21 @@ __device__ __forceinline__ void producer_parse(const uint64_t *ring, uint32_t *r
         if (lane < PKEEP) lds_st32(&rec[(base + r * PKEEP + lane) & (RN - 1)], v);
     }
 }
-__device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_t *rec, const ulonglong2 *jump, uint64_t seed, uint32_t lane) {
+__device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_t *rec, const ulonglong2 *jump, uint64_t seed,
+                                              const uint64_t *resume, uint32_t lane) {
     uint64_t z = seed;
     Xo x;
-    x.s0 = splitmix64(z);
-    x.s1 = splitmix64(z);
-    x.s2 = splitmix64(z);
-    x.s3 = splitmix64(z);
+    if (resume) {  // a later clustering() call of the same chunk continues the stream (clustering_recursive, mod.rs:158)
+        x.s0 = resume[0];
+        x.s1 = resume[1];
+        x.s2 = resume[2];
+        x.s3 = resume[3];
+    } else {
+        x.s0 = splitmix64(z);
+        x.s1 = splitmix64(z);
+        x.s2 = splitmix64(z);
+        x.s3 = splitmix64(z);
+    }
     for (uint32_t j = 0; j < lane * SEG; j++) xo_step(x);  // lane l starts at stream position l * SEG
     const uint32_t parse_n = uni(lds_ld32(&ctl->parse_n));
     uint32_t wr = 0, wp = 0;
@@ -1506,7 +1514,8 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
                                                   const uint32_t *vtype_all, const uint64_t *vt_off_all,
                                                   uint32_t vt_stride_mode, uint32_t *label_all, double *post_all,
                                                   uint32_t post_stride, double *lg_all, const uint64_t *lg_off,
-                                                  uint32_t lds_n, uint32_t lds_d, uint32_t jump_in_lds) {
+                                                  uint32_t lds_n, uint32_t lds_d, uint32_t jump_in_lds,
+                                                  const uint64_t *rng_resume) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t ci = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     ChunkState *st = &state[ci];
@@ -1527,6 +1536,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         if (lane == 0) {
             st->score = 0.0;
             st->k = 1;
+            st->draws = 0;
         }
         return;
     }
@@ -1576,7 +1586,8 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (wave == 1) {  // Xoshiro256StarStar::seed_from_u64(chunk.id * 3490)  (local_clustering/mod.rs:97)
-        producer_main(m.ctl, m.ring, m.rec, m.jump, uni64(cm.chunk_id) * 3490ULL, lane);
+        producer_main(m.ctl, m.ring, m.rec, m.jump, uni64(cm.chunk_id) * 3490ULL,
+                      rng_resume ? rng_resume + 4 * (uint64_t)ci : nullptr, lane);
         return;
     }
     const double *feat = feat_all + cm.feat_off;
@@ -1672,7 +1683,10 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         }
     }
     // stop the producer wave
-    if (lane == 0) lds_st32(&m.ctl->quit, 1);
+    if (lane == 0) {
+        lds_st32(&m.ctl->quit, 1);
+        st->draws = rng.pos;  // stream positions consumed: where the chunk's next clustering() call resumes
+    }
 #ifdef JTK_MCMC_STATS
     if (lane == 0)
         printf("K2WAIT chunk %u waits %u\n", ci, rng.waits);
@@ -1797,10 +1811,11 @@ int mcmc_upload_jump_table(hipStream_t s) {
 void launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
                  const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
                  uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
-                 const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d) {
+                 const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, const uint64_t *rng_resume) {
     if (n_chunks == 0) return;
     const size_t lds = mcmc_lds_bytes(lds_n, lds_d);
     if (mcmc_upload_jump_table(s) != 0) return;  // 16 KiB, stream-ordered before the kernel; the launch then fails loudly
     mcmc_kernel<<<n_chunks, 128, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
-                                          post_stride, lg, lg_off, lds_n, lds_d, mcmc_jump_in_lds(lds_n, lds_d) ? 1u : 0u);
+                                          post_stride, lg, lg_off, lds_n, lds_d, mcmc_jump_in_lds(lds_n, lds_d) ? 1u : 0u,
+                                          rng_resume);
 }

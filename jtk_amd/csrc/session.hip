@@ -9,6 +9,11 @@
 // (mod.rs:86-123 per chunk).  The last polishing pass that finds no edit has produced exactly the
 // modification table `clustering` would recompute (same consensus, same ops, same radius: mod.rs:105 vs
 // :112, pseudo_mcmc.rs:117), so it is reused instead of recomputed.
+//
+// Chunks with copy_num >= 8 take clustering_recursive's split branch (mod.rs:138-189): the batch pass clusters
+// them into at most four groups, and run_split() below then drives the sub-problems -- polish the group's
+// consensus, cluster it with its share of the copies, recurse -- as further resident batches, one sub-problem
+// per chunk and round because a chunk's calls share one RNG stream in depth-first order.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -29,7 +34,7 @@ size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d);
 void launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
                  const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
                  uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
-                 const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d);
+                 const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, const uint64_t *rng_resume);
 
 namespace {
 
@@ -84,6 +89,22 @@ struct KernelTimer {
     int kind = 0;
 };
 
+// result of one clustering_recursive call (ClusteringDevResult, mod.rs:124)
+struct SplitResult {
+    std::vector<uint32_t> asn;
+    std::vector<double> post;  // n x k log-posteriors
+    uint32_t k = 0;
+    double score = 0.0;
+    int status = 0;
+};
+
+// what a sub-problem inherits from its chunk instead of deriving it from its own template / read count
+struct ChunkExtra {
+    uint32_t radius;        // config.band_width (mod.rs:112,142,153)
+    double local_coverage;  // config.local_coverage (mod.rs:108-112)
+    uint64_t rng[4];        // the chunk's generator, as the previous call left it (mod.rs:158)
+};
+
 }  // namespace
 
 struct jtk_lc_session {
@@ -106,6 +127,15 @@ struct jtk_lc_session {
     size_t tmpl_bytes = 0, ops_bytes = 0;
     DevBufs bufs;
     std::vector<KernelTimer> timers;
+    // clustering_recursive (mod.rs:125-189)
+    uint32_t ignore_edge = 3;            // HMMPolishConfig ignore_edge: 3 for a chunk (mod.rs:105), 0 for a sub-problem (:153)
+    bool has_split = false;              // some chunk has copy_num >= UPPER_COPY_NUM
+    std::vector<uint32_t> h_copy0;       // Chunk.copy_num as given (ChunkMeta.copy_num is what one clustering() call sees)
+    std::vector<uint8_t> h_read_bases, h_strand;  // kept on the host only when has_split
+    std::vector<uint64_t> h_read_off;
+    std::vector<SplitResult> split;      // per chunk; .k == 0: not a split chunk
+    DevPtr d_rng;                        // 4 x u64 per chunk: where each chunk's RNG stream resumes (sub-problems only)
+    bool resume_rng = false;
     ~jtk_lc_session() {
         for (auto &t : timers) {
             if (t.a) (void)hipEventDestroy(t.a);
@@ -158,10 +188,11 @@ void tstop(jtk_lc_session *s) { (void)hipEventRecord(s->timers.back().b, s->stre
 
 extern "C" {
 
-int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
-                          const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
-                          const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
-                          uint32_t post_stride, int device, jtk_lc_session_t **out) {
+static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                             const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                             const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
+                             uint32_t post_stride, int device, const ChunkExtra *extra, uint32_t ignore_edge,
+                             jtk_lc_session_t **out) {
     g_last_error.clear();
     if (!params || !out || (n_chunks && (!chunks || !tmpl_bases || !read_bases || !read_off || !ops || !ops_off || !strand)))
         return fail(JTK_ERR_INVALID_ARG, "null argument");
@@ -177,6 +208,8 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
     s->params = *params;
     s->post_stride = post_stride;
     s->n_chunks = (uint32_t)n_chunks;
+    s->ignore_edge = ignore_edge;
+    s->h_copy0.resize(n_chunks);
     HIP_TRY(hipStreamCreate(&s->stream));
 
     // ---- host-side layout + validation + encoding
@@ -201,14 +234,17 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
         ChunkMeta &cm = s->h_chunks[c];
         memset(&cm, 0, sizeof cm);
         cm.chunk_id = ch.chunk_id;
-        cm.copy_num = ch.copy_num;
+        // one clustering() call: copy_num itself, or BRANCH_NUM = 4 in the split branch (mod.rs:136-142)
+        cm.copy_num = ch.copy_num > JTK_MAX_COPY ? 4 : ch.copy_num;
+        s->h_copy0[c] = ch.copy_num;
+        if (ch.copy_num > JTK_MAX_COPY) s->has_split = true;
         cm.n_reads = ch.n_reads;
         cm.read_first = rcount;
         cm.tmpl_cap = cap;
         cm.tmpl_off = tmpl_off;
         cm.total_off = total_off;
         const uint32_t band_width = (uint32_t)std::ceil((double)tl * params->band_frac);
-        cm.radius = band_width / 2;
+        cm.radius = extra ? extra[c].radius : band_width / 2;
         cm.edit_cap = cap / 2 + 2;
         cm.edit_off = edit_off;
         cm.feat_off = feat_off;
@@ -216,12 +252,13 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
         // per_cluster_cov (mod.rs:108-111)
         const double pcc = (double)ch.n_reads / (double)ch.copy_num;
         cm.local_coverage = ch.copy_num <= 2 ? pcc : (pcc > params->haploid_coverage ? pcc : params->haploid_coverage);
+        if (extra) cm.local_coverage = extra[c].local_coverage;
         ChunkState &st = s->h_state0[c];
         memset(&st, 0, sizeof st);
         st.tmpl_len = tl;
         st.active = 1;
         st.k = 1;
-        if (cm.radius > JTK_MAX_RADIUS || ch.copy_num > JTK_MAX_COPY) st.status = JTK_ERR_UNSUPPORTED;
+        if (cm.radius > JTK_MAX_RADIUS) st.status = JTK_ERR_UNSUPPORTED;
         h_tmpl.resize(tmpl_off + cap, 0);
         for (uint32_t p = 0; p < tl; p++) {
             const int code = base_code(tmpl_bases[ch.tmpl_off + p]);
@@ -271,7 +308,7 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
         }
         if (cap > s->max_tmpl) s->max_tmpl = cap;
         if (ch.n_reads > s->max_n) s->max_n = ch.n_reads;
-        if (ch.copy_num > s->max_copy) s->max_copy = ch.copy_num;
+        if (cm.copy_num > s->max_copy) s->max_copy = cm.copy_num;
         rcount += ch.n_reads;
         tmpl_off += cap;
         total_off += (uint64_t)JTK_NUM_ROW * (cap + 1);
@@ -283,6 +320,11 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
     }
     s->tmpl_bytes = h_tmpl.size();
     s->ops_bytes = h_ops.size();
+    if (s->has_split) {  // the sub-problems of the split branch are encoded from these again
+        s->h_read_bases.assign(read_bases, read_bases + read_off[n_reads]);
+        s->h_read_off.assign(read_off, read_off + n_reads + 1);
+        s->h_strand.assign(strand, strand + n_reads);
+    }
 
     // ---- device allocation + upload
     tstart(s, -1);
@@ -329,6 +371,12 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
     if ((rc = dev_alloc<double>(s->d_post, (uint64_t)n_reads * post_stride))) return rc;
     if ((rc = dev_alloc<double>(s->d_lg, lg_off))) return rc;
     if ((rc = dev_upload(s, s->d_lg_off, h_lg_off))) return rc;
+    if (extra) {
+        std::vector<uint64_t> h_rng(4 * n_chunks);
+        for (size_t c = 0; c < n_chunks; c++) memcpy(&h_rng[4 * c], extra[c].rng, 32);
+        if ((rc = dev_upload(s, s->d_rng, h_rng))) return rc;
+        s->resume_rng = true;
+    }
     // forward scratch: one stripe per resident wave
     {
         hipDeviceProp_t prop;
@@ -365,9 +413,18 @@ int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const 
     return 0;
 }
 
-int jtk_lc_session_run(jtk_lc_session_t *s, int skip_polish) {
-    g_last_error.clear();
-    if (!s) return fail(JTK_ERR_INVALID_ARG, "null session");
+int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                          const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                          const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
+                          uint32_t post_stride, int device, jtk_lc_session_t **out) {
+    return session_create_ex(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand,
+                             post_stride, device, nullptr, 3 /* mod.rs:105 */, out);
+}
+
+static int run_split(jtk_lc_session_t *s);
+
+// one pass of the kernel sequence over the resident batch
+static int run_batch(jtk_lc_session_t *s, int skip_polish) {
     HIP_TRY(hipSetDevice(s->device));
     const double h2d = g_timing.h2d_ms;
     memset(&g_timing, 0, sizeof g_timing);
@@ -411,8 +468,8 @@ int jtk_lc_session_run(jtk_lc_session_t *s, int skip_polish) {
         tstart(s, JTK_K_POLISH);
         launch_polish_round(st, s->n_chunks, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(),
                             s->d_table.as<double>(), s->d_total.as<double>(), s->d_edits.as<Edit>(),
-                            s->d_newlen.as<uint32_t>(), s->max_tmpl, 3 /* HMMPolishConfig ignore_edge, mod.rs:105 */,
-                            final_pass, s->d_nactive.as<uint32_t>());
+                            s->d_newlen.as<uint32_t>(), s->max_tmpl, s->ignore_edge, final_pass,
+                            s->d_nactive.as<uint32_t>());
         if (!final_pass)
             launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 1);
         tstop(s);
@@ -433,7 +490,8 @@ int jtk_lc_session_run(jtk_lc_session_t *s, int skip_polish) {
                 s->post_stride, s->d_lg.as<double>(), s->d_lg_off.as<uint64_t>(), s->max_n,
                 // a chunk picks at most ROUND * max(copy_num, 2) columns (pseudo_mcmc.rs:421,527,532): size the
                 // LDS work area for the batch, so that two chunks share a CU whenever they can
-                std::min<uint32_t>(JTK_MAX_DIM, 3u * std::max<uint32_t>(s->max_copy, 2u)));
+                std::min<uint32_t>(JTK_MAX_DIM, 3u * std::max<uint32_t>(s->max_copy, 2u)),
+                s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr);
     tstop(s);
     HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -451,6 +509,14 @@ int jtk_lc_session_run(jtk_lc_session_t *s, int skip_polish) {
         g_timing.kernel_launches[t.kind] += 1;
     }
     return 0;
+}
+
+int jtk_lc_session_run(jtk_lc_session_t *s, int skip_polish) {
+    g_last_error.clear();
+    if (!s) return fail(JTK_ERR_INVALID_ARG, "null session");
+    int rc = run_batch(s, skip_polish);
+    if (rc == 0 && s->has_split) rc = run_split(s);
+    return rc;
 }
 
 int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post, jtk_lc_result_t *result,
@@ -533,7 +599,315 @@ int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post,
         }
     }
     if (want_cons) cons_off[s->n_chunks] = co;
+    // chunks that went through clustering_recursive's split: the merged clustering replaces the first pass's
+    for (uint32_t c = 0; c < s->n_chunks && c < s->split.size(); c++) {
+        const SplitResult &sr = s->split[c];
+        if (sr.k == 0) continue;
+        const ChunkMeta &cm = s->h_chunks[c];
+        if (sr.status != 0) any_fail = 1;
+        if (result) {
+            result[c].score = sr.status == 0 ? sr.score : 0.0;
+            result[c].cluster_num = sr.status == 0 ? sr.k : 1;
+            result[c].status = sr.status;
+        }
+        for (uint32_t r = 0; r < cm.n_reads; r++) {
+            const uint32_t g = cm.read_first + r;
+            if (label) label[g] = sr.status == 0 ? sr.asn[r] : 0;
+            if (log_post)
+                for (uint32_t t = 0; t < s->post_stride; t++)
+                    log_post[(size_t)g * s->post_stride + t] = (sr.status == 0 && t < sr.k) ? sr.post[(size_t)r * sr.k + t] : 0.0;
+        }
+    }
     return any_fail ? fail(JTK_ERR_CHUNK_FAILED, "at least one chunk failed; see result[].status") : 0;
+}
+
+
+// ---- clustering_recursive's split branch (mod.rs:138-189), driven from the host --------------------------
+namespace {
+
+const uint32_t UPPER_COPY_NUM = JTK_MAX_COPY + 1;  // mod.rs:85
+const uint32_t BRANCH_NUM = 4;                     // mod.rs:139
+
+// One clustering_recursive call of a chunk, waiting for its clustering() or for its sub-calls.
+struct SplitFrame {
+    std::vector<uint8_t> tmpl;              // bases the call starts from (a sub-call polishes them first, mod.rs:153-155)
+    std::vector<uint32_t> rid;              // its reads: indices into the session's batch
+    std::vector<std::vector<uint8_t>> ops;  // their ops against tmpl
+    uint32_t copy_num = 0;
+    bool have = false;                      // the device pass of this call has run:
+    SplitResult own;                        //   clustering() with min(copy_num, BRANCH_NUM-or-itself) clusters
+    std::vector<uint8_t> cons;              //   the consensus it clustered on
+    std::vector<std::vector<uint8_t>> cops; //   and the ops re-threaded onto it
+    std::vector<uint32_t> copy_numbers;     // estim_copy_num of the split
+    std::vector<SplitResult> kids;          // finished sub-calls, in cluster order
+};
+struct SplitChunk {
+    uint32_t chunk = 0;
+    uint64_t rng[4];
+    std::vector<SplitFrame> stack;
+    bool done = false;
+};
+
+void seed_from_u64(uint64_t seed, uint64_t out[4]) {  // rand_core SeedableRng::seed_from_u64 for a 32-byte seed: SplitMix64
+    for (int i = 0; i < 4; i++) {
+        seed += 0x9e3779b97f4a7c15ULL;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        out[i] = z ^ (z >> 31);
+    }
+}
+void rng_skip(uint64_t s[4], uint64_t draws) {  // the xoshiro256 state after `draws` outputs
+    for (uint64_t i = 0; i < draws; i++) {
+        const uint64_t t = s[1] << 17;
+        s[2] ^= s[0];
+        s[3] ^= s[1];
+        s[1] ^= s[2];
+        s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = (s[3] << 45) | (s[3] >> 19);
+    }
+}
+
+// estim_copy_num (mod.rs:223-243): one copy per cluster, every further copy to the cluster whose read count is
+// farthest from coverage * copies (max_by keeps the last maximum)
+std::vector<uint32_t> estim_copy_num(const std::vector<uint32_t> &asn, uint32_t k, uint32_t copy_num, double coverage) {
+    std::vector<double> counts(k, 0.0);
+    for (uint32_t a : asn) counts[a] += 1.0;
+    std::vector<uint32_t> cp(k, 1);
+    for (uint32_t it = k; it < copy_num; it++) {
+        uint32_t arg = 0;
+        double best = 0.0;
+        for (uint32_t c = 0; c < k; c++) {
+            const double d = counts[c] - coverage * (double)cp[c], v = d * d;
+            if (c == 0 || !(v < best)) {
+                best = v;
+                arg = c;
+            }
+        }
+        cp[arg] += 1;
+    }
+    return cp;
+}
+
+// the merge of mod.rs:161-187
+SplitResult merge_split(const SplitFrame &f) {
+    const uint32_t k = f.own.k;
+    std::vector<uint32_t> offsets(k), pointers(k, 0);
+    uint32_t total = 0;
+    for (uint32_t c = 0; c < k; c++) {
+        offsets[c] = total;
+        total += f.kids[c].k;
+    }
+    SplitResult r;
+    r.k = total;
+    r.score = f.own.score;
+    double sub = 0.0;
+    for (uint32_t c = 0; c < k; c++) sub += f.kids[c].score;
+    r.score = sub + f.own.score;
+    const size_t n = f.own.asn.size();
+    r.asn.resize(n);
+    r.post.resize(n * total);
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t a = f.own.asn[i], pt = pointers[a]++;
+        const SplitResult &kid = f.kids[a];
+        double *po = &r.post[i * total];
+        uint32_t w = 0;
+        for (uint32_t c = 0; c < k; c++) {
+            const double lk = f.own.post[i * k + c] - jtk_log((double)f.kids[c].k);
+            for (uint32_t t = 0; t < f.kids[c].k; t++) po[w++] = lk;
+        }
+        for (uint32_t t = 0; t < kid.k; t++) po[t + offsets[a]] += kid.post[(size_t)pt * kid.k + t] + jtk_log((double)kid.k);
+        double sum = 0.0;
+        for (uint32_t t = 0; t < total; t++) sum += jtk_exp(po[t]);
+        if (!(std::fabs(1.0 - sum) < 0.0001)) r.status = JTK_ERR_CHUNK_FAILED;  // the reference asserts (mod.rs:184)
+        r.asn[i] = offsets[a] + kid.asn[pt];
+    }
+    return r;
+}
+
+}  // namespace
+
+static int run_split(jtk_lc_session_t *s) {
+    static const char BASES[] = "ACGT";
+    jtk_lc_timing_t acc = g_timing;
+    // ---- what the batch pass left for the split chunks: labels, posteriors, consensus, ops, draws
+    std::vector<uint32_t> label(s->n_reads);
+    std::vector<double> post((size_t)s->n_reads * s->post_stride);
+    std::vector<jtk_lc_result_t> res(s->n_chunks);
+    std::vector<uint8_t> cons(s->tmpl_bytes + 8), ops_out(s->ops_bytes + 8);
+    std::vector<uint64_t> cons_off(s->n_chunks + 1), ops_off(s->n_reads + 1);
+    std::vector<ChunkState> state(s->n_chunks);
+    s->split.clear();  // fetch below must see the batch pass's own results
+    int rc = jtk_lc_session_fetch(s, label.data(), post.data(), res.data(), cons.data(), cons_off.data(), cons.size(),
+                                  ops_out.data(), ops_off.data(), ops_out.size());
+    if (rc != 0 && rc != JTK_ERR_CHUNK_FAILED) return rc;
+    HIP_TRY(hipMemcpy(state.data(), s->d_state.p, state.size() * sizeof(ChunkState), hipMemcpyDeviceToHost));
+    acc.d2h_ms = 0;
+    s->split.assign(s->n_chunks, SplitResult());
+    std::vector<SplitChunk> work;
+    for (uint32_t c = 0; c < s->n_chunks; c++) {
+        if (s->h_copy0[c] < UPPER_COPY_NUM) continue;
+        const ChunkMeta &cm = s->h_chunks[c];
+        if (res[c].status != 0) {
+            s->split[c].k = 1;
+            s->split[c].status = res[c].status;
+            continue;
+        }
+        if (res[c].cluster_num > s->post_stride) return fail(JTK_ERR_INVALID_ARG, "post_stride smaller than a cluster count");
+        SplitChunk w;
+        w.chunk = c;
+        seed_from_u64(cm.chunk_id * 3490ULL, w.rng);  // mod.rs:97
+        rng_skip(w.rng, state[c].draws);
+        SplitFrame f;
+        f.copy_num = s->h_copy0[c];
+        f.have = true;
+        f.own.k = res[c].cluster_num;
+        f.own.score = res[c].score;
+        f.cons.assign(cons.begin() + cons_off[c], cons.begin() + cons_off[c + 1]);
+        for (uint32_t r = 0; r < cm.n_reads; r++) {
+            const uint32_t g = cm.read_first + r;
+            f.rid.push_back(g);
+            f.own.asn.push_back(label[g]);
+            for (uint32_t t = 0; t < f.own.k; t++) f.own.post.push_back(post[(size_t)g * s->post_stride + t]);
+            f.cops.emplace_back(ops_out.begin() + ops_off[g], ops_out.begin() + ops_off[g + 1]);
+        }
+        w.stack.push_back(std::move(f));
+        work.push_back(std::move(w));
+    }
+    // ---- rounds: advance every chunk to its next clustering() call, run those calls as one resident batch
+    for (;;) {
+        std::vector<SplitChunk *> waiting;
+        for (SplitChunk &w : work) {
+            while (!w.done) {
+                SplitFrame &f = w.stack.back();
+                if (!f.have) break;
+                SplitResult out;
+                bool finished = false;
+                if (f.own.status != 0) {
+                    out.k = 1;
+                    out.status = f.own.status;
+                    w.stack.resize(1);  // the chunk fails as a whole
+                    finished = true;
+                } else if (f.copy_num < UPPER_COPY_NUM || f.own.k <= 1) {  // mod.rs:136-137, :146-148
+                    out = std::move(f.own);
+                    finished = true;
+                } else if (f.kids.size() == f.own.k) {
+                    out = merge_split(f);
+                    finished = true;
+                } else {
+                    if (f.copy_numbers.empty())
+                        f.copy_numbers = estim_copy_num(f.own.asn, f.own.k, f.copy_num, s->params.haploid_coverage);
+                    const uint32_t c = (uint32_t)f.kids.size(), cp = f.copy_numbers[c];
+                    SplitFrame kid;  // filter_sub_clusters (mod.rs:198-221)
+                    for (size_t i = 0; i < f.rid.size(); i++)
+                        if (f.own.asn[i] == c) {
+                            kid.rid.push_back(f.rid[i]);
+                            kid.ops.push_back(f.cops[i]);
+                        }
+                    if (cp < 2 || kid.rid.empty()) {
+                        // clustering() returns at once, with no draw (pseudo_mcmc.rs:86-88): the polish before it
+                        // (mod.rs:153-155) cannot reach the result and is not run
+                        SplitResult t;
+                        t.k = 1;
+                        t.asn.assign(kid.rid.size(), 0);
+                        t.post.assign(kid.rid.size(), 0.0);
+                        f.kids.push_back(std::move(t));
+                        continue;
+                    }
+                    kid.tmpl = f.cons;
+                    kid.copy_num = cp;
+                    w.stack.push_back(std::move(kid));
+                    continue;
+                }
+                if (finished) {
+                    w.stack.pop_back();
+                    if (w.stack.empty()) {
+                        s->split[w.chunk] = std::move(out);
+                        w.done = true;
+                    } else if (out.status != 0) {
+                        w.stack.back().own.status = out.status;
+                    } else {
+                        w.stack.back().kids.push_back(std::move(out));
+                    }
+                }
+            }
+            if (!w.done) waiting.push_back(&w);
+        }
+        if (waiting.empty()) break;
+        // pack the waiting calls
+        const size_t nb = waiting.size();
+        std::vector<jtk_lc_chunk_t> chunks(nb);
+        std::vector<ChunkExtra> extra(nb);
+        std::vector<uint8_t> tmpl, reads, opsv, strand;
+        std::vector<uint64_t> roff(1, 0), ooff(1, 0);
+        for (size_t b = 0; b < nb; b++) {
+            const SplitChunk &w = *waiting[b];
+            const SplitFrame &f = w.stack.back();
+            const ChunkMeta &cm = s->h_chunks[w.chunk];
+            chunks[b].chunk_id = cm.chunk_id;
+            chunks[b].copy_num = f.copy_num;
+            chunks[b].n_reads = (uint32_t)f.rid.size();
+            chunks[b].tmpl_off = tmpl.size();
+            chunks[b].tmpl_len = f.tmpl.size();
+            chunks[b].read_first = strand.size();
+            extra[b].radius = cm.radius;
+            extra[b].local_coverage = cm.local_coverage;
+            memcpy(extra[b].rng, w.rng, 32);
+            tmpl.insert(tmpl.end(), f.tmpl.begin(), f.tmpl.end());
+            for (size_t i = 0; i < f.rid.size(); i++) {
+                const uint32_t g = f.rid[i];
+                reads.insert(reads.end(), s->h_read_bases.begin() + s->h_read_off[g], s->h_read_bases.begin() + s->h_read_off[g + 1]);
+                roff.push_back(reads.size());
+                opsv.insert(opsv.end(), f.ops[i].begin(), f.ops[i].end());
+                ooff.push_back(opsv.size());
+                strand.push_back(s->h_strand[g]);
+            }
+        }
+        const uint32_t stride = JTK_MAX_COPY;
+        jtk_lc_session_t *sub = nullptr;
+        rc = session_create_ex(&s->params, nb, chunks.data(), tmpl.data(), reads.data(), roff.data(), opsv.data(), ooff.data(),
+                               strand.data(), stride, s->device, extra.data(), 0 /* mod.rs:153 */, &sub);
+        if (rc) return rc;
+        std::unique_ptr<jtk_lc_session> guard(sub);
+        if ((rc = run_batch(sub, 0))) return rc;
+        for (int k = 0; k < JTK_K_COUNT; k++) {
+            acc.kernel_ms[k] += g_timing.kernel_ms[k];
+            acc.kernel_launches[k] += g_timing.kernel_launches[k];
+        }
+        acc.total_ms += g_timing.total_ms;
+        const uint32_t nr = (uint32_t)strand.size();
+        std::vector<uint32_t> lab(nr);
+        std::vector<double> pst((size_t)nr * stride);
+        std::vector<jtk_lc_result_t> rs(nb);
+        std::vector<uint8_t> cs(sub->tmpl_bytes + 8), os(sub->ops_bytes + 8);
+        std::vector<uint64_t> coff(nb + 1), ofo(nr + 1);
+        std::vector<ChunkState> sst(nb);
+        rc = jtk_lc_session_fetch(sub, lab.data(), pst.data(), rs.data(), cs.data(), coff.data(), cs.size(), os.data(),
+                                  ofo.data(), os.size());
+        if (rc != 0 && rc != JTK_ERR_CHUNK_FAILED) return rc;
+        HIP_TRY(hipMemcpy(sst.data(), sub->d_state.p, sst.size() * sizeof(ChunkState), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < nb; b++) {
+            SplitChunk &w = *waiting[b];
+            SplitFrame &f = w.stack.back();
+            f.have = true;
+            f.own.status = rs[b].status;
+            if (rs[b].status != 0) continue;
+            rng_skip(w.rng, sst[b].draws);
+            f.own.k = rs[b].cluster_num;
+            f.own.score = rs[b].score;
+            f.cons.assign(cs.begin() + coff[b], cs.begin() + coff[b + 1]);
+            const uint32_t first = (uint32_t)chunks[b].read_first;
+            for (uint32_t r = 0; r < chunks[b].n_reads; r++) {
+                f.own.asn.push_back(lab[first + r]);
+                for (uint32_t t = 0; t < f.own.k; t++) f.own.post.push_back(pst[(size_t)(first + r) * stride + t]);
+                f.cops.emplace_back(os.begin() + ofo[first + r], os.begin() + ofo[first + r + 1]);
+            }
+        }
+    }
+    (void)BASES;
+    g_timing = acc;
+    return 0;
 }
 
 int jtk_lc_session_destroy(jtk_lc_session_t *s) {
@@ -687,7 +1061,7 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
     launch_mcmc(s->stream, (uint32_t)n_chunks, d_chunks.as<ChunkMeta>(), d_state.as<ChunkState>(),
                 d_params.as<jtk_lc_params_t>(), d_var.as<double>(), d_vt.as<uint32_t>(), d_vtoff.as<uint64_t>(), 1,
                 d_label.as<uint32_t>(), d_post.as<double>(), post_stride, d_lg.as<double>(), d_lgoff.as<uint64_t>(),
-                max_n, max_d);
+                max_n, max_d, nullptr);
     HIP_TRY(hipEventRecord(ev1, s->stream));
     HIP_TRY(hipMemcpyAsync(sts.data(), d_state.p, sts.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(label, d_label.p, n_reads * 4, hipMemcpyDeviceToHost, s->stream));

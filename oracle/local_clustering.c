@@ -11,6 +11,7 @@
 #include <omp.h>
 #endif
 
+#include "jtk_math.h"
 #include "jtk_oracle.h"
 
 static double now_ms(void) {
@@ -22,13 +23,176 @@ static double now_ms(void) {
 /* ReadType::band_width (definitions/src/lib.rs:201-210) */
 static size_t band_width_of(double frac, size_t len) { return (size_t)ceil((double)len * frac); }
 
+
+/* ---- clustering_recursive (mod.rs:125-189) ------------------------------------------------------------ */
+#define UPPER_COPY_NUM 8 /* mod.rs:85 */
+#define BRANCH_NUM 4     /* mod.rs:139 */
+
+/* estim_copy_num (mod.rs:223-243): every cluster gets one copy, each remaining copy goes to the cluster
+ * whose read count is farthest from coverage * copies (max_by keeps the LAST maximum). */
+static void estim_copy_num(const size_t *asn, size_t n, size_t k, size_t copy_num, double coverage,
+                           size_t *copy_numbers) {
+    double counts[BRANCH_NUM] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n; i++) counts[asn[i]] += 1.0;
+    for (size_t c = 0; c < k; c++) copy_numbers[c] = 1;
+    for (size_t it = k; it < copy_num; it++) {
+        size_t arg = 0;
+        double best = 0.0;
+        for (size_t c = 0; c < k; c++) {
+            double d = counts[c] - coverage * (double)copy_numbers[c];
+            double v = d * d; /* powi(2) */
+            if (c == 0 || !(v < best)) {
+                best = v;
+                arg = c;
+            }
+        }
+        copy_numbers[arg] += 1;
+    }
+}
+
+/* One call of clustering_recursive.  assign[n]; *post_out = malloc'd n x (*k_out) log-posteriors.
+ * ops are read-only here (the split branch polishes clones, mod.rs:152-155). Returns 0 or a jtk status. */
+static int clustering_recursive(const jtk_lc_params_t *params, const uint8_t *cons, size_t cl, size_t n,
+                                const uint8_t *const *reads, const size_t *read_len, uint8_t *const *ops,
+                                const size_t *ops_len, size_t ops_cap, const uint8_t *strands, jo_rng_t *rng,
+                                const jo_cluster_config_t *cfg, size_t *assign, double **post_out,
+                                double *score_out, size_t *k_out, size_t *nv_out) {
+    *post_out = NULL;
+    if (cfg->copy_num < UPPER_COPY_NUM) {
+        size_t kcap = cfg->copy_num > 1 ? cfg->copy_num : 1;
+        double *pk = (double *)malloc((n ? n : 1) * kcap * sizeof(double));
+        size_t nv = 0;
+        int rc = jo_clustering(cons, cl, n, reads, read_len, (const uint8_t *const *)ops, ops_len, strands, rng,
+                               &params->forward, &params->reverse, cfg, assign, pk, score_out, k_out, &nv);
+        if (nv_out) *nv_out = nv;
+        if (rc != 0) {
+            free(pk);
+            return JTK_ERR_CHUNK_FAILED;
+        }
+        *post_out = pk;
+        return 0;
+    }
+    jo_cluster_config_t rec = *cfg;
+    rec.copy_num = BRANCH_NUM; /* mod.rs:140-141 */
+    double *pk = (double *)malloc((n ? n : 1) * BRANCH_NUM * sizeof(double));
+    double score = 0;
+    size_t k = 1, nv = 0;
+    int rc = jo_clustering(cons, cl, n, reads, read_len, (const uint8_t *const *)ops, ops_len, strands, rng,
+                           &params->forward, &params->reverse, &rec, assign, pk, &score, &k, &nv);
+    if (nv_out) *nv_out = nv;
+    if (rc != 0) {
+        free(pk);
+        return JTK_ERR_CHUNK_FAILED;
+    }
+    if (k <= 1) { /* mod.rs:146-148 */
+        *post_out = pk;
+        *score_out = score;
+        *k_out = k;
+        return 0;
+    }
+    size_t copy_numbers[BRANCH_NUM];
+    estim_copy_num(assign, n, k, cfg->copy_num, cfg->coverage, copy_numbers);
+    size_t *sub_asn[BRANCH_NUM] = {0};
+    double *sub_post[BRANCH_NUM] = {0};
+    size_t sub_k[BRANCH_NUM] = {0};
+    double sub_scores = 0.0;
+    int status = 0;
+    for (size_t c = 0; c < k && status == 0; c++) {
+        /* filter_sub_clusters (mod.rs:198-221) */
+        size_t m = 0;
+        for (size_t i = 0; i < n; i++) m += assign[i] == c;
+        const uint8_t **sreads = (const uint8_t **)malloc((m ? m : 1) * sizeof(*sreads));
+        size_t *srlen = (size_t *)malloc((m ? m : 1) * sizeof(size_t));
+        uint8_t **sops = (uint8_t **)malloc((m ? m : 1) * sizeof(*sops));
+        size_t *solen = (size_t *)malloc((m ? m : 1) * sizeof(size_t));
+        uint8_t *sstr = (uint8_t *)malloc(m ? m : 1);
+        size_t j = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (assign[i] != c) continue;
+            sreads[j] = reads[i];
+            srlen[j] = read_len[i];
+            solen[j] = ops_len[i];
+            sops[j] = (uint8_t *)malloc(ops_cap + 8);
+            memcpy(sops[j], ops[i], ops_len[i]);
+            sstr[j] = strands[i];
+            j++;
+        }
+        sub_asn[c] = (size_t *)malloc((m ? m : 1) * sizeof(size_t));
+        double sc = 0.0;
+        if (copy_numbers[c] < 2) {
+            /* clustering() returns before it looks at the consensus (pseudo_mcmc.rs:86-88) and draws nothing:
+             * the polish of mod.rs:153-155 cannot reach the result, so it is not run here */
+            for (size_t i = 0; i < m; i++) sub_asn[c][i] = 0;
+            sub_post[c] = (double *)calloc(m ? m : 1, sizeof(double));
+            sub_k[c] = 1;
+        } else {
+            /* HMMPolishConfig::new(band_width, seqs.len(), 0) with the clustering config's band (mod.rs:153) */
+            size_t ccap = cl + cl / 4 + 64;
+            uint8_t *scons = (uint8_t *)malloc(ccap + 8);
+            int64_t scl = jo_phmm_polish(&params->forward, &params->reverse, cons, cl, m, sreads, srlen, sops, solen,
+                                         ops_cap, sstr, cfg->band_width, m, 0, scons, ccap, NULL);
+            if (scl < 0)
+                status = JTK_ERR_CHUNK_FAILED;
+            else {
+                jo_cluster_config_t sub = *cfg;
+                sub.copy_num = copy_numbers[c]; /* mod.rs:156-157 */
+                status = clustering_recursive(params, scons, (size_t)scl, m, sreads, srlen, sops, solen, ops_cap,
+                                              sstr, rng, &sub, sub_asn[c], &sub_post[c], &sc, &sub_k[c], NULL);
+            }
+            free(scons);
+        }
+        sub_scores += sc;
+        for (size_t i = 0; i < m; i++) free(sops[i]);
+        free(sreads);
+        free(srlen);
+        free(sops);
+        free(solen);
+        free(sstr);
+    }
+    if (status == 0) {
+        /* merge (mod.rs:161-187) */
+        size_t offsets[BRANCH_NUM], total = 0, pointers[BRANCH_NUM] = {0, 0, 0, 0};
+        for (size_t c = 0; c < k; c++) {
+            offsets[c] = total;
+            total += sub_k[c];
+        }
+        double *merged = (double *)malloc((n ? n : 1) * total * sizeof(double));
+        for (size_t i = 0; i < n && status == 0; i++) {
+            size_t a = assign[i], pt = pointers[a]++;
+            const double *in_ps = sub_post[a] + pt * sub_k[a];
+            double *po = merged + i * total;
+            size_t w = 0;
+            for (size_t c = 0; c < k; c++) {
+                double lk = pk[i * k + c] - jtk_log((double)sub_k[c]);
+                for (size_t t = 0; t < sub_k[c]; t++) po[w++] = lk;
+            }
+            for (size_t t = 0; t < sub_k[a]; t++) po[t + offsets[a]] += in_ps[t] + jtk_log((double)sub_k[a]);
+            double sum = 0.0;
+            for (size_t t = 0; t < total; t++) sum += jtk_exp(po[t]);
+            if (!(fabs(1.0 - sum) < 0.0001)) status = JTK_ERR_CHUNK_FAILED; /* assert, mod.rs:184 */
+            assign[i] = offsets[a] + sub_asn[a][pt];
+        }
+        if (status == 0) {
+            *post_out = merged;
+            *score_out = sub_scores + score;
+            *k_out = total;
+        } else
+            free(merged);
+    }
+    for (size_t c = 0; c < BRANCH_NUM; c++) {
+        free(sub_asn[c]);
+        free(sub_post[c]);
+    }
+    free(pk);
+    return status;
+}
+
 int jo_clustering_on_pileup(const jtk_lc_params_t *params, uint64_t chunk_id, size_t copy_num,
                             const uint8_t *tmpl, size_t tl, size_t n, const uint8_t *const *reads,
                             const size_t *read_len, uint8_t **ops, size_t *ops_len, size_t ops_cap,
                             const uint8_t *strands, int skip_polish, size_t *assign, double *post,
                             size_t post_stride, uint8_t *cons, size_t cons_cap, jo_chunk_result_t *res) {
     memset(res, 0, sizeof *res);
-    if (copy_num >= 8) return JTK_ERR_UNSUPPORTED; /* clustering_recursive split branch, mod.rs:138-189 */
     double t0 = now_ms();
     size_t band_width = band_width_of(params->band_frac, tl);
     jo_rng_t rng;
@@ -59,12 +223,11 @@ int jo_clustering_on_pileup(const jtk_lc_params_t *params, uint64_t chunk_id, si
     cfg.coverage = params->haploid_coverage;
     cfg.copy_num = copy_num;
     cfg.local_coverage = per_cluster_cov;
-    size_t kcap = copy_num > 1 ? copy_num : 1;
-    double *pk = (double *)malloc((n ? n : 1) * kcap * sizeof(double));
+    double *pk = NULL;
     double score = 0;
     size_t k = 1, nv = 0;
-    int rc = jo_clustering(cons, (size_t)cl, n, reads, read_len, (const uint8_t *const *)ops, ops_len, strands,
-                           &rng, &params->forward, &params->reverse, &cfg, assign, pk, &score, &k, &nv);
+    int rc = clustering_recursive(params, cons, (size_t)cl, n, reads, read_len, ops, ops_len, ops_cap, strands, &rng,
+                                  &cfg, assign, &pk, &score, &k, &nv); /* mod.rs:113-114 */
     if (rc == 0) {
         for (size_t i = 0; i < n; i++) {
             for (size_t c = 0; c < post_stride; c++) post[i * post_stride + c] = 0.0;

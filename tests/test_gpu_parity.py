@@ -181,10 +181,46 @@ def test_edge_cases(lib):
     assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
     assert dev["result"]["cluster_num"][0] == 1 and dev["result"]["cluster_num"][1] == 1
     assert np.abs(dev["log_post"] - ora["log_post"]).max() < TOL
-    # copy_num >= 8 is reported, not silently mis-handled
+    # copy_num >= 8 on a small diploid pile-up: the split branch finds one cluster and returns it (mod.rs:146-148)
     b.chunks["copy_num"][2] = 8
-    out = api.cluster_chunks(p, b, raise_on_chunk_failure=False)
-    assert out["rc"] == -6 and out["result"]["status"][2] == -3
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b)
+    assert np.array_equal(dev["label"], ora["label"])
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert np.abs(dev["log_post"] - ora["log_post"]).max() < TOL
+
+
+@pytest.mark.parametrize("tmpl_len,rph,div,n_haps,copy_num", [(600, 10, 2e-2, 8, 9), (800, 12, 1e-2, 8, 8),
+                                                              (800, 10, 2e-2, 10, 12)])
+def test_recursive_split_matches_oracle(lib, tmpl_len, rph, div, n_haps, copy_num):
+    """copy_num >= 8: clustering_recursive's split branch (mod.rs:138-189) -- a 4-way clustering, then per group a
+    consensus polish and a clustering with the group's share of the copies, all on one RNG stream per chunk;
+    copy_num 12 nests a second split.  The last chunk keeps its reads but is declared diploid, so that split and
+    plain chunks share a batch."""
+    b, cfg, p = helpers.small_batch(config="ont_4copy", n_chunks=4, tmpl_len=tmpl_len, reads_per_hap=rph,
+                                    n_haps=n_haps, copy_num=copy_num, divergence=div, min_variants=3)
+    b.chunks["copy_num"][3] = 2
+    ora = O.cluster_chunks(helpers.oracle_params(p), b)
+    assert ora["rc"] == 0
+    assert ora["result"]["cluster_num"][:3].max() > 4, "the inputs must exercise the merge of sub-clusterings"
+    dev = api.cluster_chunks(p, b)
+    assert np.array_equal(dev["label"], ora["label"])
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert np.abs(dev["log_post"] - ora["log_post"]).max() < TOL
+    assert np.abs(dev["result"]["score"] - ora["result"]["score"]).max() < TOL
+    n = int(dev["cons_off"][-1])
+    assert np.array_equal(dev["cons_off"], ora["cons_off"]) and bytes(dev["cons"][:n]) == bytes(ora["cons"][:n])
+    m = int(dev["ops_out_off"][-1])
+    assert np.array_equal(dev["ops_out"][:m], ora["ops_out"][:m])
+    for c in range(b.n_chunks):
+        k = int(dev["result"][c]["cluster_num"])
+        rows = dev["log_post"][list(b.chunk_reads(c))][:, :k]
+        assert np.abs(np.log(np.exp(rows).sum(axis=1))).max() < 1e-4       # mod.rs:184-185
+    # a second run of the same session repeats the recursion from the chunk seeds
+    with api.Session(p, b) as s:
+        s.run()
+        again = s.fetch()
+    assert np.array_equal(again["label"], dev["label"]) and np.array_equal(again["log_post"], dev["log_post"])
 
 
 def test_session_is_repeatable_and_matches_one_shot(lib):
