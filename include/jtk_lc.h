@@ -192,6 +192,16 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks,
 
 /* ---- host-side helpers (no GPU needed) ------------------------------------------------------------ */
 
+/* ---- stage preamble: gains calibration ------------------------------------------------------------
+ * Replaces `estimate_gain(hmm, seed, seq_len, band, homop_len)` (likelihood_gains.rs:162-184); the stage
+ * calls it through `estimate_gain_default` = (hmm, 309423, 100, 10, 3) (likelihood_gains.rs:186-192,
+ * local_clustering/mod.rs:60).  Per (type, homopolymer length) profile: 100 simulated variant pairs x 100
+ * simulated reads, every read scored against both members of its pair with the banded pair-HMM
+ * (likelihood_antidiagonal_bootstrap); the sampling runs on the host, the bootstrap alignments and the
+ * likelihoods on the device.  `out` is what jtk_lc_params_t.gains expects. */
+int jtk_lc_estimate_gains(const jtk_hmm_t *forward, const jtk_hmm_t *reverse, uint64_t seed, uint32_t seq_len,
+                          uint32_t band, uint32_t homop_len, jtk_gains_t *out, int device);
+
 /* Sort key of pileup_nodes (mod.rs:47-50): number of alignment columns that are not '|' in
  * Node::recover (definitions/src/lib.rs:773-813) for run-length cigar ops given per base. */
 int jtk_lc_pileup_sort_key(const uint8_t *tmpl, uint64_t tmpl_len, const uint8_t *read, uint64_t read_len,

@@ -71,6 +71,14 @@ def modification_table(params, tmpl, reads, ops, strands, device=0):
     return table, lk
 
 
+def estimate_gains(hmm_forward, hmm_reverse, seed=309423, seq_len=100, band=10, homop_len=3, device=0):
+    """jtk_lc_estimate_gains; the defaults are estimate_gain_default's (likelihood_gains.rs:186-192)."""
+    out = ffi.Gains()
+    check(ffi.lib().jtk_lc_estimate_gains(C.byref(hmm_forward), C.byref(hmm_reverse), seed, seq_len, band, homop_len,
+                                          C.byref(out), device))
+    return out
+
+
 def cluster_features(params, feature_chunks, variants, variant_type, post_stride, device=0,
                      raise_on_chunk_failure=True):
     """jtk_lc_cluster_features: cluster_filtered_variants + posterior on caller-supplied feature matrices."""

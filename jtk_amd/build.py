@@ -10,7 +10,7 @@ OUT_DIR = os.path.join(PKG, "_build")
 OUT = os.path.join(OUT_DIR, "libjtk_lc.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["phmm_kernels.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip", "session.hip",
+SOURCES = ["phmm_kernels.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip", "session.hip", "gains.hip",
            "host_api.cpp", "synth.cpp"]
 # -ffp-contract=off: device f64 arithmetic must round exactly like the reference (no implicit fma);
 # the pair-HMM specification uses explicit fma() where it wants one.

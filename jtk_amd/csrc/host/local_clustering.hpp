@@ -10,9 +10,11 @@
 // this header is how the host logic around the ABI (mod.rs:33-83, 244-260; normalize.rs; misc.rs:177-225,
 // 394-407) is exercised end to end (tests/test_host_mirror.py).
 //
-// Two preambles of local_clustering_selected need kiley and therefore stay with the caller:
-//   ds.update_models_on_both_strands()   (mod.rs:58, model_tune.rs:96-156)  -> ds.model_param is used as given
-//   estimate_gain_default(&hmm)          (mod.rs:60)                        -> LocalClusteringOptions::gains
+// The preambles of local_clustering_selected:
+//   ds.update_models_on_both_strands()   (mod.rs:58, model_tune.rs:96-156)  needs kiley's Baum-Welch and stays with
+//                                                                            the caller: ds.model_param is used as given
+//   estimate_gain_default(&hmm)          (mod.rs:60)                        jtk_lc_estimate_gains on the device, unless
+//                                                                            LocalClusteringOptions::gains supplies them
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -86,7 +88,7 @@ struct DataSet {  // definitions/src/lib.rs:6-34 (fields the stage reads or writ
 
 struct LocalClusteringOptions {
     int device = 0;
-    const jtk_gains_t *gains = nullptr;  // result of estimate_gain_default (likelihood_gains.rs:186-192)
+    const jtk_gains_t *gains = nullptr;  // optional: a cached result of estimate_gain_default (likelihood_gains.rs:186-192)
 };
 
 inline double band_frac(ReadType t) {  // definitions/src/lib.rs:173-175, 201-210
@@ -166,11 +168,15 @@ inline void normalize_local_clustering(DataSet &ds) {
 inline void local_clustering_selected(DataSet &ds, const std::unordered_set<uint64_t> &selection,
                                       const LocalClusteringOptions &opt = LocalClusteringOptions()) {
     update_coverage(ds);  // mod.rs:57
-    if (!opt.gains) throw std::invalid_argument("LocalClusteringOptions::gains (estimate_gain_default) is required");
     jtk_lc_params_t params;
     params.forward = ds.model_param.forward;  // mod.rs:59 (refit of mod.rs:58 is the caller's, see header)
     params.reverse = ds.model_param.reverse;
-    params.gains = *opt.gains;  // mod.rs:60
+    if (opt.gains) {
+        params.gains = *opt.gains;
+    } else {  // mod.rs:60: estimate_gain_default = estimate_gain(hmm, 309423, 100, 10, 3)
+        const int rc = jtk_lc_estimate_gains(&params.forward, &params.reverse, 309423, 100, 10, 3, &params.gains, opt.device);
+        if (rc != 0) throw std::runtime_error(std::string("jtk_lc_estimate_gains: ") + jtk_lc_last_error());
+    }
     params.haploid_coverage = ds.coverage.unwrap();
     params.band_frac = band_frac(ds.read_type);
     // pileup_nodes (mod.rs:33-53): nodes of the selected chunks in order of appearance, then a STABLE sort by

@@ -777,11 +777,21 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
     double lk = get_lk(tg, np, cl, posm, infm);
     double max = lk;
     const uint32_t total = 2000u * n;
+#ifdef JTK_MCMC_STATS
+    unsigned long long gs[6] = {0, 0, 0, 0, 0, 0};
+#define GS_MARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); gs[k] += now_ - gs_t; gs_t = now_; }
+#else
+#define GS_MARK(k)
+#endif
     for (uint32_t t = 0; t < total; t++) {
+#ifdef JTK_MCMC_STATS
+        unsigned long long gs_t = __builtin_readcyclecounter();
+#endif
         const uint32_t idx = (uint32_t)gen_range_usize(rng, n);
         const uint32_t old = lab_get<SMALL>(assign, idx);
         const uint32_t pos = choose_pos(rng, K);
         const uint32_t nw = pos < old ? pos : pos + 1;
+        GS_MARK(0);
         Elem el = {0.0, 0, 0};
         if (lane < D) el = elem_of(m.data[idx * D + lane]);
         // ---- tentative flip (:764-783): only the two touched clusters change
@@ -818,14 +828,20 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
         double proposed = 0.0;
         bool accept = false, decided = false, have_v = false;
         uint64_t v = 0;
+        GS_MARK(1);
         const double dA = unif64(approx_lk(T, P, ncl, npm, nim) - lk);
+        GS_MARK(2);
         if (ubool(dA < -1e-3)) {
             v = next_u64(rng);
             have_v = true;
             const float u = (float)(uint32_t)(v >> 40) * 0x1p-24f;  // v / 2^64 within 2^-24
             decided = ubool(dA <= -44.5 || u > __expf((float)dA) * 1.001f + 3e-7f);  // certainly rejected
         }
+        GS_MARK(3);
         if (!decided) {
+#ifdef JTK_MCMC_STATS
+            gs[5]++;
+#endif
             proposed = get_lk(T, P, ncl, npm, nim);
             const double diff = unif64(proposed - lk);
             // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
@@ -857,7 +873,13 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
                 if ((uint32_t)c == nw) tg[c] = T[c] - el.x;
             }
         }
+        GS_MARK(4);
     }
+#ifdef JTK_MCMC_STATS
+    if (lane == 0)
+        printf("GENSTAT K %d n %u D %u steps %u draws %llu flip %llu approx %llu decide %llu tail %llu exact %llu\n", K, n, D,
+               total, gs[0], gs[1], gs[2], gs[3], gs[4], gs[5]);
+#endif
     wsync();
 #pragma unroll
     for (int r = 0; r < (SMALL ? 1 : 4); r++) {

@@ -999,6 +999,46 @@ int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl
     return 0;
 }
 
+
+// log P(read | template) of every read of a resident batch with a fixed band radius: band_prep + the forward
+// sweep of phmm_kernel (the backward sweep runs too and is ignored; these batches are tiny).  Used by the
+// gains calibration (gains.hip), which evaluates kiley's likelihood_antidiagonal_bootstrap 180,000 times.
+int jtk_internal_likelihoods(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                             const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                             const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t radius,
+                             int device, double *lk_out) {
+    std::vector<ChunkExtra> extra(n_chunks);
+    for (auto &e : extra) {
+        memset(&e, 0, sizeof e);
+        e.radius = radius;
+    }
+    jtk_lc_session_t *s = nullptr;
+    int rc = session_create_ex(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, 1, device,
+                               extra.data(), 0, &s);
+    if (rc) return rc;
+    std::unique_ptr<jtk_lc_session> guard(s);
+    hipStream_t st = s->stream;
+    ChunkState *state = s->d_state.as<ChunkState>();
+    HIP_TRY(hipMemcpyAsync(state, s->h_state0.data(), s->h_state0.size() * sizeof(ChunkState), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_tmpl0.p, s->d_tmpl_init.p, s->tmpl_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_ops0.p, s->d_ops_init.p, s->ops_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_opslen0.p, s->d_opslen_init.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToDevice, st));
+    launch_band_prep(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
+                     s->d_delta.as<uint64_t>(), 0);
+    launch_phmm(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
+                s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(), s->d_scratch.as<double>(),
+                s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(), s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
+    std::vector<ChunkState> cs(n_chunks);
+    HIP_TRY(hipMemcpyAsync(cs.data(), state, cs.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(lk_out, s->d_lk.p, (size_t)s->n_reads * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    for (const ChunkState &c : cs)
+        if (c.status != 0) return fail(c.status, "likelihood batch failed (ops mismatch or unsupported band)");
+    return 0;
+}
+
 int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_feature_chunk_t *chunks,
                             const double *variants, const uint32_t *variant_type, uint32_t *label, double *log_post,
                             uint32_t post_stride, jtk_lc_result_t *result, int device) {
@@ -1089,6 +1129,7 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
 }
 
 const char *jtk_lc_last_error(void) { return g_last_error.c_str(); }
+void jtk_internal_set_error(const char *msg) { g_last_error = msg ? msg : ""; }
 
 int jtk_lc_last_timing(jtk_lc_timing_t *out) {
     if (!out) return JTK_ERR_INVALID_ARG;

@@ -19,13 +19,14 @@ static std::string cigar_string(const jtk::Ops &ops) {  // Display for Ops, defi
 
 int main(int argc, char **argv) {
     if (argc < 6) {
-        fprintf(stderr, "usage: %s n_chunks tmpl_len reads_per_hap gains_file(18 doubles) n_selected\n", argv[0]);
+        fprintf(stderr, "usage: %s n_chunks tmpl_len reads_per_hap gains_file(18 doubles; '-' = estimate on the device) n_selected\n", argv[0]);
         return 2;
     }
     const int n_chunks = atoi(argv[1]), tmpl_len = atoi(argv[2]), rph = atoi(argv[3]), n_selected = atoi(argv[5]);
     jtk_gains_t gains{};
     gains.max_homopolymer_len = 3;
-    {
+    const bool device_gains = std::string(argv[4]) == "-";  // mod.rs:60 inside the stage call
+    if (!device_gains) {
         FILE *f = fopen(argv[4], "r");
         if (!f) return 3;
         jtk_gain_profile_t *rows[3] = {gains.subst, gains.deletions, gains.insertions};
@@ -82,7 +83,7 @@ int main(int argc, char **argv) {
         }
     }
     jtk::LocalClusteringOptions opt;
-    opt.gains = &gains;
+    opt.gains = device_gains ? nullptr : &gains;
     try {
         if (n_selected >= n_chunks) {
             jtk::local_clustering(ds, opt);

@@ -68,6 +68,28 @@ def test_modification_table_rejects_inconsistent_ops(lib):
     assert e.value.status == -5
 
 
+@pytest.mark.parametrize("seed,seq_len,band,homop_len", [(309423, 100, 10, 3), (77, 60, 8, 2)])
+def test_estimate_gains_matches_oracle(lib, seed, seq_len, band, homop_len):
+    """the stage preamble estimate_gain (likelihood_gains.rs:162-192): host sampling, device bootstrap alignments and
+    banded likelihoods, against the oracle's all-CPU restatement -- gains and null probabilities of all 9 profiles"""
+    import ctypes as C
+    p = jb.default_params(haploid_coverage=30.0)
+    if seed != 309423:                     # strands with different models (update_models_on_both_strands fits two)
+        p.reverse.mat_mat -= 0.01
+        p.reverse.mat_del += 0.01
+    dev = api.estimate_gains(p.forward, p.reverse, seed, seq_len, band, homop_len)
+    po = helpers.oracle_params(p)
+    ora = O.Gains()
+    O.lib().jo_estimate_gain(C.byref(po.forward), C.byref(po.reverse), seed, seq_len, band, homop_len, C.byref(ora))
+    assert dev.max_homopolymer_len == ora.max_homopolymer_len == homop_len
+    for name in ("subst", "deletions", "insertions"):
+        for h in range(homop_len):
+            d, o = getattr(dev, name)[h], getattr(ora, name)[h]
+            assert abs(d.gain - o.gain) < TOL and abs(d.prob - o.prob) < TOL, (name, h, d.gain, o.gain, d.prob, o.prob)
+            assert d.gain == o.gain and d.prob == o.prob      # this build: identical bits
+            assert d.gain > 0.0 and 1e-9 <= d.prob <= 1.0
+
+
 def random_feature_problem(rng, n, dim, k_true, cid, copy_num):
     """feature matrix shaped like search_variants output: +gain for carriers, -gain otherwise, some zeros"""
     lab = rng.integers(0, k_true, n)

@@ -108,6 +108,9 @@ def test_compute_fails_loudly_without_gpu(jtk_lib):
     assert e.value.status == -2
     with pytest.raises(ffi.JtkError):
         api.Session(p, b)
+    with pytest.raises(ffi.JtkError) as e:
+        api.estimate_gains(p.forward, p.reverse)
+    assert e.value.status == -2
 
 
 def test_invalid_arguments_are_rejected(jtk_lib):

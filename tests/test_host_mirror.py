@@ -49,8 +49,10 @@ def runs_of(ops):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_selected", [3, 2])
-def test_host_mirror_matches_oracle(jtk_lib, tmp_path, n_selected):
+@pytest.mark.parametrize("n_selected,device_gains", [(3, False), (2, False), (3, True)])
+def test_host_mirror_matches_oracle(jtk_lib, tmp_path, n_selected, device_gains):
+    """device_gains: the stage call runs estimate_gain_default itself (mod.rs:60, jtk_lc_estimate_gains); the result
+    must be the golden gains the other cases read from a file"""
     assert jtk_lib.jtk_lc_device_ok(0) == 1
     exe = build_driver()
     n_chunks, tmpl_len, rph = 3, 400, 8
@@ -59,7 +61,7 @@ def test_host_mirror_matches_oracle(jtk_lib, tmp_path, n_selected):
         for name in ("subst", "deletions", "insertions"):
             for g, p in jb.DEFAULT_GAINS[name]:
                 f.write(f"{g!r} {p!r}\n")
-    out = subprocess.run([exe, str(n_chunks), str(tmpl_len), str(rph), str(gains_file), str(n_selected)],
+    out = subprocess.run([exe, str(n_chunks), str(tmpl_len), str(rph), "-" if device_gains else str(gains_file), str(n_selected)],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     chunks, nodes = {}, {}
