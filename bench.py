@@ -176,6 +176,14 @@ def main():
                     launches_per_step=klaunch[dom] / args.steps,
                     algorithmic_bytes_per_step=alg_bytes_per_step,
                     all_kernels_ms_per_step={n: ktime[n] / args.steps for n in ffi.KERNEL_NAMES},
+                    # measured HBM traffic (committed PMC passes) of every kernel family against its live device time:
+                    # what each family actually moves, as opposed to the algorithmic bytes above
+                    hbm_traffic_by_kernel={
+                        n: dict(ms_per_step=ktime[n] / args.steps, launches_per_step=klaunch[n] / args.steps,
+                                traffic_bytes_per_launch=pmc_traffic(n, args.workload, n_chunks),
+                                traffic_GBps=(pmc_traffic(n, args.workload, n_chunks) * klaunch[n] / 1e9 / (ktime[n] / 1e3)
+                                              if pmc_traffic(n, args.workload, n_chunks) and ktime[n] > 0 else None))
+                        for n in ffi.KERNEL_NAMES},
                     note="byte/integer + f64 scan work: HBM-compulsory traffic is ~126 KB/chunk, so the HBM fraction "
                          "is tiny by construction; the binding limits are the serial Metropolis chain latency and "
                          "FP64 VALU in the banded pair-HMM (DESIGN.md)")

@@ -99,14 +99,15 @@ __device__ __forceinline__ void rng_wait_rec(Rng &r, uint32_t upto) {  // until 
 __device__ __forceinline__ void rng_release(Rng &r, uint32_t lane) {  // draws before r.pos may be overwritten
     if (lane == 0) lds_st32(&r.ctl->rd, r.pos);
 }
+__device__ __forceinline__ void rng_refill(Rng &r) {  // the register window: 64 draws from r.pos on, one per lane
+    r.win_base = r.pos;
+    lds_st32(&r.ctl->rd, r.pos);  // every lane stores the same value: draws before r.pos may be overwritten
+    rng_wait(r, r.pos + 64);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    r.win = lds_ld64(&r.ring[ring_slot(r.pos + (threadIdx.x & 63u))]);
+}
 __device__ __forceinline__ uint64_t next_u64(Rng &r) {
-    if ((uint32_t)(r.pos - r.win_base) >= 64u) {  // refill: 64 draws from r.pos on, one per lane
-        r.win_base = r.pos;
-        lds_st32(&r.ctl->rd, r.pos);  // every lane stores the same value: draws before r.pos may be overwritten
-        rng_wait(r, r.pos + 64);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        r.win = lds_ld64(&r.ring[ring_slot(r.pos + (threadIdx.x & 63u))]);
-    }
+    if ((uint32_t)(r.pos - r.win_base) >= 64u) rng_refill(r);
     const uint32_t off = r.pos - r.win_base;
     const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(r.win >> 32), (int)off) << 32) |
                        (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)r.win, (int)off);
@@ -783,13 +784,62 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
 #else
 #define GS_MARK(k)
 #endif
+    // Proposals are parsed from the 64-draw register window, not draw by draw.  A proposal is gen_range(0..n) -- the
+    // first draw at or after its start whose widening product passes the zone test -- and then, for i = 1..K-1,
+    // gen_index(i) on the upper halves of the following draws, each with its own zone test; the pick is the last i
+    // whose index came out 0 (choose_pos).  Which draws pass which test, and which give index 0, depends on the draws
+    // only: one ballot each per window, after which a proposal is a few scalar shift / find-first-set steps instead of
+    // ~6 rejection loops on values that have to cross from the vector to the scalar side one at a time.
+    uint32_t wp_base = 0xfffffff0u, wp_hi = 0;
+    unsigned long long wp_ok0 = 0, wp_ok[K], wp_z[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) wp_ok[i] = wp_z[i] = 0;
+    const uint64_t zone_n = ((uint64_t)n << __clzll((long long)n)) - 1;
     for (uint32_t t = 0; t < total; t++) {
 #ifdef JTK_MCMC_STATS
         unsigned long long gs_t = __builtin_readcyclecounter();
 #endif
-        const uint32_t idx = (uint32_t)gen_range_usize(rng, n);
+        uint32_t idx = 0, pos = 0;
+        {
+            uint32_t off = rng.pos - rng.win_base;
+            if (off >= 40u) {  // keep 24 draws of look-ahead: reload the window at the current position
+                rng_refill(rng);
+                off = 0;
+            }
+            if (wp_base != rng.win_base) {
+                const uint64_t v = rng.win;
+                const uint32_t v32 = (uint32_t)(v >> 32);
+                wp_hi = (uint32_t)__umul64hi(v, (uint64_t)n);
+                wp_ok0 = __ballot(v * (uint64_t)n <= zone_n);
+#pragma unroll
+                for (int i = 1; i < K; i++) {
+                    const uint32_t zone = ((uint32_t)i << __builtin_clz((uint32_t)i)) - 1u;
+                    const uint64_t mi = (uint64_t)v32 * (uint32_t)i;
+                    wp_ok[i] = __ballot((uint32_t)mi <= zone);
+                    wp_z[i] = __ballot((uint32_t)(mi >> 32) == 0u);
+                }
+                wp_base = rng.win_base;
+            }
+            const unsigned long long m0 = wp_ok0 >> off;
+            bool good = m0 != 0ull;
+            const uint32_t p0 = off + (uint32_t)__builtin_ctzll(m0 | (1ull << 63));
+            uint32_t q = p0;
+#pragma unroll
+            for (int i = 1; i < K; i++) {
+                const unsigned long long mm = (good && q < 63u) ? wp_ok[i] >> (q + 1u) : 0ull;
+                good = good && mm != 0ull;
+                q = (q + 1u + (uint32_t)__builtin_ctzll(mm | (1ull << 63))) & 63u;
+                if ((wp_z[i] >> q) & 1ull) pos = (uint32_t)i - 1u;
+            }
+            if (good) {
+                idx = (uint32_t)__builtin_amdgcn_readlane((int)wp_hi, (int)p0);
+                rng.pos = rng.win_base + q + 1u;
+            } else {  // the proposal runs past the window: draw by draw
+                idx = (uint32_t)gen_range_usize(rng, n);
+                pos = choose_pos(rng, K);
+            }
+        }
         const uint32_t old = lab_get<SMALL>(assign, idx);
-        const uint32_t pos = choose_pos(rng, K);
         const uint32_t nw = pos < old ? pos : pos + 1;
         GS_MARK(0);
         Elem el = {0.0, 0, 0};
