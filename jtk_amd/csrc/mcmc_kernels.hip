@@ -24,6 +24,7 @@
 //    ((tg - x) + x, not a restore); get_lk's left-to-right sum visits only the non-zero terms.
 // Sums that the reference evaluates left to right are evaluated left to right here -- integer labels only
 // match if every f64 rounding matches.
+#include <mutex>
 #include <vector>
 
 #include "device_common.h"
@@ -1842,9 +1843,8 @@ V256 m_apply(const M256 &a, const V256 &v) {
 void m_mul(const M256 &a, const M256 &b, M256 &out) {  // out = a * b
     for (int i = 0; i < 256; i++) out.col[i] = m_apply(a, b.col[i]);
 }
-const std::vector<uint64_t> &jump_table_host() {
-    static std::vector<uint64_t> tab;
-    if (!tab.empty()) return tab;
+std::vector<uint64_t> build_jump_table() {
+    std::vector<uint64_t> tab;
     auto *m = new M256, *acc = new M256, *tmp = new M256;
     for (int b = 0; b < 256; b++) {
         V256 e{{0, 0, 0, 0}};
@@ -1873,11 +1873,25 @@ const std::vector<uint64_t> &jump_table_host() {
     delete tmp;
     return tab;
 }
+const std::vector<uint64_t> &jump_table_host() {  // sessions run on several host threads: initialised exactly once
+    static const std::vector<uint64_t> tab = build_jump_table();
+    return tab;
+}
+std::mutex g_jump_mutex;
+bool g_jump_uploaded[64];  // per device ordinal
 }  // namespace
 
+// The table is a constant of the generator: uploaded once per device, synchronously, before the first chain kernel.
 int mcmc_upload_jump_table(hipStream_t s) {
+    (void)s;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    std::lock_guard<std::mutex> lock(g_jump_mutex);
+    if (g_jump_uploaded[dev]) return 0;
     const std::vector<uint64_t> &tab = jump_table_host();
-    return (int)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_jump_tab), tab.data(), tab.size() * 8, 0, hipMemcpyHostToDevice, s);
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_jump_tab), tab.data(), tab.size() * 8, 0, hipMemcpyHostToDevice);
+    if (e == hipSuccess) g_jump_uploaded[dev] = true;
+    return (int)e;
 }
 
 void launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,

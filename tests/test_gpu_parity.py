@@ -245,6 +245,35 @@ def test_recursive_split_matches_oracle(lib, tmpl_len, rph, div, n_haps, copy_nu
     assert np.array_equal(again["label"], dev["label"]) and np.array_equal(again["log_post"], dev["log_post"])
 
 
+def test_concurrent_sessions_match_one_shot(lib):
+    """sessions are independent (own stream, own workspaces): four of them driven from four host threads, as bench.py
+    does to overlap one batch's chain tail with another's pair-HMM passes, give the one-shot results"""
+    import threading
+    b, cfg, p = helpers.small_batch(n_chunks=6, tmpl_len=500, reads_per_hap=10)
+    one = api.cluster_chunks(p, b)
+    sessions = [api.Session(p, b) for _ in range(4)]
+    errors = []
+
+    def worker(s):
+        try:
+            for _ in range(3):
+                s.run()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in sessions]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    for s in sessions:
+        out = s.fetch()
+        for k in ("label", "log_post", "cons", "ops_out"):
+            assert np.array_equal(out[k], one[k])
+        s.close()
+
+
 def test_session_is_repeatable_and_matches_one_shot(lib):
     b, cfg, p = helpers.small_batch(n_chunks=3, tmpl_len=400, reads_per_hap=8)
     one = api.cluster_chunks(p, b)
