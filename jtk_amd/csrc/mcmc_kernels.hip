@@ -46,11 +46,16 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 }
 
 // The ring of raw xoshiro256** outputs.  `wr` draws have been produced, the consumer has released `rd`.
-#define RN 4096  // draws in the ring (32 KiB): two superblocks of the producer
+#ifndef JTK_MCMC_SEG_LOG
+#define JTK_MCMC_SEG_LOG 4
+#endif
+#define SEG (1 << JTK_MCMC_SEG_LOG)  // draws per producer lane per superblock
+#define SBLK (64 * SEG)              // draws per superblock
+#define RN (2 * SBLK)                // draws in the ring: two superblocks of the producer
 // stream position -> ring slot.  Inside a superblock, draw j of segment g sits at j * 64 + ((g + j) & 63): the
 // producer's 64 lanes (one segment each) and the consumer's 64-draw windows (consecutive j) both hit distinct banks.
 __device__ __forceinline__ uint32_t ring_slot(uint32_t pos) {
-    const uint32_t o = pos & (RN / 2 - 1), g = o >> 5, j = o & 31;
+    const uint32_t o = pos & (RN / 2 - 1), g = o >> JTK_MCMC_SEG_LOG, j = o & (SEG - 1);
     return (pos & (RN / 2)) | (j * 64 + ((g + j) & 63));
 }
 struct RCtl {
@@ -459,8 +464,6 @@ __device__ __forceinline__ uint32_t choose_pos(Rng &r, uint32_t k) {
 // lane's segment and has to skip the other 63 segments: multiplication of the 256-bit state by the constant matrix
 // M^(63*SEG), done as 128 two-bit look-ups in a 16 KiB table (g_jump_tab, computed once on the host from the step
 // function itself, staged in LDS) XOR-ed together.  The sequence of draws is exactly that of the sequential generator.
-#define SEG 32              // draws per lane per superblock
-#define SBLK (64 * SEG)     // draws per superblock
 static_assert(RN == 2 * SBLK, "the ring holds two superblocks");
 __device__ ulonglong2 g_jump_tab[128 * 4 * 2];  // [2-bit digit position][digit] -> 256-bit column sum of M^(63*SEG)
 #define JUMP_TAB_BYTES (128 * 4 * 32)           // 16 KiB, copied into LDS by every workgroup
