@@ -691,6 +691,21 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
             }
         size_to_lk.v[r] = mx;
     }
+    // Pile-ups of more than 255 reads (high copy numbers: 8 copies x 40 reads) do not fit the four-register tables:
+    // sizes and labels then live in LDS (m.size_to_lk, m.assign in place, m.argmax), one extra round trip per look-up.
+    const bool big = !SMALL && n > 255u;
+    if (big) {
+        for (uint32_t x = lane; x <= n; x += 64) {
+            double mx = -__builtin_inf();
+            for (int c = 1; c <= K; c++) {
+                const double lam = cov * (double)c;
+                mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
+            }
+            m.size_to_lk[x] = mx;
+        }
+        wsync();
+    }
+    auto size_lk = [&](uint32_t x) -> double { return big ? unif64(m.size_to_lk[x]) : tab_get<SMALL>(size_to_lk, x); };
     // ---- initial LKCounts in the reference's order (reads outer)
     double tg[K];
     int np[K], w[K], cl[K];
@@ -730,13 +745,17 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
         assign.v[r] = i < n ? (int)m.assign[i] : 0;
         argmax.v[r] = assign.v[r];
     }
+    if (big) {
+        for (uint32_t i = lane; i < n; i += 64) m.argmax[i] = m.assign[i];
+        wsync();
+    }
     // get_lk (:785-795) on a tentative state: size terms first, then clusters outer / columns inner, left to
     // right; exactly-zero terms (unused column or total_gain <= 0) leave the f64 sum unchanged and are skipped.
     auto get_lk = [&](const double *T, const int *P, const int *cls, const unsigned long long *pm,
                       const unsigned long long *im) -> double {
         double S = 0.0;
 #pragma unroll
-        for (int c = 0; c < K; c++) S += tab_get<SMALL>(size_to_lk, (uint32_t)cls[c]);
+        for (int c = 0; c < K; c++) S += size_lk((uint32_t)cls[c]);
         int in_use = 0;
         unsigned long long anym = 0;
 #pragma unroll
@@ -764,7 +783,7 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
                          const unsigned long long *im) -> double {
         double S = 0.0;
 #pragma unroll
-        for (int c = 0; c < K; c++) S += tab_get<SMALL>(size_to_lk, (uint32_t)cls[c]);
+        for (int c = 0; c < K; c++) S += size_lk((uint32_t)cls[c]);
         int in_use = 0;
         unsigned long long anym = 0;
 #pragma unroll
@@ -843,7 +862,7 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
                 pos = choose_pos(rng, K);
             }
         }
-        const uint32_t old = lab_get<SMALL>(assign, idx);
+        const uint32_t old = big ? uni((uint32_t)m.assign[idx]) : lab_get<SMALL>(assign, idx);
         const uint32_t nw = pos < old ? pos : pos + 1;
         GS_MARK(0);
         Elem el = {0.0, 0, 0};
@@ -913,11 +932,20 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
                 posm[c] = npm[c];
                 infm[c] = nim[c];
             }
-            lab_set<SMALL>(assign, idx, nw, lane);
+            if (big) {
+                if (lane == 0) m.assign[idx] = (uint8_t)nw;
+                wsync();
+            } else {
+                lab_set<SMALL>(assign, idx, nw, lane);
+            }
             lk = proposed;
             if (ubool(max < lk)) {
                 max = proposed;
                 argmax = assign;
+                if (big) {
+                    for (uint32_t i = lane; i < n; i += 64) m.argmax[i] = m.assign[i];
+                    wsync();
+                }
             }
         } else {
             // flip back (:746): the reference re-adds / re-subtracts, which leaves rounding residue
@@ -935,10 +963,14 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
                total, gs[0], gs[1], gs[2], gs[3], gs[4], gs[5]);
 #endif
     wsync();
+    if (big) {
+        for (uint32_t i = lane; i < n; i += 64) m.assign[i] = m.argmax[i];
+    } else {
 #pragma unroll
-    for (int r = 0; r < (SMALL ? 1 : 4); r++) {
-        const uint32_t i = lane + 64 * r;
-        if (i < n) m.assign[i] = (uint8_t)argmax.v[r];
+        for (int r = 0; r < (SMALL ? 1 : 4); r++) {
+            const uint32_t i = lane + 64 * r;
+            if (i < n) m.assign[i] = (uint8_t)argmax.v[r];
+        }
     }
     wsync();
     return max;
@@ -1616,7 +1648,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         }
         return;
     }
-    if (copy_num > JTK_MAX_COPY || n > 255 || n > lds_n || D > lds_d) {
+    if (copy_num > JTK_MAX_COPY || n > JTK_MAX_PILEUP || n > lds_n || D > lds_d) {
         if (threadIdx.x == 0) st->status = JTK_ERR_UNSUPPORTED;
         return;
     }

@@ -213,7 +213,8 @@ def test_edge_cases(lib):
 
 
 @pytest.mark.parametrize("tmpl_len,rph,div,n_haps,copy_num", [(600, 10, 2e-2, 8, 9), (800, 12, 1e-2, 8, 8),
-                                                              (800, 10, 2e-2, 10, 12)])
+                                                              (800, 10, 2e-2, 10, 12),
+                                                              (400, 33, 2e-2, 8, 8)])   # 264 reads: LDS-table chain
 def test_recursive_split_matches_oracle(lib, tmpl_len, rph, div, n_haps, copy_num):
     """copy_num >= 8: clustering_recursive's split branch (mod.rs:138-189) -- a 4-way clustering, then per group a
     consensus polish and a clustering with the group's share of the copies, all on one RNG stream per chunk;
@@ -238,6 +239,8 @@ def test_recursive_split_matches_oracle(lib, tmpl_len, rph, div, n_haps, copy_nu
         k = int(dev["result"][c]["cluster_num"])
         rows = dev["log_post"][list(b.chunk_reads(c))][:, :k]
         assert np.abs(np.log(np.exp(rows).sum(axis=1))).max() < 1e-4       # mod.rs:184-185
+    if rph > 30:
+        return       # (the large pile-ups spend ~100 s in the generic chain: one run is enough)
     # a second run of the same session repeats the recursion from the chunk seeds
     with api.Session(p, b) as s:
         s.run()
@@ -302,6 +305,25 @@ def test_chain_variants_match_oracle(lib):
     assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
     assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(ora["log_post"]))
     assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(ora["result"]["score"]))
+
+
+def test_large_pileups_match_oracle(lib):
+    """more than 255 reads (7 copies x 40 reads, or the first pass of a copy_num >= 8 chunk): the generic chain with its
+    per-read and per-size tables in LDS instead of registers; 256 and 511 are the edges of that mode"""
+    p = jb.default_params(haploid_coverage=40.0)
+    specs = [(256, 4, 2, 2), (300, 6, 3, 3), (511, 3, 2, 2), (255, 4, 3, 3)]   # ~40 s: the generic chain is slow
+    dev, ora, truth = run_features_both(p, specs, seed=19)
+    assert np.array_equal(dev["result"]["status"], np.zeros(len(specs), np.int32))
+    assert np.array_equal(dev["label"], ora["label"])
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(ora["log_post"]))
+    assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(ora["result"]["score"]))
+    # one more read than the kernel takes is reported, not mis-clustered
+    x, vt, _ = random_feature_problem(np.random.default_rng(3), 512, 3, 2, 0, 2)
+    ch = np.zeros(1, dtype=ffi.FEATURE_CHUNK_DT)
+    ch[0] = (5, 2, 512, 3, 0, 0, 0, 0, 256.0)
+    out = api.cluster_features(p, ch, x.ravel(), vt.ravel().astype(np.uint32), 2, raise_on_chunk_failure=False)
+    assert out["rc"] == -6 and out["result"]["status"][0] == -3
 
 
 def test_size_only_moves_match_oracle(lib):
