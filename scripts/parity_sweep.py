@@ -1,5 +1,5 @@
 """Diagnostic (GPU box): randomized feature-level parity sweep of the chain kernels against the CPU oracle --
-labels, posteriors and scores bit for bit.  `python scripts/parity_sweep.py [n_seeds]`"""
+labels, posteriors and scores bit for bit.  `python scripts/parity_sweep.py [n_seeds] [first_seed]`"""
 import sys
 import numpy as np
 import torch  # noqa: F401  (first: see bench.py)
@@ -10,8 +10,9 @@ import test_gpu_parity as T  # noqa: E402
 from jtk_amd import batch as jb  # noqa: E402
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+first_seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 bad = total = 0
-for seed in range(100, 100 + n_seeds):
+for seed in range(first_seed, first_seed + n_seeds):
     rng = np.random.default_rng(seed)
     specs = []
     for _ in range(14):
