@@ -212,8 +212,7 @@ def test_edge_cases(lib):
     assert np.abs(dev["log_post"] - ora["log_post"]).max() < TOL
 
 
-@pytest.mark.parametrize("tmpl_len,rph,div,n_haps,copy_num", [(600, 10, 2e-2, 8, 9), (800, 12, 1e-2, 8, 8),
-                                                              (800, 10, 2e-2, 10, 12),
+@pytest.mark.parametrize("tmpl_len,rph,div,n_haps,copy_num", [(600, 10, 2e-2, 8, 9), (800, 10, 2e-2, 10, 12),
                                                               (400, 33, 2e-2, 8, 8)])   # 264 reads: LDS-table chain
 def test_recursive_split_matches_oracle(lib, tmpl_len, rph, div, n_haps, copy_num):
     """copy_num >= 8: clustering_recursive's split branch (mod.rs:138-189) -- a 4-way clustering, then per group a
