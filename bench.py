@@ -137,7 +137,12 @@ def main():
     # CUs that another batch's chain kernel leaves idle during its long tail.  Step s runs on session s % streams;
     # every session holds the same synthetic batch, so every step does the same work as with --streams 1.
     n_streams = max(1, min(args.streams, args.steps))
-    sessions = [api.Session(params, batch, device=local_rank) for _ in range(n_streams)]
+    free0 = torch.cuda.mem_get_info(local_rank)[0]
+    sessions = [api.Session(params, batch, device=local_rank)]
+    per_session = free0 - torch.cuda.mem_get_info(local_rank)[0]      # every workspace is allocated up front
+    while len(sessions) < n_streams and torch.cuda.mem_get_info(local_rank)[0] > 1.25 * per_session:
+        sessions.append(api.Session(params, batch, device=local_rank))
+    n_streams = len(sessions)                                         # fewer in flight when HBM is the limit (cfg 3/4)
     sess = sessions[0]
     gathered = None
     ktime = {n: 0.0 for n in ffi.KERNEL_NAMES}
