@@ -1,0 +1,201 @@
+"""File-level drop-in for the stage: `DataSet` JSON in, `DataSet` JSON out.
+
+JTK passes ONE JSON object between its stages (definitions/src/lib.rs:6-35; `jtk ... > x.encoded.json`,
+`jtk local_clustering < x.encoded.json > x.clustered.json`, cli/src/pipeline.rs:153-159).  This module reads that
+object, runs `LocalClustering::local_clustering{,_selected}` (haplotyper/src/local_clustering/mod.rs:17-83) through
+the C ABI and writes the object back; every field the stage does not touch is passed through as parsed.
+
+    python -m jtk_amd.dataset in.encoded.json out.clustered.json [--chunks id,id,...] [--device 0]
+
+Wire format of the fields the stage reads or writes (serde derives of definitions/src/lib.rs):
+  coverage         "NotAvailable" | {"Protected": f64} | {"Estimated": f64}          (:46-55, externally tagged enum)
+  read_type        "CCS" | "CLR" | "ONT" | "None"                                     (:156-162)
+  model_param      {"forward": HMMParam, "reverse": HMMParam}; HMMParam = 9 transition fields + mat_emit[16] +
+                   ins_emit[20]                                                        (:95-126)
+  selected_chunks  [{"id", "seq": "ACGT..", "cluster_num", "copy_num", "score"}]       (:403-415, DNASeq as a string)
+  encoded_reads    [{.., "nodes": [{"position_from_start", "chunk", "cluster", "seq": "ACGT..", "is_forward",
+                   "cigar": "10M2D3I", "posterior": [f64]}]}]                          (:672-683, Ops as a string :825-877)
+
+One preamble is NOT run here: `update_models_on_both_strands` (mod.rs:58, model_tune.rs:96-156) needs kiley's
+Baum-Welch; `model_param` is used as found in the file.  The gains calibration (mod.rs:60) runs on the device
+(`jtk_lc_estimate_gains`).  This is the same host logic as the C++ mirror `csrc/host/local_clustering.hpp`; the two
+are tested against each other (tests/test_dataset_json.py)."""
+import argparse
+import ctypes as C
+import json
+import re
+import sys
+
+import numpy as np
+
+from . import api, ffi
+from .batch import pack, pileup_sort
+
+BAND_FRAC = {"CCS": 0.01, "ONT": 0.03, "CLR": 0.05, "None": 0.05}   # definitions/src/lib.rs:173-175
+_OP_RE = re.compile(r"(\d+)([MDI])")
+_OP_CODE = {"M": ffi.OP_MATCH, "D": ffi.OP_DEL, "I": ffi.OP_INS}
+
+
+def cigar_to_ops(cigar):
+    """Ops::from_str (definitions/src/lib.rs:857-877) + ops_to_kiley (misc.rs:177-186): one op code per base."""
+    out = []
+    pos = 0
+    for m in _OP_RE.finditer(cigar):
+        if m.start() != pos:
+            raise ValueError(f"bad cigar {cigar!r}")
+        out.append(np.full(int(m.group(1)), _OP_CODE[m.group(2)], dtype=np.uint8))
+        pos = m.end()
+    if pos != len(cigar):
+        raise ValueError(f"bad cigar {cigar!r}")
+    return np.concatenate(out) if out else np.zeros(0, np.uint8)
+
+
+def ops_to_cigar(ops):
+    """kiley_op_to_ops (misc.rs:188-225; Match and Mismatch merge into one M run) + Display for Ops (:827-838)."""
+    ops = np.asarray(ops, dtype=np.uint8)
+    if len(ops) == 0:
+        return ""
+    kind = np.where(ops == ffi.OP_DEL, 1, np.where(ops == ffi.OP_INS, 2, 0))
+    cut = np.flatnonzero(np.diff(kind)) + 1
+    starts = np.concatenate([[0], cut])
+    ends = np.concatenate([cut, [len(kind)]])
+    return "".join(f"{e - s}{'MDI'[kind[s]]}" for s, e in zip(starts.tolist(), ends.tolist()))
+
+
+def coverage_of(ds):
+    cov = ds["coverage"]
+    if isinstance(cov, dict):
+        (tag, value), = cov.items()
+        return tag, float(value)
+    return cov, None
+
+
+def update_coverage(ds):
+    """misc.rs:394-407: unless protected, haploid coverage = median node count per chunk / 2."""
+    tag, _ = coverage_of(ds)
+    if tag == "Protected":
+        return
+    counts = {}
+    for read in ds["encoded_reads"]:
+        for node in read["nodes"]:
+            counts[node["chunk"]] = counts.get(node["chunk"], 0) + 1
+    if not counts:
+        raise ValueError("update_coverage: no nodes")
+    c = sorted(counts.values())
+    ds["coverage"] = {"Estimated": c[len(c) // 2] / 2.0}
+
+
+def _hmm(d):
+    h = ffi.Hmm()
+    for name in ("mat_mat", "mat_ins", "mat_del", "ins_mat", "ins_ins", "ins_del", "del_mat", "del_ins", "del_del"):
+        setattr(h, name, float(d[name]))
+    if len(d["mat_emit"]) != 16 or len(d["ins_emit"]) != 20:
+        raise ValueError("HMMParam: mat_emit must have 16 and ins_emit 20 entries")
+    for i, v in enumerate(d["mat_emit"]):
+        h.mat_emit[i] = float(v)
+    for i, v in enumerate(d["ins_emit"]):
+        h.ins_emit[i] = float(v)
+    return h
+
+
+def _seq(s):
+    return np.frombuffer(s.encode("ascii"), dtype=np.uint8)
+
+
+def normalize_local_clustering(ds):
+    """normalize.rs:6-51 over every node of the dataset: clusters relabelled by descending size, posteriors permuted."""
+    L = ffi.lib()
+    piles = {}
+    for read in ds["encoded_reads"]:
+        for node in read["nodes"]:
+            piles.setdefault(node["chunk"], []).append(node)
+    cluster_num = {c["id"]: c["cluster_num"] for c in ds["selected_chunks"]}
+    for cid, nodes in piles.items():
+        if cid not in cluster_num:
+            raise ValueError("normalize_local_clustering: node on an unknown chunk")
+        k = cluster_num[cid]
+        if any(len(n["posterior"]) != k for n in nodes):   # assert_eq!, normalize.rs:27-29
+            raise ValueError("normalize_local_clustering: posterior length != cluster_num")
+        if k == 0:
+            continue
+        label = np.array([n["cluster"] for n in nodes], dtype=np.uint32)
+        post = np.array([n["posterior"] for n in nodes], dtype=np.float64).reshape(len(nodes), k)
+        ffi.check(L.jtk_lc_normalize_pileup(len(nodes), k, ffi.u32p(label), ffi.f64p(post), k))
+        for i, n in enumerate(nodes):
+            n["cluster"] = int(label[i])
+            n["posterior"] = post[i].tolist()
+
+
+def local_clustering_selected(ds, selection, gains=None, device=0):
+    """mod.rs:56-83 on the parsed JSON object `ds` (modified in place)."""
+    update_coverage(ds)                                                       # mod.rs:57
+    params = ffi.Params()
+    params.forward = _hmm(ds["model_param"]["forward"])                       # mod.rs:59 (no refit, see module doc)
+    params.reverse = _hmm(ds["model_param"]["reverse"])
+    params.gains = gains if gains is not None else api.estimate_gains(params.forward, params.reverse, device=device)
+    params.haploid_coverage = coverage_of(ds)[1]
+    params.band_frac = BAND_FRAC[ds["read_type"]]
+    # pileup_nodes (mod.rs:33-53): nodes of the selected chunks in order of appearance, then a stable sort by the
+    # number of non-'|' alignment columns against the unpolished chunk sequence
+    selection = set(selection)
+    chunk_of = {c["id"]: c for c in ds["selected_chunks"] if c["id"] in selection}
+    piles = {cid: [] for cid in chunk_of}
+    for read in ds["encoded_reads"]:
+        for node in read["nodes"]:
+            if node["chunk"] in piles:
+                piles[node["chunk"]].append(node)
+    order = sorted(cid for cid, nodes in piles.items() if nodes)
+    pileups = []
+    for cid in order:
+        chunk, nodes = chunk_of[cid], piles[cid]
+        tmpl = _seq(chunk["seq"])
+        reads = [_seq(n["seq"]) for n in nodes]
+        ops = [cigar_to_ops(n["cigar"]) for n in nodes]
+        perm = pileup_sort(tmpl, reads, ops)
+        piles[cid] = [nodes[i] for i in perm]
+        pileups.append((cid, int(chunk["copy_num"]), tmpl, [reads[i] for i in perm], [ops[i] for i in perm],
+                        [1 if nodes[i]["is_forward"] else 0 for i in perm], None))
+    batch = pack(pileups)
+    out = api.cluster_chunks(params, batch, device=device)                    # the hot loop of mod.rs:64-72
+    # update_by_clusterings (mod.rs:244-260) and the chunk write-back (mod.rs:74-81)
+    for c, cid in enumerate(order):
+        k = int(out["result"][c]["cluster_num"])
+        for r, node in zip(batch.chunk_reads(c), piles[cid]):
+            node["posterior"] = out["log_post"][r, :k].tolist()
+            node["cluster"] = int(out["label"][r])
+            node["cigar"] = ops_to_cigar(out["ops_out"][int(out["ops_out_off"][r]):int(out["ops_out_off"][r + 1])])
+        chunk = chunk_of[cid]
+        chunk["seq"] = bytes(out["cons"][int(out["cons_off"][c]):int(out["cons_off"][c + 1])]).decode("ascii")
+        chunk["score"] = float(out["result"][c]["score"])
+        chunk["cluster_num"] = k
+    normalize_local_clustering(ds)                                            # mod.rs:82
+    return ds
+
+
+def local_clustering(ds, gains=None, device=0):
+    """mod.rs:23-26: every selected chunk."""
+    return local_clustering_selected(ds, [c["id"] for c in ds["selected_chunks"]], gains=gains, device=device)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("input", help="DataSet JSON ('-' = stdin)")
+    ap.add_argument("output", help="DataSet JSON ('-' = stdout)")
+    ap.add_argument("--chunks", default="", help="comma-separated chunk ids (local_clustering_selected); default: all")
+    ap.add_argument("--device", type=int, default=0)
+    args = ap.parse_args(argv)
+    ds = json.load(sys.stdin if args.input == "-" else open(args.input))
+    if args.chunks:
+        local_clustering_selected(ds, [int(x) for x in args.chunks.split(",")], device=args.device)
+    else:
+        local_clustering(ds, device=args.device)
+    text = json.dumps(ds)
+    if args.output == "-":
+        sys.stdout.write(text + "\n")
+    else:
+        with open(args.output, "w") as f:
+            f.write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@ ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "_build", "libjtk_lc.so")
 
 NUM_ROW = 14
+OP_MATCH, OP_MISMATCH, OP_INS, OP_DEL = 0, 1, 2, 3   # enum jtk_op (jtk_lc.h) == kiley::Op
 GAINS_MAX_HOMOP = 8
 K_COUNT = 4
 KERNEL_NAMES = ("phmm", "polish", "filter", "mcmc")

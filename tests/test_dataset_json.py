@@ -1,0 +1,112 @@
+"""The DataSet JSON stage (jtk_amd/dataset.py): wire-format helpers on the CPU; on the GPU the whole stage on a JSON
+object against the C++ host mirror (tests/cpp/host_mirror_main.cpp) fed the same synthetic pile-ups -- two
+independent restatements of mod.rs:33-83 + normalize.rs on top of the same C ABI."""
+import copy
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from jtk_amd import batch as jb, dataset as D, ffi, synth
+
+import test_host_mirror as HM
+
+
+def test_cigar_round_trip_and_match_mismatch_merge():
+    ops = D.cigar_to_ops("3M2D1I4M")
+    assert ops.tolist() == [0, 0, 0, 3, 3, 2, 0, 0, 0, 0]
+    assert D.ops_to_cigar(ops) == "3M2D1I4M"
+    assert D.ops_to_cigar(np.array([0, 1, 1, 0, 3, 2, 2, 1], np.uint8)) == "4M1D2I1M"   # misc.rs:188-225
+    assert D.ops_to_cigar(np.zeros(0, np.uint8)) == "" and len(D.cigar_to_ops("")) == 0
+    with pytest.raises(ValueError):
+        D.cigar_to_ops("3M2X")
+    with pytest.raises(ValueError):
+        D.cigar_to_ops("M3")
+
+
+def test_update_coverage_follows_misc_rs():
+    def ds_with(counts, coverage):
+        reads = [{"nodes": [{"chunk": c} for c, n in counts.items() for _ in range(n)]}]
+        return {"coverage": coverage, "encoded_reads": reads}
+    ds = ds_with({1: 10, 2: 30, 3: 61}, "NotAvailable")
+    D.update_coverage(ds)
+    assert ds["coverage"] == {"Estimated": 15.0}          # median node count / 2 (misc.rs:394-407)
+    ds = ds_with({1: 10, 2: 30}, {"Estimated": 3.0})
+    D.update_coverage(ds)
+    assert ds["coverage"] == {"Estimated": 15.0}          # sorted [10, 30][len / 2] = 30
+    ds = ds_with({1: 10}, {"Protected": 22.5})
+    D.update_coverage(ds)
+    assert ds["coverage"] == {"Protected": 22.5}
+    with pytest.raises(ValueError):
+        D.update_coverage({"coverage": "NotAvailable", "encoded_reads": []})
+
+
+def synthetic_dataset(n_chunks, tmpl_len, rph):
+    """the DataSet host_mirror_main.cpp builds, as the JSON object JTK would write (definitions/src/lib.rs)"""
+    cfg = dict(synth.CONFIGS["ont_diploid"])
+    cfg.update(tmpl_len=tmpl_len, reads_per_hap=rph)
+    hmm = {k: 0.97 if k.endswith("_mat") else 0.01 for k in ("mat_mat", "mat_ins", "mat_del", "ins_mat", "ins_ins",
+                                                            "ins_del", "del_mat", "del_ins", "del_del")}
+    hmm["mat_emit"] = [0.97 if r == q else 0.01 for r in range(4) for q in range(4)]
+    hmm["ins_emit"] = [0.25] * 20
+    reads = [{"id": r, "original_length": 0, "leading_gap": "", "trailing_gap": "", "edges": [], "nodes": []}
+             for r in range(2 * rph)]
+    chunks = []
+    for c in range(n_chunks):
+        cid, cn, tmpl, rs, ops, strands, truth = synth.make_pileup(c, cfg, min_variants=1, sort=False)
+        chunks.append({"id": c, "seq": bytes(tmpl).decode(), "cluster_num": 2, "copy_num": 2, "score": 0.0})
+        for r in range(2 * rph):
+            reads[r]["nodes"].append({"position_from_start": 0, "chunk": c, "cluster": 0, "seq": bytes(rs[r]).decode(),
+                                      "is_forward": bool(strands[r]), "cigar": D.ops_to_cigar(ops[r]),
+                                      "posterior": [math.log(0.5)] * 2})
+    return {"input_file": "synthetic", "masked_kmers": {"k": 0, "thr": 0}, "coverage": {"Protected": float(rph)},
+            "raw_reads": [], "hic_pairs": [], "selected_chunks": chunks, "encoded_reads": reads, "hic_edges": [],
+            "read_type": "ONT", "model_param": {"forward": hmm, "reverse": copy.deepcopy(hmm)},
+            "error_rate": {"del": 0.01, "del_sd": 0.0, "ins": 0.01, "ins_sd": 0.0, "mismatch": 0.01, "mismatch_sd": 0.0,
+                           "total": 0.03, "total_sd": 0.0},
+            "processed_stages": [{"stage_name": "encode", "arg": []}]}
+
+
+def test_untouched_fields_survive_the_json_round_trip(tmp_path):
+    ds = synthetic_dataset(1, 120, 2)
+    text = json.dumps(ds)
+    again = json.loads(text)
+    assert again == ds and again["encoded_reads"][0]["nodes"][0]["cigar"] == ds["encoded_reads"][0]["nodes"][0]["cigar"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_selected", [3, 2])
+def test_json_stage_matches_the_cpp_host_mirror(jtk_lib, tmp_path, n_selected):
+    assert jtk_lib.jtk_lc_device_ok(0) == 1
+    n_chunks, tmpl_len, rph = 3, 400, 8
+    ds = synthetic_dataset(n_chunks, tmpl_len, rph)
+    src, dst = tmp_path / "in.json", tmp_path / "out.json"
+    src.write_text(json.dumps(ds))
+    argv = [str(src), str(dst)] + (["--chunks", ",".join(str(c) for c in range(n_selected))] if n_selected < n_chunks else [])
+    D.main(argv)                                      # gains: estimate_gain_default on the device (mod.rs:60)
+    out = json.loads(dst.read_text())
+    exe = HM.build_driver()
+    ref = subprocess.run([exe, str(n_chunks), str(tmpl_len), str(rph), "-", str(n_selected)], capture_output=True, text=True)
+    assert ref.returncode == 0, ref.stderr
+    chunks, nodes = {}, {}
+    for line in ref.stdout.splitlines():
+        f = line.split("\t")
+        if f[0] == "CHUNK":
+            chunks[int(f[1])] = (int(f[2]), float(f[3]), f[4])
+        else:
+            nodes[(int(f[1]), int(f[2]))] = (int(f[3]), f[4], [float(x) for x in f[5:]])
+    for c in out["selected_chunks"]:
+        k, score, seq = chunks[c["id"]]
+        assert (c["cluster_num"], c["seq"]) == (k, seq) and c["score"] == score
+    for r, read in enumerate(out["encoded_reads"]):
+        for node in read["nodes"]:
+            cl, cig, ps = nodes[(r, node["chunk"])]
+            assert (node["cluster"], node["cigar"]) == (cl, cig) and node["posterior"] == ps
+    # everything the stage does not own is passed through
+    for key in ("input_file", "masked_kmers", "raw_reads", "hic_pairs", "hic_edges", "read_type", "model_param",
+                "error_rate", "processed_stages", "coverage"):
+        assert out[key] == ds[key]
