@@ -18,12 +18,18 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "device_common.h"
+
+#define JTK_POOL_DEVICES 16
 
 // launchers defined in the other translation units
 void launch_filter(hipStream_t s, uint32_t n_chunks, const ReadMeta *reads, const ChunkMeta *chunks,
@@ -73,10 +79,51 @@ HmmDev to_dev(const jtk_hmm_t &h) {
     return d;
 }
 
+// Device blocks of destroyed sessions are kept for the next session on the same device: a stage call is one-shot
+// (create, run, fetch, destroy) and is entered several times per pipeline with batches of similar shape, and mapping
+// ~95 GB of workspaces for 2500 chunks costs 1.3 s on a fresh device and up to 3.8 s once the same memory has been
+// freed before (the driver scrubs it) -- more than the kernels take.  Nothing relies on the contents of a fresh
+// block.  jtk_lc_trim_cache() returns everything to the driver.
+struct BlockPool {
+    static const size_t MIN_BYTES = 1u << 20;           // smaller blocks are not worth keeping
+    static const size_t MAX_CACHED = 200ull << 30;      // per device
+    std::mutex m;
+    std::multimap<size_t, void *> blocks[JTK_POOL_DEVICES];
+    size_t cached[JTK_POOL_DEVICES] = {};
+    void *take(int dev, size_t bytes, size_t *cap) {
+        std::lock_guard<std::mutex> lock(m);
+        auto &b = blocks[dev];
+        auto it = b.lower_bound(bytes);
+        if (it == b.end() || it->first > bytes + bytes / 4 + MIN_BYTES) return nullptr;
+        void *p = it->second;
+        *cap = it->first;
+        cached[dev] -= it->first;
+        b.erase(it);
+        return p;
+    }
+    bool give(int dev, void *p, size_t cap) {
+        std::lock_guard<std::mutex> lock(m);
+        if (cap < MIN_BYTES || cached[dev] + cap > MAX_CACHED) return false;
+        blocks[dev].emplace(cap, p);
+        cached[dev] += cap;
+        return true;
+    }
+    void trim(int dev) {
+        std::lock_guard<std::mutex> lock(m);
+        for (auto &kv : blocks[dev]) (void)hipFree(kv.second);
+        blocks[dev].clear();
+        cached[dev] = 0;
+    }
+};
+BlockPool g_pool;
+
 struct DevPtr {
     void *p = nullptr;
+    size_t cap = 0;
+    int dev = -1;
     ~DevPtr() {
-        if (p) (void)hipFree(p);
+        if (!p) return;
+        if (dev < 0 || dev >= JTK_POOL_DEVICES || !g_pool.give(dev, p, cap)) (void)hipFree(p);
     }
     template <typename T>
     T *as() const {
@@ -137,6 +184,7 @@ struct jtk_lc_session {
     DevPtr d_rng;                        // 4 x u64 per chunk: where each chunk's RNG stream resumes (sub-problems only)
     bool resume_rng = false;
     ~jtk_lc_session() {
+        if (stream) (void)hipStreamSynchronize(stream);  // blocks go back to the pool, not through hipFree's implicit sync
         for (auto &t : timers) {
             if (t.a) (void)hipEventDestroy(t.a);
             if (t.b) (void)hipEventDestroy(t.b);
@@ -150,7 +198,24 @@ namespace {
 template <typename T>
 int dev_alloc(DevPtr &d, size_t count) {
     const size_t bytes = (count ? count : 1) * sizeof(T);
-    HIP_TRY(hipMalloc(&d.p, bytes));
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < JTK_POOL_DEVICES && bytes >= BlockPool::MIN_BYTES) {
+        d.p = g_pool.take(dev, bytes, &d.cap);
+        if (d.p) {
+            d.dev = dev;
+            return 0;
+        }
+    }
+    hipError_t e = hipMalloc(&d.p, bytes);
+    if (e == hipErrorOutOfMemory && dev >= 0 && dev < JTK_POOL_DEVICES) {  // cached blocks of another shape are in the way
+        (void)hipGetLastError();
+        g_pool.trim(dev);
+        e = hipMalloc(&d.p, bytes);
+    }
+    HIP_TRY(e);
+    d.cap = bytes;
+    d.dev = dev;
     return 0;
 }
 template <typename T>
@@ -259,12 +324,6 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         st.active = 1;
         st.k = 1;
         if (cm.radius > JTK_MAX_RADIUS) st.status = JTK_ERR_UNSUPPORTED;
-        h_tmpl.resize(tmpl_off + cap, 0);
-        for (uint32_t p = 0; p < tl; p++) {
-            const int code = base_code(tmpl_bases[ch.tmpl_off + p]);
-            if (code < 0) return fail(JTK_ERR_INVALID_ARG, "non-ACGT base in a template");
-            h_tmpl[tmpl_off + p] = (uint8_t)code;
-        }
         h_homop_off[c] = tmpl_off;
         h_aux_off[c] = aux_off;
         h_lg_off[c] = lg_off;
@@ -283,20 +342,6 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
             rm.table_off = table_off;
             rm.raw_off = raw_off;
             rm.row_off = row_off;
-            h_ey.resize(ey_off + rl + 1, 0);
-            int prev = 4;
-            for (uint64_t j = 0; j < rl; j++) {
-                const int code = base_code(read_bases[read_off[g] + j]);
-                if (code < 0) return fail(JTK_ERR_INVALID_ARG, "non-ACGT base in a read");
-                h_ey[ey_off + j + 1] = (uint8_t)(code | (prev << 2));
-                prev = code;
-            }
-            h_ops.resize(ops_cap_off + rm.ops_cap, 0);
-            for (uint64_t k = 0; k < ol; k++) {
-                const uint8_t op = ops[ops_off[g] + k];
-                if (op > JTK_OP_DEL) return fail(JTK_ERR_INVALID_ARG, "bad op code");
-                h_ops[ops_cap_off + k] = op;
-            }
             h_opslen[g] = (uint32_t)ol;
             if (rl > s->max_read) s->max_read = (uint32_t)rl;
             ey_off += rl + 1;
@@ -317,6 +362,56 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         feat_off += (uint64_t)ch.n_reads * JTK_MAX_DIM;
         aux_off += (uint64_t)3 * H * (ch.n_reads + 1) + (ch.n_reads + 1) + (JTK_MAX_COPY + 2);
         lg_off += (uint64_t)ch.n_reads * (JTK_MAX_COPY + 1);
+    }
+    // ---- per-base encoding (2-bit template codes, read codes with their context, op validation): the layout above
+    //      fixed every offset, so the chunks are encoded side by side on the host's cores
+    h_tmpl.assign(tmpl_off, 0);
+    h_ey.assign(ey_off, 0);
+    h_ops.assign(ops_cap_off, 0);
+    {
+        std::atomic<int> bad(0);
+        std::atomic<size_t> next(0);
+        auto encode = [&]() {
+            for (size_t c = next.fetch_add(1); c < n_chunks && !bad.load(std::memory_order_relaxed); c = next.fetch_add(1)) {
+                const jtk_lc_chunk_t &ch = chunks[c];
+                const ChunkMeta &cm = s->h_chunks[c];
+                for (uint64_t p = 0; p < ch.tmpl_len; p++) {
+                    const int code = base_code(tmpl_bases[ch.tmpl_off + p]);
+                    if (code < 0) bad = 1;
+                    h_tmpl[cm.tmpl_off + p] = (uint8_t)(code & 3);
+                }
+                for (uint32_t r = 0; r < ch.n_reads; r++) {
+                    const uint64_t g = cm.read_first + r;
+                    const ReadMeta &rm = s->h_reads[g];
+                    const uint8_t *rb = read_bases + read_off[g];
+                    uint8_t *ey = h_ey.data() + rm.ey_off;
+                    int prev = 4;
+                    for (uint32_t j = 0; j < rm.read_len; j++) {
+                        const int code = base_code(rb[j]);
+                        if (code < 0) bad = 2;
+                        ey[j + 1] = (uint8_t)((code & 3) | (prev << 2));
+                        prev = code & 3;
+                    }
+                    const uint8_t *src = ops + ops_off[g];
+                    uint8_t *dst = h_ops.data() + rm.ops_off;
+                    uint8_t worst = 0;
+                    for (uint32_t k = 0; k < h_opslen[g]; k++) {
+                        dst[k] = src[k];
+                        worst |= src[k];
+                    }
+                    if (worst > JTK_OP_DEL) bad = 3;   // op codes are 0..3
+                }
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t n_workers = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), std::max<size_t>(n_chunks / 16, 1));
+        std::vector<std::thread> workers;
+        for (size_t w = 1; w < n_workers; w++) workers.emplace_back(encode);
+        encode();
+        for (auto &w : workers) w.join();
+        if (bad == 1) return fail(JTK_ERR_INVALID_ARG, "non-ACGT base in a template");
+        if (bad == 2) return fail(JTK_ERR_INVALID_ARG, "non-ACGT base in a read");
+        if (bad == 3) return fail(JTK_ERR_INVALID_ARG, "bad op code");
     }
     s->tmpl_bytes = h_tmpl.size();
     s->ops_bytes = h_ops.size();
@@ -917,11 +1012,11 @@ int jtk_lc_session_destroy(jtk_lc_session_t *s) {
     return 0;
 }
 
-static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
-                    const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off, const uint8_t *ops,
-                    const uint64_t *ops_off, const uint8_t *strand, int skip_polish, uint32_t *label, double *log_post,
-                    uint32_t post_stride, jtk_lc_result_t *result, uint8_t *cons_out, uint64_t *cons_off,
-                    uint64_t cons_cap, uint8_t *ops_out, uint64_t *ops_out_off, uint64_t ops_cap, int device) {
+static int run_slice(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                     const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off, const uint8_t *ops,
+                     const uint64_t *ops_off, const uint8_t *strand, int skip_polish, uint32_t *label, double *log_post,
+                     uint32_t post_stride, jtk_lc_result_t *result, uint8_t *cons_out, uint64_t *cons_off,
+                     uint64_t cons_cap, uint8_t *ops_out, uint64_t *ops_out_off, uint64_t ops_cap, int device) {
     jtk_lc_session_t *s = nullptr;
     int rc = jtk_lc_session_create(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand,
                                    post_stride, device, &s);
@@ -932,6 +1027,122 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
     const std::string keep = g_last_error;
     jtk_lc_session_destroy(s);
     g_last_error = keep;
+    return rc;
+}
+
+// The one-shot entry points on a large batch: up to three slices of the batch run as independent sessions on their own streams
+// and host threads, so that one slice's pair-HMM passes fill the CUs another slice's chain kernel leaves idle during
+// its tail (the overlap bench.py gets from four resident batches, §6 of DESIGN.md).  Chunks are independent (the RNG
+// is seeded per chunk), so the results do not depend on the slicing.  A slice keeps >= 500 chunks: below that the
+// tail of its own chain kernel is all there is to hide.  JTK_LC_SLICES overrides the count (tests, tuning).
+static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                    const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off, const uint8_t *ops,
+                    const uint64_t *ops_off, const uint8_t *strand, int skip_polish, uint32_t *label, double *log_post,
+                    uint32_t post_stride, jtk_lc_result_t *result, uint8_t *cons_out, uint64_t *cons_off,
+                    uint64_t cons_cap, uint8_t *ops_out, uint64_t *ops_out_off, uint64_t ops_cap, int device) {
+    size_t n_slices = std::min<size_t>(3, n_chunks / 500);  // 2500 chunks: 2.48 s unsliced, 2.21 / 2.12 s in 2 / 3 slices
+    if (const char *e = getenv("JTK_LC_SLICES")) n_slices = (size_t)atoi(e);
+    if (n_slices > n_chunks) n_slices = n_chunks;
+    if (n_slices < 2 || !params || !chunks || !read_off || !ops_off || !label || !log_post || !result)
+        return run_slice(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, skip_polish, label,
+                         log_post, post_stride, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap, device);
+    g_last_error.clear();
+    uint64_t n_reads = 0;
+    for (size_t c = 0; c < n_chunks; c++) {
+        if (chunks[c].read_first != n_reads) return fail(JTK_ERR_INVALID_ARG, "chunks must list their reads contiguously in order");
+        n_reads += chunks[c].n_reads;
+    }
+    // slice boundaries: equal shares of the reads
+    std::vector<size_t> first(n_slices + 1, n_chunks);
+    first[0] = 0;
+    {
+        size_t sl = 1;
+        uint64_t seen = 0;
+        for (size_t c = 0; c < n_chunks && sl < n_slices; c++) {
+            seen += chunks[c].n_reads;
+            if (seen * n_slices >= n_reads * sl) first[sl++] = c + 1;
+        }
+    }
+    const bool want_cons = cons_out && cons_off, want_ops = ops_out && ops_out_off;
+    struct Slice {
+        std::vector<jtk_lc_chunk_t> chunks;
+        std::vector<uint8_t> cons, ops;
+        std::vector<uint64_t> cons_off, ops_off;
+        int rc = 0;
+        std::string error;
+        jtk_lc_timing_t timing;
+    };
+    std::vector<Slice> slices(n_slices);
+    std::vector<std::thread> threads;
+    for (size_t sl = 0; sl < n_slices; sl++) {
+        Slice &S = slices[sl];
+        const size_t c0 = first[sl], c1 = first[sl + 1];
+        memset(&S.timing, 0, sizeof S.timing);
+        if (c0 >= c1) continue;
+        const uint64_t r0 = chunks[c0].read_first, r1 = chunks[c1 - 1].read_first + chunks[c1 - 1].n_reads;
+        S.chunks.assign(chunks + c0, chunks + c1);
+        uint64_t cons_need = 64, ops_need = 64;
+        for (auto &ch : S.chunks) {
+            ch.read_first -= r0;
+            cons_need += ch.tmpl_len + ch.tmpl_len / 4 + 64;
+            ops_need += (uint64_t)ch.n_reads * (ch.tmpl_len / 4 + 72);
+        }
+        ops_need += ops_off[r1] - ops_off[r0];
+        if (want_cons) {
+            S.cons.resize(cons_need);
+            S.cons_off.resize(c1 - c0 + 1);
+        }
+        if (want_ops) {
+            S.ops.resize(ops_need);
+            S.ops_off.resize(r1 - r0 + 1);
+        }
+        threads.emplace_back([=, &S]() {
+            S.rc = run_slice(params, c1 - c0, S.chunks.data(), tmpl_bases, read_bases, read_off + r0, ops, ops_off + r0,
+                             strand + r0, skip_polish, label + r0, log_post + r0 * post_stride, post_stride, result + c0,
+                             want_cons ? S.cons.data() : nullptr, want_cons ? S.cons_off.data() : nullptr, S.cons.size(),
+                             want_ops ? S.ops.data() : nullptr, want_ops ? S.ops_off.data() : nullptr, S.ops.size(), device);
+            S.error = g_last_error;   // thread-local in the slice's thread
+            S.timing = g_timing;
+        });
+    }
+    for (auto &t : threads) t.join();
+    // stitch the variable-length outputs together in chunk order
+    int rc = 0;
+    uint64_t co = 0, oo = 0;
+    memset(&g_timing, 0, sizeof g_timing);
+    for (size_t sl = 0; sl < n_slices; sl++) {
+        Slice &S = slices[sl];
+        const size_t c0 = first[sl], c1 = first[sl + 1];
+        if (c0 >= c1) continue;
+        if (S.rc != 0 && (rc == 0 || rc == JTK_ERR_CHUNK_FAILED)) {
+            rc = S.rc;
+            g_last_error = S.error;
+        }
+        if (S.rc != 0 && S.rc != JTK_ERR_CHUNK_FAILED) continue;
+        const uint64_t r0 = chunks[c0].read_first, nr = chunks[c1 - 1].read_first + chunks[c1 - 1].n_reads - r0;
+        if (want_cons) {
+            const uint64_t len = S.cons_off[c1 - c0];
+            if (co + len > cons_cap) return fail(JTK_ERR_INVALID_ARG, "cons_cap too small");
+            memcpy(cons_out + co, S.cons.data(), len);
+            for (size_t c = c0; c < c1; c++) cons_off[c] = co + S.cons_off[c - c0];
+            co += len;
+        }
+        if (want_ops) {
+            const uint64_t len = S.ops_off[nr];
+            if (oo + len > ops_cap) return fail(JTK_ERR_INVALID_ARG, "ops_cap too small");
+            memcpy(ops_out + oo, S.ops.data(), len);
+            for (uint64_t g = 0; g <= nr; g++) ops_out_off[r0 + g] = oo + S.ops_off[g];
+            oo += len;
+        }
+        g_timing.h2d_ms += S.timing.h2d_ms;
+        g_timing.d2h_ms += S.timing.d2h_ms;
+        g_timing.total_ms = std::max(g_timing.total_ms, S.timing.total_ms);   // the slices run side by side
+        for (int k = 0; k < JTK_K_COUNT; k++) {
+            g_timing.kernel_ms[k] += S.timing.kernel_ms[k];
+            g_timing.kernel_launches[k] += S.timing.kernel_launches[k];
+        }
+    }
+    if (want_cons) cons_off[n_chunks] = co;
     return rc;
 }
 
@@ -1126,6 +1337,16 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
         if (sts[c].status != 0) any_fail = 1;
     }
     return any_fail ? fail(JTK_ERR_CHUNK_FAILED, "at least one chunk failed; see result[].status") : 0;
+}
+
+int jtk_lc_trim_cache(int device) {
+    if (device < 0 || device >= JTK_POOL_DEVICES) return JTK_ERR_INVALID_ARG;
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return JTK_ERR_NO_DEVICE;
+    (void)hipSetDevice(device);
+    g_pool.trim(device);
+    (void)hipSetDevice(cur);
+    return 0;
 }
 
 const char *jtk_lc_last_error(void) { return g_last_error.c_str(); }

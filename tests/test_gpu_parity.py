@@ -276,6 +276,29 @@ def test_concurrent_sessions_match_one_shot(lib):
         s.close()
 
 
+@pytest.mark.parametrize("n_slices", [2, 3, 7])
+def test_one_shot_slicing_does_not_change_results(lib, monkeypatch, n_slices):
+    """jtk_lc_cluster_chunks runs a large batch as up to four slices on their own streams and host threads (>= 500
+    chunks each); JTK_LC_SLICES forces that path on a small ragged batch: every output, including the stitched
+    consensus / ops offsets, must equal the unsliced call"""
+    b, cfg, p = helpers.small_batch(n_chunks=7, tmpl_len=350, reads_per_hap=6)
+    b.chunks["copy_num"][2] = 1          # a trivial chunk inside a slice
+    monkeypatch.setenv("JTK_LC_SLICES", "1")
+    whole = api.cluster_chunks(p, b)
+    whole_pol = api.cluster_polished(p, b)
+    monkeypatch.setenv("JTK_LC_SLICES", str(n_slices))
+    sliced = api.cluster_chunks(p, b)
+    for k in ("label", "log_post", "cons", "cons_off", "ops_out", "ops_out_off"):
+        assert np.array_equal(sliced[k], whole[k]), k
+    for f in ("score", "cluster_num", "status", "polish_rounds", "n_variants"):
+        assert np.array_equal(sliced["result"][f], whole["result"][f]), f
+    sliced_pol = api.cluster_polished(p, b)
+    assert np.array_equal(sliced_pol["label"], whole_pol["label"])
+    assert np.array_equal(sliced_pol["log_post"], whole_pol["log_post"])
+    t = api.last_timing()
+    assert t["kernel_launches"]["mcmc"] == min(n_slices, 7)
+
+
 def test_session_is_repeatable_and_matches_one_shot(lib):
     b, cfg, p = helpers.small_batch(n_chunks=3, tmpl_len=400, reads_per_hap=8)
     one = api.cluster_chunks(p, b)
