@@ -779,11 +779,22 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
     // The same quantity without the ordering (any order of the same terms: off by ~1e-12 at most).  The ordered sum
     // costs a v_readlane + a dependent add per term; this costs one cross-lane reduction, and it is enough to see
     // that a proposal is certainly rejected -- which > 96% of them are.
-    auto approx_lk = [&](const double *T, const int *P, const int *cls, const unsigned long long *pm,
+    // (its size terms come from three small per-cluster tables -- the entry of the current size, of one read less and
+    // of one read more -- kept up to date on the rare accepts: no table look-up per proposal)
+    double sz0[K], szm[K], szp[K];
+    auto size_terms = [&](int c) {
+        const uint32_t x = (uint32_t)cl[c];
+        sz0[c] = size_lk(x);
+        szm[c] = x > 0 ? size_lk(x - 1) : 0.0;
+        szp[c] = x < n ? size_lk(x + 1) : 0.0;
+    };
+#pragma unroll
+    for (int c = 0; c < K; c++) size_terms(c);
+    auto approx_lk = [&](const double *T, const int *P, uint32_t from, uint32_t to, const unsigned long long *pm,
                          const unsigned long long *im) -> double {
         double S = 0.0;
 #pragma unroll
-        for (int c = 0; c < K; c++) S += size_lk((uint32_t)cls[c]);
+        for (int c = 0; c < K; c++) S += (uint32_t)c == from ? szm[c] : ((uint32_t)c == to ? szp[c] : sz0[c]);
         int in_use = 0;
         unsigned long long anym = 0;
 #pragma unroll
@@ -902,7 +913,7 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
         bool accept = false, decided = false, have_v = false;
         uint64_t v = 0;
         GS_MARK(1);
-        const double dA = unif64(approx_lk(T, P, ncl, npm, nim) - lk);
+        const double dA = unif64(approx_lk(T, P, old, nw, npm, nim) - lk);
         GS_MARK(2);
         if (ubool(dA < -1e-3)) {
             v = next_u64(rng);
@@ -931,6 +942,7 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
                 cl[c] = ncl[c];
                 posm[c] = npm[c];
                 infm[c] = nim[c];
+                if ((uint32_t)c == old || (uint32_t)c == nw) size_terms(c);
             }
             if (big) {
                 if (lane == 0) m.assign[idx] = (uint8_t)nw;
