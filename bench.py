@@ -82,7 +82,7 @@ def pmc_traffic(family, workload, n_chunks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg2_ont_diploid_500x60x2kbp", choices=sorted(WORKLOADS))
     ap.add_argument("--chunks", type=int, default=0, help="override chunks per GPU (diagnostic runs only)")

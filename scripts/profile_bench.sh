@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $REPO/bench.py --steps 8 --warmup 1 --no-cpu-baseline"
+CMD="python3 $REPO/bench.py --steps 16 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $CMD > $OUT/prof_stats.log 2>&1
 echo "stats rc=$?"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- $CMD > $OUT/prof_fetch.log 2>&1

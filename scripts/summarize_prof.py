@@ -23,8 +23,8 @@ def main(root, json_path=None):
     out = []
     pmc = {}
     stats = glob.glob(f"{root}/prof_stats/*/*_kernel_stats.csv")
-    out.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 1 --no-cpu-baseline ==")
-    out.append("(12 hot-path passes over 500-chunk batches, 4 batches in flight: 4 warm-up + 8 timed)")
+    out.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 16 --warmup 1 --no-cpu-baseline ==")
+    out.append("(20 hot-path passes over 500-chunk batches, 4 batches in flight: 4 warm-up + 16 timed)")
     out.append(f"{'kernel':28s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>12s} {'pct':>7s}")
     for f in stats:
         for r in csv.DictReader(open(f)):
@@ -47,7 +47,7 @@ def main(root, json_path=None):
     print("\n".join(out))
     if json_path:  # what bench.py reads back as roofline.traffic
         json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py "
-                              "--steps 8 --warmup 1 --no-cpu-baseline",
+                              "--steps 16 --warmup 1 --no-cpu-baseline",
                    "workload": "cfg2_ont_diploid_500x60x2kbp",
                    "note": "KiB per launch; FETCH_SIZE on gfx950 reports half of the bytes of wide coalesced reads "
                            "(MI355X_MICROARCH.md HBM): hbm_bytes = (2*FETCH + WRITE)*1024",
