@@ -796,7 +796,6 @@ SplitResult merge_split(const SplitFrame &f) {
     }
     SplitResult r;
     r.k = total;
-    r.score = f.own.score;
     double sub = 0.0;
     for (uint32_t c = 0; c < k; c++) sub += f.kids[c].score;
     r.score = sub + f.own.score;
@@ -824,7 +823,6 @@ SplitResult merge_split(const SplitFrame &f) {
 }  // namespace
 
 static int run_split(jtk_lc_session_t *s) {
-    static const char BASES[] = "ACGT";
     jtk_lc_timing_t acc = g_timing;
     // ---- what the batch pass left for the split chunks: labels, posteriors, consensus, ops, draws
     std::vector<uint32_t> label(s->n_reads);
@@ -1000,7 +998,6 @@ static int run_split(jtk_lc_session_t *s) {
             }
         }
     }
-    (void)BASES;
     g_timing = acc;
     return 0;
 }
