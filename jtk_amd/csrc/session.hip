@@ -916,6 +916,8 @@ static int run_split(jtk_lc_session_t *s) {
                 if (finished) {
                     w.stack.pop_back();
                     if (w.stack.empty()) {
+                        // the merged clustering has up to copy_num clusters: the caller's rows must hold them
+                        if (out.status == 0 && out.k > s->post_stride) out.status = JTK_ERR_INVALID_ARG;
                         s->split[w.chunk] = std::move(out);
                         w.done = true;
                     } else if (out.status != 0) {
