@@ -212,8 +212,9 @@ int jtk_lc_pileup_sort_key(const uint8_t *tmpl, uint64_t tmpl_len, const uint8_t
 int jtk_lc_normalize_pileup(uint32_t n_reads, uint32_t cluster_num, uint32_t *label, double *log_post,
                             uint32_t post_stride);
 
-/* Device workspaces of finished calls are kept (up to 200 GB per device) for the next call of similar shape:
- * mapping ~95 GB for a 2500-chunk batch costs seconds otherwise.  This returns them to the driver. */
+/* Device workspaces of finished calls are kept for the next call of similar shape (up to JTK_LC_POOL_GB per device,
+ * default 32; 0 disables the pool): mapping tens of GB for a 2500-chunk batch costs seconds otherwise.  This returns
+ * them to the driver. */
 int jtk_lc_trim_cache(int device);
 
 const char *jtk_lc_strerror(int status);

@@ -1,5 +1,5 @@
-/* jtk_synth.h -- host-only synthetic pile-up generator exported by libjtk_lc.so for bench.py and the
- * tests.  It stands in for the upstream JTK stages that produce the hot path's inputs
+/* jtk_synth.h -- host-only synthetic pile-up generator of bench.py and the tests, built as its own library
+ * libjtk_synth.so (it is not linked into the product library libjtk_lc.so).  It stands in for the upstream JTK stages that produce the hot path's inputs
  * (chunk selection, minimap2/edlib encoding); the usage pattern follows the reference's dev harness
  * sandbox/src/bin/benchmark_clustering.rs:55-100 and gen_sim_genome.rs:24-28.  Not part of the hot path. */
 #ifndef JTK_SYNTH_H

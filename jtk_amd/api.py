@@ -96,6 +96,11 @@ def cluster_features(params, feature_chunks, variants, variant_type, post_stride
     return dict(rc=rc, label=label, log_post=post, result=result)
 
 
+def trim_cache(device=0):
+    """jtk_lc_trim_cache: hand the pooled device blocks of finished calls back to the driver."""
+    check(ffi.lib().jtk_lc_trim_cache(device))
+
+
 def last_timing():
     t = ffi.Timing()
     check(ffi.lib().jtk_lc_last_timing(C.byref(t)))

@@ -8,10 +8,13 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OUT_DIR = os.path.join(PKG, "_build")
 OUT = os.path.join(OUT_DIR, "libjtk_lc.so")
+# the synthetic pile-up generator (bench.py and tests only) is NOT part of the product library
+SYNTH_OUT = os.path.join(OUT_DIR, "libjtk_synth.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = ["phmm_kernels.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip", "session.hip", "gains.hip",
-           "host_api.cpp", "synth.cpp"]
+           "host_api.cpp"]
+SYNTH_SOURCES = ["synth.cpp"]
 # -ffp-contract=off: device f64 arithmetic must round exactly like the reference (no implicit fma);
 # the pair-HMM specification uses explicit fma() where it wants one.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -30,11 +33,12 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     objs = []
+    synth_objs = []
     procs = []
-    for src in SOURCES:
+    for src in SOURCES + SYNTH_SOURCES:
         path = os.path.join(CSRC, src)
         obj = os.path.join(OUT_DIR, os.path.splitext(src)[0] + ".o")
-        objs.append(obj)
+        (synth_objs if src in SYNTH_SOURCES else objs).append(obj)
         if force or _stale(obj, [path] + headers):
             cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", path, "-o", obj]
             if verbose:
@@ -49,10 +53,20 @@ def build(force=False, verbose=False):
             failed = True
     if failed:
         raise RuntimeError("hipcc failed")
-    if force or procs or _stale(OUT, objs):
+    if force or _stale(OUT, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
         subprocess.check_call(cmd)
+    if force or _stale(SYNTH_OUT, synth_objs):
+        subprocess.check_call([HIPCC, "-shared", "-fPIC", "-o", SYNTH_OUT] + synth_objs)
     return OUT
+
+
+def is_stale():
+    """True when a source is newer than the library built from it (bench.py refuses to time a stale build)."""
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    return (_stale(OUT, [os.path.join(CSRC, f) for f in SOURCES] + headers)
+            or _stale(SYNTH_OUT, [os.path.join(CSRC, f) for f in SYNTH_SOURCES] + headers))
 
 
 if __name__ == "__main__":

@@ -1492,8 +1492,51 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
     return max;
 }
 
+// get_lk (:785-795) of the labels in `assign` from freshly filled counters (reads in order, :752-758): what the
+// reference compares the tracked maximum with before returning it (`assert!((max - lk).abs() < 0.0001)`, :759-760).
+template <int K>
+__device__ __noinline__ double fresh_lk(const Lds &m, uint32_t n, uint32_t D, double cov, const uint8_t *assign, uint32_t lane) {
+    Counts<K> q;
+    int clusters[K];
+    fill_counts<K>(m, n, D, assign, q, clusters, lane);
+    const unsigned long long usedm = __ballot(lane < D && column_used<K>(q));
+    double S = 0.0;
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        const uint32_t x = uni((uint32_t)clusters[c]);
+        double mx = -__builtin_inf();
+        for (int cc = 1; cc <= K; cc++) {
+            const double lam = cov * (double)cc;
+            mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
+        }
+        S += unif64(mx);
+    }
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        unsigned long long mm = usedm;
+        while (mm) {
+            const uint32_t d = (uint32_t)__builtin_ctzll(mm);
+            mm &= mm - 1;
+            S += jtk_fmax(readlane_f64(q.tg[c], d), 0.0);
+        }
+    }
+    return S;
+}
+
+template <int K>
+__device__ __forceinline__ double mcmc_chain_dispatch(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane);
+
+// mcmc_with_filter (:704-762): the chain, then the reference's closing self-check.  NaN = the reference panics.
 template <int K>
 __device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
+    const double max = mcmc_chain_dispatch<K>(m, n, D, cov, rng, lane);
+    const double fresh = fresh_lk<K>(m, n, D, cov, m.assign, lane);
+    if (!ubool(fabs(max - fresh) < 0.0001)) return __builtin_nan("");
+    return max;
+}
+
+template <int K>
+__device__ __forceinline__ double mcmc_chain_dispatch(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
     if (K == 2 && n <= 127 && D >= 1 && D <= 8) {
         const K2Mem km = {m.data, m.lfact, m.assign, m.k2_stats};
         if (n <= 63) {
@@ -1563,6 +1606,7 @@ __device__ __forceinline__ bool mcmc_clustering(const Lds &m, uint32_t n, uint32
     for (int it = 0; it < 20; it++) {
         if (!kmeans(m, n, D, K, rng, lane)) return false;
         const double lk = mcmc_with_filter<K>(m, n, D, cov, rng, lane);
+        if (ubool(lk != lk)) return false;  // the reference panicked inside mcmc_with_filter
 #ifdef JTK_DEBUG_LK
         if (lane == 0 && n == 65) printf("DEVLK n %u D %u it %d lk %.17g pos %u\n", n, D, it, lk, rng.pos);
 #endif
@@ -1711,8 +1755,21 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         return;
     }
     const double *feat = feat_all + cm.feat_off;
+    // LKCount::{add,sub} assert `x.abs() < POS_THR` for a value that is neither above POS_THR nor below -POS_THR
+    // (:830,:841: exactly +-POS_THR, or NaN), and mcmc_with_filter asserts that its size table has no NaN (:714-715:
+    // x ln(lambda) - lambda - ln x! is NaN at x = 0 unless 0 < lambda < inf): the reference panics, the chunk fails.
+    bool bad_value = false;
     for (uint32_t e = lane; e < n * D; e += 64) {
-        m.data[e] = feat[e];
+        const double x = feat[e];
+        m.data[e] = x;
+        bad_value = bad_value || (!(JTK_POS_THR < x) && !(x < -JTK_POS_THR) && !(fabs(x) < JTK_POS_THR));
+    }
+    if (ubool(__ballot(bad_value) != 0ull) || !(coverage > 0.0 && coverage < __builtin_inf())) {
+        if (lane == 0) {
+            lds_st32(&m.ctl->quit, 1);
+            st->status = JTK_ERR_CHUNK_FAILED;
+        }
+        return;
     }
     // lfact[x] = sum_{c=1..x} ln c, summed left to right as poisson_lk does (:636-638)
     if (lane == 0) {
@@ -1941,14 +1998,15 @@ int mcmc_upload_jump_table(hipStream_t s) {
     return (int)e;
 }
 
-void launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
-                 const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
-                 uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
-                 const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, const uint64_t *rng_resume) {
-    if (n_chunks == 0) return;
+int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
+                const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
+                uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
+                const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, const uint64_t *rng_resume) {
+    if (n_chunks == 0) return 0;
     const size_t lds = mcmc_lds_bytes(lds_n, lds_d);
-    if (mcmc_upload_jump_table(s) != 0) return;  // 16 KiB, stream-ordered before the kernel; the launch then fails loudly
+    if (mcmc_upload_jump_table(s) != 0) return -1;  // the caller fails the call: nothing was launched
     mcmc_kernel<<<n_chunks, 128, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
                                           post_stride, lg, lg_off, lds_n, lds_d, mcmc_jump_in_lds(lds_n, lds_d) ? 1u : 0u,
                                           rng_resume);
+    return 0;
 }

@@ -37,10 +37,10 @@ void launch_filter(hipStream_t s, uint32_t n_chunks, const ReadMeta *reads, cons
                    uint16_t *homop, const uint64_t *homop_off, double *aux, const uint64_t *aux_off, double *cand,
                    uint32_t *list, uint8_t *sel, double *feat, uint32_t *vtype, uint32_t *pos, uint32_t max_tmpl);
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d);
-void launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
-                 const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
-                 uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
-                 const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, const uint64_t *rng_resume);
+int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
+                const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
+                uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
+                const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, const uint64_t *rng_resume);
 
 namespace {
 
@@ -86,7 +86,16 @@ HmmDev to_dev(const jtk_hmm_t &h) {
 // block.  jtk_lc_trim_cache() returns everything to the driver.
 struct BlockPool {
     static const size_t MIN_BYTES = 1u << 20;           // smaller blocks are not worth keeping
-    static const size_t MAX_CACHED = 200ull << 30;      // per device
+    // per device: JTK_LC_POOL_GB (default 32: the pool must not starve torch / RCCL / another library in the same process;
+    // blocks beyond the cap go straight back to the driver), 0 disables pooling
+    static size_t max_cached() {
+        static const size_t v = []() -> size_t {
+            const char *e = getenv("JTK_LC_POOL_GB");
+            const double gb = e ? atof(e) : 32.0;
+            return gb > 0.0 ? (size_t)(gb * 1073741824.0) : 0;
+        }();
+        return v;
+    }
     std::mutex m;
     std::multimap<size_t, void *> blocks[JTK_POOL_DEVICES];
     size_t cached[JTK_POOL_DEVICES] = {};
@@ -103,7 +112,7 @@ struct BlockPool {
     }
     bool give(int dev, void *p, size_t cap) {
         std::lock_guard<std::mutex> lock(m);
-        if (cap < MIN_BYTES || cached[dev] + cap > MAX_CACHED) return false;
+        if (cap < MIN_BYTES || cached[dev] + cap > max_cached()) return false;
         blocks[dev].emplace(cap, p);
         cached[dev] += cap;
         return true;
@@ -303,6 +312,10 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         cm.copy_num = ch.copy_num > JTK_MAX_COPY ? 4 : ch.copy_num;
         s->h_copy0[c] = ch.copy_num;
         if (ch.copy_num > JTK_MAX_COPY) s->has_split = true;
+        // a posterior row holds up to cluster_num <= copy_num entries (merged sub-clusterings included, mod.rs:161-187)
+        // (a sub-problem of the split branch is one clustering() call: its rows hold cm.copy_num entries)
+        if ((extra ? cm.copy_num : ch.copy_num) > post_stride && ch.n_reads > 0)
+            return fail(JTK_ERR_INVALID_ARG, "post_stride smaller than a chunk's copy_num");
         cm.n_reads = ch.n_reads;
         cm.read_first = rcount;
         cm.tmpl_cap = cap;
@@ -580,7 +593,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                   s->max_tmpl);
     tstop(s);
     tstart(s, JTK_K_MCMC);
-    launch_mcmc(st, s->n_chunks, chunks, state, s->d_params.as<jtk_lc_params_t>(), s->d_feat.as<double>(),
+    const int mcmc_rc = launch_mcmc(st, s->n_chunks, chunks, state, s->d_params.as<jtk_lc_params_t>(), s->d_feat.as<double>(),
                 s->d_vtype.as<uint32_t>(), nullptr, 0, s->d_label.as<uint32_t>(), s->d_post.as<double>(),
                 s->post_stride, s->d_lg.as<double>(), s->d_lg_off.as<uint64_t>(), s->max_n,
                 // a chunk picks at most ROUND * max(copy_num, 2) columns (pseudo_mcmc.rs:421,527,532): size the
@@ -588,6 +601,10 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                 std::min<uint32_t>(JTK_MAX_DIM, 3u * std::max<uint32_t>(s->max_copy, 2u)),
                 s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr);
     tstop(s);
+    if (mcmc_rc != 0) {
+        (void)hipStreamSynchronize(st);
+        return fail(JTK_ERR_INTERNAL, "the chain kernel could not be launched (jump table upload failed)");
+    }
     HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -847,7 +864,11 @@ static int run_split(jtk_lc_session_t *s) {
             s->split[c].status = res[c].status;
             continue;
         }
-        if (res[c].cluster_num > s->post_stride) return fail(JTK_ERR_INVALID_ARG, "post_stride smaller than a cluster count");
+        if (res[c].cluster_num > s->post_stride) {  // (unreachable since session_create checks copy_num; per chunk anyway)
+            s->split[c].k = 1;
+            s->split[c].status = JTK_ERR_INVALID_ARG;
+            continue;
+        }
         SplitChunk w;
         w.chunk = c;
         seed_from_u64(cm.chunk_id * 3490ULL, w.rng);  // mod.rs:97
@@ -1223,7 +1244,9 @@ int jtk_internal_likelihoods(const jtk_lc_params_t *params, size_t n_chunks, con
         e.radius = radius;
     }
     jtk_lc_session_t *s = nullptr;
-    int rc = session_create_ex(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, 1, device,
+    uint32_t stride = 1;
+    for (size_t c = 0; c < n_chunks; c++) stride = std::max(stride, std::min<uint32_t>(chunks[c].copy_num, JTK_MAX_COPY));
+    int rc = session_create_ex(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, stride, device,
                                extra.data(), 0, &s);
     if (rc) return rc;
     std::unique_ptr<jtk_lc_session> guard(s);
@@ -1257,6 +1280,9 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
         return fail(JTK_ERR_INVALID_ARG, "null argument");
     int rc = pick_device(device);
     if (rc) return rc;
+    // declared before the session: destructors run in reverse order, so the session's (which synchronises its stream)
+    // runs before these blocks go back to the pool on every early return
+    DevPtr d_params, d_chunks, d_state, d_var, d_vt, d_vtoff, d_label, d_post, d_lg, d_lgoff;
     jtk_lc_session sess;
     jtk_lc_session *s = &sess;
     s->device = device;
@@ -1280,6 +1306,8 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
         sts[c].dim = fc.dim;
         sts[c].k = 1;
         if (fc.dim > JTK_MAX_DIM || fc.copy_num > JTK_MAX_COPY) sts[c].status = JTK_ERR_UNSUPPORTED;
+        else if (fc.copy_num > post_stride)  // a posterior row holds up to copy_num entries
+            return fail(JTK_ERR_INVALID_ARG, "post_stride smaller than a chunk's copy_num");
         vt_off[c] = fc.vt_off;
         lg_off[c] = lgo;
         lgo += (uint64_t)fc.n_reads * (JTK_MAX_COPY + 1);
@@ -1292,7 +1320,6 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
     std::vector<jtk_lc_params_t> pv(1, *params);
     std::vector<double> varv(variants, variants + n_var);
     std::vector<uint32_t> vtv(variant_type, variant_type + 2 * n_vt);
-    DevPtr d_params, d_chunks, d_state, d_var, d_vt, d_vtoff, d_label, d_post, d_lg, d_lgoff;
     if ((rc = dev_upload(s, d_params, pv))) return rc;
     if ((rc = dev_upload(s, d_chunks, cms))) return rc;
     if ((rc = dev_upload(s, d_state, sts))) return rc;
@@ -1308,10 +1335,11 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
     HIP_TRY(hipEventRecord(ev0, s->stream));
-    launch_mcmc(s->stream, (uint32_t)n_chunks, d_chunks.as<ChunkMeta>(), d_state.as<ChunkState>(),
-                d_params.as<jtk_lc_params_t>(), d_var.as<double>(), d_vt.as<uint32_t>(), d_vtoff.as<uint64_t>(), 1,
-                d_label.as<uint32_t>(), d_post.as<double>(), post_stride, d_lg.as<double>(), d_lgoff.as<uint64_t>(),
-                max_n, max_d, nullptr);
+    if (launch_mcmc(s->stream, (uint32_t)n_chunks, d_chunks.as<ChunkMeta>(), d_state.as<ChunkState>(),
+                    d_params.as<jtk_lc_params_t>(), d_var.as<double>(), d_vt.as<uint32_t>(), d_vtoff.as<uint64_t>(), 1,
+                    d_label.as<uint32_t>(), d_post.as<double>(), post_stride, d_lg.as<double>(), d_lgoff.as<uint64_t>(),
+                    max_n, max_d, nullptr) != 0)
+        return fail(JTK_ERR_INTERNAL, "the chain kernel could not be launched (jump table upload failed)");
     HIP_TRY(hipEventRecord(ev1, s->stream));
     HIP_TRY(hipMemcpyAsync(sts.data(), d_state.p, sts.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(label, d_label.p, n_reads * 4, hipMemcpyDeviceToHost, s->stream));

@@ -1,4 +1,5 @@
-"""ctypes binding of libjtk_lc.so (the C-ABI of include/jtk_lc.h + include/jtk_synth.h).
+"""ctypes binding of libjtk_lc.so (the C-ABI of include/jtk_lc.h) and of libjtk_synth.so (include/jtk_synth.h: the
+synthetic pile-up generator of bench.py and the tests, deliberately a separate library).
 
 There is no Python or CPU fallback: if the shared library is missing this module raises, and a compute
 call on a machine without a gfx950 device returns JTK_ERR_NO_DEVICE which is raised as JtkError.
@@ -11,6 +12,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "_build", "libjtk_lc.so")
+SYNTH_LIB_PATH = os.path.join(PKG_DIR, "_build", "libjtk_synth.so")
 
 NUM_ROW = 14
 OP_MATCH, OP_MISMATCH, OP_INS, OP_DEL = 0, 1, 2, 3   # enum jtk_op (jtk_lc.h) == kiley::Op
@@ -67,14 +69,14 @@ FEATURE_CHUNK_DT = np.dtype([("chunk_id", "<u8"), ("copy_num", "<u4"), ("n_reads
                              ("reserved", "<u4"), ("var_off", "<u8"), ("vt_off", "<u8"), ("read_first", "<u8"),
                              ("local_coverage", "<f8")])
 
-# every symbol declared in include/jtk_lc.h and include/jtk_synth.h (tests check the library exports them)
+# every symbol declared in include/jtk_lc.h (tests check the library exports them)
 EXPORTED_SYMBOLS = (
     "jtk_lc_cluster_chunks", "jtk_lc_cluster_polished", "jtk_lc_modification_table",
     "jtk_lc_cluster_features", "jtk_lc_estimate_gains", "jtk_lc_trim_cache", "jtk_lc_pileup_sort_key", "jtk_lc_normalize_pileup", "jtk_lc_strerror",
     "jtk_lc_last_error", "jtk_lc_version", "jtk_lc_device_ok", "jtk_lc_last_timing",
     "jtk_lc_session_create", "jtk_lc_session_run", "jtk_lc_session_fetch", "jtk_lc_session_destroy",
-    "jtk_synth_pileup",
 )
+SYNTH_SYMBOLS = ("jtk_synth_pileup",)
 
 
 def u8p(a):
@@ -135,10 +137,26 @@ def lib():
     sig("jtk_lc_session_run", i32, vp, i32)
     sig("jtk_lc_session_fetch", i32, vp, PU32, PD, vp, PU8, PU64, u64, PU8, PU64, u64)
     sig("jtk_lc_session_destroy", i32, vp)
-    sig("jtk_synth_pileup", i32, C.POINTER(SynthCfg), PU8, u64, PU64, PU8, u64, PU64, PU8, u64, PU64, PU8,
-        PU32)
     _lib = L
     return L
+
+
+_synth = None
+
+
+def synth_lib():
+    """libjtk_synth.so: synthetic inputs for bench.py and the tests (not part of the product library)."""
+    global _synth
+    if _synth is None:
+        if not os.path.exists(SYNTH_LIB_PATH):
+            raise ImportError(f"{SYNTH_LIB_PATH} is missing: run __graft_entry__.build()")
+        L = C.CDLL(SYNTH_LIB_PATH)
+        PU8, PU64, PU32 = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        L.jtk_synth_pileup.restype = C.c_int
+        L.jtk_synth_pileup.argtypes = [C.POINTER(SynthCfg), PU8, C.c_uint64, PU64, PU8, C.c_uint64, PU64, PU8,
+                                       C.c_uint64, PU64, PU8, PU32]
+        _synth = L
+    return _synth
 
 
 def check(status):

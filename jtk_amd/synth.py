@@ -26,7 +26,7 @@ CONFIGS = {
 
 
 def make_pileup(chunk_id, cfg, seed0=SEED0, min_variants=0, sort=True):
-    L = ffi.lib()
+    L = ffi.synth_lib()
     sc = ffi.SynthCfg(seed=seed0 + chunk_id, tmpl_len=cfg["tmpl_len"], n_haps=cfg["n_haps"],
                       reads_per_hap=cfg["reads_per_hap"], min_variants=min_variants,
                       divergence=cfg["divergence"], err_sub=cfg["err"][0], err_ins=cfg["err"][1],

@@ -117,6 +117,10 @@ size_t jo_search_variants(const uint8_t *tmpl, size_t tl, size_t n, const uint8_
                           const jo_cluster_config_t *cfg, double *variants, size_t *vt_homop, int *vt_type,
                           size_t *pos_out);
 
+/* ---------------- exact_clustering.c: exact_clustering.rs:7-26 (the comparator of benchmark_mcmc.rs) -------- */
+double jo_cluster_filtered_variants_exact(const double *variants, size_t n, size_t dim, size_t copy_num,
+                                          size_t *assign, double *lk_gain);
+
 /* ---------------- normalize.c ----------------------------------------------------------------------- */
 void jo_reorder_f64(double *xs, uint64_t *indices, size_t n); /* normalize.rs:54-63 */
 void jo_reorder_i64(int64_t *xs, uint64_t *indices, size_t n);

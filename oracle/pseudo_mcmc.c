@@ -396,11 +396,26 @@ static void fill_lks(const double *data, size_t n, size_t dim, const size_t *ass
     }
 }
 
-/* pseudo_mcmc.rs:704-762 */
+/* pseudo_mcmc.rs:704-762.  Returns NaN where the reference panics:
+ *   assert!(is_valid_lk) :714-715 (a NaN in size_to_lk), LKCount::{add,sub}'s assert!(x.abs() < POS_THR) :830,:841
+ *   (a value that is neither > POS_THR nor < -POS_THR nor inside the band: exactly +-POS_THR, or NaN) and
+ *   assert!((max - lk).abs() < 0.0001) :759-760 (the likelihood of argmax recomputed from scratch). */
 double jo_mcmc_with_filter(const double *data, size_t n, size_t dim, size_t *assign, size_t k, double cov,
                            jo_rng_t *rng) {
     double *size_to_lk = (double *)malloc((n + 1) * sizeof(double));
-    for (size_t x = 0; x <= n; x++) size_to_lk[x] = jo_max_poisson_lk(x, cov, 1, k);
+    int panic = 0;
+    for (size_t x = 0; x <= n; x++) {
+        size_to_lk[x] = jo_max_poisson_lk(x, cov, 1, k);
+        if (size_to_lk[x] != size_to_lk[x]) panic = 1; /* :714-715 */
+    }
+    for (size_t e = 0; e < n * dim; e++) { /* every row is added once before the first proposal (:720-725) */
+        const double x = data[e];
+        if (!(JO_POS_THR < x) && !(x < -JO_POS_THR) && !(__builtin_fabs(x) < JO_POS_THR)) panic = 1; /* :830 */
+    }
+    if (panic) {
+        free(size_to_lk);
+        return __builtin_nan("");
+    }
     size_t *clusters = (size_t *)malloc(k * sizeof(size_t));
     lkcount_t *lks = (lkcount_t *)malloc(k * dim * sizeof(lkcount_t));
     uint8_t *use = (uint8_t *)malloc(dim ? dim : 1);
@@ -428,8 +443,10 @@ double jo_mcmc_with_filter(const double *data, size_t n, size_t dim, size_t *ass
         }
     }
     memcpy(assign, argmax, n * sizeof(size_t));
-    /* the reference recomputes the likelihood of argmax and asserts |max - lk| < 1e-4 (:751-760);
-     * the value returned is the tracked max */
+    /* :751-760: the likelihood of argmax from freshly filled counters must agree with the tracked maximum */
+    fill_lks(data, n, dim, assign, k, lks, clusters);
+    const double fresh = get_lk(lks, clusters, k, dim, size_to_lk, use);
+    if (!(__builtin_fabs(max - fresh) < 0.0001)) max = __builtin_nan("");
     free(size_to_lk);
     free(clusters);
     free(lks);
@@ -487,6 +504,10 @@ int jo_mcmc_clustering(const double *data, size_t n, size_t dim, size_t k, doubl
             break;
         }
         double lk = jo_mcmc_with_filter(data, n, dim, cur, k, cov, rng);
+        if (lk != lk) { /* the reference panicked inside mcmc_with_filter */
+            rc = -1;
+            break;
+        }
         if (!have || !(lk < best)) { /* max_by: last maximum */
             best = lk;
             have = 1;

@@ -36,3 +36,14 @@ def same_partition(a, b):
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def random_feature_problem(rng, n, dim, k_true):
+    """feature matrix shaped like search_variants output: +gain for carriers, -gain otherwise, some zeros"""
+    lab = rng.integers(0, k_true, n)
+    owner = rng.integers(0, k_true, dim)
+    x = np.where(lab[:, None] == owner[None, :], rng.normal(4.5, 0.8, (n, dim)), rng.normal(-4.5, 0.8, (n, dim)))
+    x[rng.random((n, dim)) < 0.08] = 0.0
+    x[rng.random((n, dim)) < 0.03] *= -1
+    vt = np.stack([rng.integers(1, 4, dim), rng.integers(0, 3, dim)], axis=1).astype(np.uint32)
+    return x, vt, lab

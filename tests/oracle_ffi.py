@@ -158,6 +158,7 @@ def lib():
     sig("jo_poisson_lk", d, sz, d)
     sig("jo_max_poisson_lk", d, sz, d, sz, sz)
     sig("jo_mcmc_with_filter", d, PD, sz, sz, PSZ, sz, d, C.POINTER(Rng))
+    sig("jo_cluster_filtered_variants_exact", d, PD, sz, sz, sz, PSZ, PD)
     sig("jo_reorder_f64", None, PD, C.POINTER(u64), sz)
     sig("jo_reorder_i64", None, C.POINTER(C.c_int64), C.POINTER(u64), sz)
     sig("jo_normalize_pileup", None, sz, sz, C.POINTER(u64), PD, sz)

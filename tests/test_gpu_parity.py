@@ -90,15 +90,8 @@ def test_estimate_gains_matches_oracle(lib, seed, seq_len, band, homop_len):
             assert d.gain > 0.0 and 1e-9 <= d.prob <= 1.0
 
 
-def random_feature_problem(rng, n, dim, k_true, cid, copy_num):
-    """feature matrix shaped like search_variants output: +gain for carriers, -gain otherwise, some zeros"""
-    lab = rng.integers(0, k_true, n)
-    owner = rng.integers(0, k_true, dim)
-    x = np.where(lab[:, None] == owner[None, :], rng.normal(4.5, 0.8, (n, dim)), rng.normal(-4.5, 0.8, (n, dim)))
-    x[rng.random((n, dim)) < 0.08] = 0.0
-    x[rng.random((n, dim)) < 0.03] *= -1
-    vt = np.stack([rng.integers(1, 4, dim), rng.integers(0, 3, dim)], axis=1).astype(np.uint32)
-    return x, vt, lab
+def random_feature_problem(rng, n, dim, k_true, cid=0, copy_num=2):
+    return helpers.random_feature_problem(rng, n, dim, k_true)
 
 
 def run_features_both(p, specs, seed):

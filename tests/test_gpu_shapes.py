@@ -1,0 +1,199 @@
+"""Parity at the DEFINING shapes of the BASELINE.json configurations (the small-shape tests of test_gpu_parity.py take
+other code paths: table-driven chain instead of the generic one, one table register instead of two, ...), a fixed-seed
+slice of the randomized campaigns of scripts/parity_*.py, the reference's panics as chunk failures, and the
+reference's brute-force comparator as an upper bound of the device chain's score.  All through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+import oracle_ffi as O
+from jtk_amd import api, batch as jb, ffi, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def lib(jtk_lib):
+    assert jtk_lib.jtk_lc_device_ok(0) == 1, "needs a gfx950 device"
+    return jtk_lib
+
+
+def assert_full_parity(dev, ora, b):
+    assert ora["rc"] == 0
+    assert np.array_equal(dev["result"]["status"], ora["result"]["status"])
+    assert np.array_equal(dev["result"]["polish_rounds"], ora["result"]["polish_rounds"])
+    assert np.array_equal(dev["cons_off"], ora["cons_off"])
+    n = int(dev["cons_off"][-1])
+    assert bytes(dev["cons"][:n]) == bytes(ora["cons"][:n])
+    assert np.array_equal(dev["ops_out_off"], ora["ops_out_off"])
+    m = int(dev["ops_out_off"][-1])
+    assert np.array_equal(dev["ops_out"][:m], ora["ops_out"][:m])
+    assert np.array_equal(dev["result"]["n_variants"], ora["result"]["n_variants"])
+    assert np.array_equal(dev["label"], ora["label"])                       # bit-exact integer labels
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert np.abs(dev["log_post"] - ora["log_post"]).max() < TOL            # north_star tolerance
+    assert np.abs(dev["result"]["score"] - ora["result"]["score"]).max() < TOL
+    # this build: identical bits
+    assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(ora["log_post"]))
+    assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(ora["result"]["score"]))
+    for c in range(b.n_chunks):
+        k = int(dev["result"][c]["cluster_num"])
+        rows = dev["log_post"][list(b.chunk_reads(c))][:, :k]
+        assert np.abs(np.log(np.exp(rows).sum(axis=1))).max() < 1e-4       # mod.rs:184-185
+
+
+def full_shape(config, n_chunks, first, **kw):
+    b, cfg = synth.make_batch(config, n_chunks, first_chunk_id=first, **kw)
+    cov = cfg["coverage"] if "reads_per_hap" not in kw else float(kw["reads_per_hap"])
+    return b, cfg, jb.default_params(haploid_coverage=cov, band_frac=cfg["band_frac"])
+
+
+def test_cfg4_full_shape_matches_oracle(lib):
+    """BASELINE cfg 4 at its defining shape: 4 copies x 40 reads x 2 kbp (160 reads), candidate k = 2, 3, 4 -- every
+    pass runs the chain for more than 127 reads, K = 3 and 4 on 160 reads"""
+    b, cfg, p = full_shape("ont_4copy", 2, first=4100, min_variants=2)
+    assert int(b.chunks["n_reads"][0]) == 160 and int(b.chunks["tmpl_len"][0]) >= 1900
+    ora = O.cluster_chunks(helpers.oracle_params(p), b)
+    dev = api.cluster_chunks(p, b)
+    assert_full_parity(dev, ora, b)
+    assert ora["result"]["cluster_num"].max() >= 3, "the inputs must reach k >= 3"
+
+
+def test_cfg5_full_shape_matches_oracle(lib):
+    """BASELINE cfg 5 at its defining shape: HiFi error model, 40 reads x 2 kbp, band radius 10, the whole path"""
+    b, cfg, p = full_shape("hifi_diploid", 3, first=5200, min_variants=1)
+    assert int(b.chunks["n_reads"][0]) == 40 and p.band_frac == 0.01
+    ora = O.cluster_chunks(helpers.oracle_params(p), b)
+    dev = api.cluster_chunks(p, b)
+    assert_full_parity(dev, ora, b)
+
+
+@pytest.mark.parametrize("rph", [32, 39, 47])
+def test_poisson_tail_pileups_match_oracle(lib, rph):
+    """60x ONT pile-ups are Poisson(60) deep in real data: 64..94 reads x 2 kbp take the two-register tables of the
+    diploid chain"""
+    b, cfg, p = full_shape("ont_diploid", 2, first=6000 + rph, reads_per_hap=rph, min_variants=1)
+    assert 64 <= int(b.chunks["n_reads"][0]) <= 94
+    ora = O.cluster_chunks(helpers.oracle_params(p), b)
+    dev = api.cluster_chunks(p, b)
+    assert_full_parity(dev, ora, b)
+
+
+def test_headline_shape_random_ids_match_oracle(lib):
+    """a fixed-seed slice of scripts/parity_headline.py: cfg 2/3 pile-ups (60 reads x 2 kbp) with chunk ids -- RNG
+    streams -- no other test uses"""
+    first = int(np.random.default_rng(2).integers(0, 1 << 40))
+    b, cfg, p = full_shape("ont_diploid", 6, first=first)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b)
+    dev = api.cluster_chunks(p, b)
+    assert_full_parity(dev, ora, b)
+
+
+def test_random_shape_sweep_matches_oracle(lib):
+    """a fixed-seed slice of scripts/parity_sweep_full.py: random configuration, template length, depth and chunk ids;
+    every fifth batch goes through clustering_recursive's split"""
+    rng = np.random.default_rng(77)
+    for it in range(10):
+        config = str(rng.choice(["ont_diploid", "ont_diploid", "ont_noisy", "hifi_diploid", "ont_4copy"]))
+        L = int(rng.integers(130, 1400))
+        rph = int(rng.integers(3, 12))
+        first = int(rng.integers(0, 1 << 40))
+        kw = {}
+        if it % 5 == 4:
+            config, L, rph = "ont_4copy", int(rng.integers(400, 900)), int(rng.integers(6, 12))
+            kw = dict(n_haps=int(rng.integers(6, 11)), copy_num=int(rng.integers(8, 15)), divergence=2e-2, min_variants=3)
+        b, cfg, p = helpers.small_batch(config=config, n_chunks=3, tmpl_len=L, reads_per_hap=rph, first=first, **kw)
+        dev = api.cluster_chunks(p, b, raise_on_chunk_failure=False)
+        ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
+        assert_full_parity(dev, ora, b)
+
+
+def test_random_chain_sweep_matches_oracle(lib):
+    """a fixed-seed slice of scripts/parity_sweep.py: random feature problems, K = 2..4"""
+    import test_gpu_parity as T
+    for seed in (300, 301):
+        rng = np.random.default_rng(seed)
+        specs = []
+        for _ in range(14):
+            cn = int(rng.choice([2, 2, 2, 2, 3, 4]))
+            n = int(rng.integers(4, 128)) if cn == 2 else int(rng.integers(6, 90))
+            d = int(rng.integers(1, 9)) if cn == 2 else int(rng.integers(1, 3 * cn + 1))
+            specs.append((n, d, int(rng.integers(1, cn + 1)), cn))
+        p = jb.default_params(haploid_coverage=float(rng.choice([8.0, 15.0, 30.0])))
+        dev, ora, _ = T.run_features_both(p, specs, seed=seed)
+        assert np.array_equal(dev["label"], ora["label"])
+        assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+        assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(ora["log_post"]))
+        assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(ora["result"]["score"]))
+
+
+def one_feature_chunk(x, vt, copy_num, chunk_id=1000):
+    n, dim = x.shape
+    ch = np.zeros(1, dtype=ffi.FEATURE_CHUNK_DT)
+    ch[0] = (chunk_id, copy_num, n, dim, 0, 0, 0, 0, n / copy_num)
+    return ch, np.ascontiguousarray(x.ravel()), np.ascontiguousarray(vt.ravel().astype(np.uint32))
+
+
+def test_chunk_fails_where_the_reference_asserts(lib):
+    """LKCount's zero-band assert (pseudo_mcmc.rs:830,:841: a value of exactly +-POS_THR, or NaN) and the NaN check of
+    the size table (:714-715) are panics in the reference: the device reports JTK_ERR_CHUNK_FAILED for that chunk,
+    exactly where the oracle does, and clusters the other chunks of the batch"""
+    rng = np.random.default_rng(9)
+    p = jb.default_params(haploid_coverage=6.0)
+    x, vt, _ = helpers.random_feature_problem(rng, 12, 3, 2)
+    for bad in (1e-5, -1e-5, float("nan"), 0.99e-5):
+        y = x.copy()
+        y[7, 1] = bad
+        ch, var, vts = one_feature_chunk(y, vt, 2)
+        out = api.cluster_features(p, ch, var, vts, 2, raise_on_chunk_failure=False)
+        expect_fail = bad != 0.99e-5
+        assert (out["rc"] == -6 and out["result"]["status"][0] == -6) == expect_fail, bad
+        if not expect_fail:
+            assert out["rc"] == 0
+    ch, var, vts = one_feature_chunk(x, vt, 2)
+    for cov in (float("nan"), 0.0, -3.0, float("inf")):
+        p.haploid_coverage = cov
+        out = api.cluster_features(p, ch, var, vts, 2, raise_on_chunk_failure=False)
+        assert out["rc"] == -6 and out["result"]["status"][0] == -6, cov
+    # a failing chunk does not take its neighbours with it
+    p.haploid_coverage = 6.0
+    y = x.copy()
+    y[0, 0] = 1e-5
+    chunks = np.zeros(2, dtype=ffi.FEATURE_CHUNK_DT)
+    chunks[0] = (1, 2, 12, 3, 0, 0, 0, 0, 6.0)
+    chunks[1] = (1000, 2, 12, 3, 0, 36, 3, 12, 6.0)
+    var = np.concatenate([y.ravel(), x.ravel()])
+    vts = np.concatenate([vt.ravel(), vt.ravel()]).astype(np.uint32)
+    out = api.cluster_features(p, chunks, var, vts, 2, raise_on_chunk_failure=False)
+    assert out["rc"] == -6 and out["result"]["status"].tolist() == [-6, 0]
+    good = api.cluster_features(p, *one_feature_chunk(x, vt, 2), 2)
+    assert np.array_equal(out["label"][12:], good["label"])
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_device_chain_score_is_bounded_by_the_exact_optimum(lib, seed):
+    """cluster_filtered_variants_exact (exact_clustering.rs:7-26), the comparator of sandbox benchmark_mcmc.rs:111-122:
+    the device chain's score never exceeds it, and reaches it on cleanly separated pile-ups"""
+    rng = np.random.default_rng(200 + seed)
+    p = jb.default_params(haploid_coverage=6.0)
+    for n, dim, k_true, copy_num in [(12, 3, 2, 2), (10, 4, 2, 2), (12, 2, 3, 3), (11, 5, 2, 2)]:
+        x, vt, _ = helpers.random_feature_problem(rng, n, dim, k_true)
+        out = api.cluster_features(p, *one_feature_chunk(x, vt, copy_num, chunk_id=seed * 31 + n), copy_num)
+        asn = np.zeros(n, dtype=np.uintp)
+        gain = np.zeros((n, copy_num))
+        best = O.lib().jo_cluster_filtered_variants_exact(O.f64p(np.ascontiguousarray(x)), n, dim, copy_num, O.szp(asn),
+                                                          O.f64p(gain))
+        assert out["result"]["score"][0] <= best + 1e-9
+    lab = np.array([0] * 6 + [1] * 6)
+    owner = np.array([0, 1, 0])
+    x = np.where(lab[:, None] == owner[None, :], rng.normal(5.0, 0.3, (12, 3)), rng.normal(-5.0, 0.3, (12, 3)))
+    vt = np.stack([np.ones(3), np.zeros(3)], axis=1).astype(np.uint32)
+    out = api.cluster_features(p, *one_feature_chunk(x, vt, 2, chunk_id=seed), 2)
+    asn = np.zeros(12, dtype=np.uintp)
+    gain = np.zeros((12, 2))
+    best = O.lib().jo_cluster_filtered_variants_exact(O.f64p(np.ascontiguousarray(x)), 12, 3, 2, O.szp(asn), O.f64p(gain))
+    assert abs(out["result"]["score"][0] - best) < 1e-9
+    assert helpers.same_partition(out["label"], lab)

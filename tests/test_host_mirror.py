@@ -22,7 +22,7 @@ def build_driver():
     if not os.path.exists(EXE) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(EXE):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "jtk_amd", "csrc"), src,
-                               "-L" + os.path.join(ROOT, "jtk_amd", "_build"), "-ljtk_lc",
+                               "-L" + os.path.join(ROOT, "jtk_amd", "_build"), "-ljtk_lc", "-ljtk_synth",
                                "-Wl,-rpath," + os.path.join(ROOT, "jtk_amd", "_build"), "-o", EXE])
     return EXE
 
