@@ -89,6 +89,11 @@ struct DataSet {  // definitions/src/lib.rs:6-34 (fields the stage reads or writ
 struct LocalClusteringOptions {
     int device = 0;
     const jtk_gains_t *gains = nullptr;  // optional: a cached result of estimate_gain_default (likelihood_gains.rs:186-192)
+    // The reference panics when a chunk hits one of its asserts.  nullptr: this mirror throws like it, before touching the
+    // DataSet.  Otherwise chunks that come back with a status (where the reference would panic, or a shape this build does
+    // not take) are left exactly as they were, their (chunk id, jtk_status) pairs are appended here and every other chunk
+    // is written back.
+    std::vector<std::pair<uint64_t, int>> *failed = nullptr;
 };
 
 inline double band_frac(ReadType t) {  // definitions/src/lib.rs:173-175, 201-210
@@ -249,12 +254,16 @@ inline void local_clustering_selected(DataSet &ds, const std::unordered_set<uint
                                          ops.data(), ops_off.data(), strand.data(), label.data(), post.data(), stride,
                                          result.data(), cons.data(), cons_off.data(), cons_cap, ops_out.data(),
                                          ops_out_off.data(), ops_cap, opt.device);
-    if (rc != 0)  // the reference panics on every failure of this stage
+    if (rc != 0 && !(rc == JTK_ERR_CHUNK_FAILED && opt.failed))  // the reference panics on every failure of this stage
         throw std::runtime_error(std::string("local_clustering: ") + jtk_lc_strerror(rc) + ": " + jtk_lc_last_error());
     // update_by_clusterings (mod.rs:244-260) and the chunk write-back (mod.rs:74-81)
     std::unordered_map<uint64_t, size_t> index_of;
     for (size_t c = 0; c < order.size(); c++) index_of[order[c]] = c;
     for (size_t c = 0; c < order.size(); c++) {
+        if (result[c].status != 0) {
+            opt.failed->emplace_back(order[c], result[c].status);
+            continue;
+        }
         Pile &p = piles[order[c]];
         const size_t k = result[c].cluster_num;
         for (size_t r = 0; r < p.nodes.size(); r++) {
@@ -269,6 +278,7 @@ inline void local_clustering_selected(DataSet &ds, const std::unordered_set<uint
         auto it = index_of.find(chunk.id);
         if (it == index_of.end()) continue;
         const size_t c = it->second;
+        if (result[c].status != 0) continue;
         chunk.seq.assign((const char *)cons.data() + cons_off[c], cons_off[c + 1] - cons_off[c]);
         chunk.score = result[c].score;
         chunk.cluster_num = result[c].cluster_num;

@@ -32,6 +32,69 @@ from . import api, ffi
 from .batch import pack, pileup_sort
 
 BAND_FRAC = {"CCS": 0.01, "ONT": 0.03, "CLR": 0.05, "None": 0.05}   # definitions/src/lib.rs:173-175
+
+# Field names of the serde derives of definitions/src/lib.rs (no #[serde(rename/default/skip)] anywhere in that file, so
+# the wire names are the Rust names and every field is required on input): struct -> fields in declaration order.
+SCHEMA = {
+    "DataSet": ("input_file", "masked_kmers", "coverage", "raw_reads", "hic_pairs", "selected_chunks", "encoded_reads",
+                "hic_edges", "read_type", "model_param", "error_rate", "processed_stages"),                 # :6-34
+    "ProcessedStage": ("stage_name", "arg"),                                                               # :38-43
+    "HMMParamOnStrands": ("forward", "reverse"),                                                           # :95-99
+    "HMMParam": ("mat_mat", "mat_ins", "mat_del", "ins_mat", "ins_ins", "ins_del", "del_mat", "del_ins", "del_del",
+                 "mat_emit", "ins_emit"),                                                                  # :101-126
+    "MaskInfo": ("k", "thr"),
+    "RawRead": ("name", "desc", "id", "seq"),
+    "HiCPair": ("pair1", "pair2", "pair_id", "seq1", "seq2"),
+    "Chunk": ("id", "seq", "cluster_num", "copy_num", "score"),                                            # :403-415
+    "EncodedRead": ("id", "original_length", "leading_gap", "trailing_gap", "edges", "nodes"),
+    "Edge": ("from", "to", "offset", "label"),
+    "Node": ("position_from_start", "chunk", "cluster", "seq", "is_forward", "cigar", "posterior"),        # :672-683
+    "HiCEdge": ("pair_id", "pair1", "pair2"),
+    "ErrorRate": ("del", "del_sd", "ins", "ins_sd", "mismatch", "mism_sd", "total", "total_sd"),           # :900-909
+}
+READ_TYPES = ("CCS", "CLR", "ONT", "None")                                                                 # :156-162
+
+
+def _need(obj, struct, where):
+    if not isinstance(obj, dict):
+        raise ValueError(f"{where}: expected a {struct} object")
+    missing = [k for k in SCHEMA[struct] if k not in obj]
+    if missing:   # serde: "missing field `x`"
+        raise ValueError(f"{where}: {struct} is missing field(s) {missing}")
+
+
+def validate(ds):
+    """What serde_json would reject on the way into `DataSet` (definitions/src/lib.rs): missing fields, a coverage or
+    read type that is not one of the enum's variants.  Unknown extra fields are ignored, as serde does by default."""
+    _need(ds, "DataSet", "dataset")
+    _need(ds["masked_kmers"], "MaskInfo", "masked_kmers")
+    cov = ds["coverage"]
+    if not (cov == "NotAvailable" or (isinstance(cov, dict) and len(cov) == 1 and next(iter(cov)) in ("Protected", "Estimated"))):
+        raise ValueError("coverage: expected \"NotAvailable\", {\"Protected\": x} or {\"Estimated\": x}")
+    if ds["read_type"] not in READ_TYPES:
+        raise ValueError(f"read_type: unknown variant {ds['read_type']!r}")
+    _need(ds["model_param"], "HMMParamOnStrands", "model_param")
+    for strand in ("forward", "reverse"):
+        _need(ds["model_param"][strand], "HMMParam", f"model_param.{strand}")
+    _need(ds["error_rate"], "ErrorRate", "error_rate")
+    for i, st in enumerate(ds["processed_stages"]):
+        _need(st, "ProcessedStage", f"processed_stages[{i}]")
+    for i, r in enumerate(ds["raw_reads"]):
+        _need(r, "RawRead", f"raw_reads[{i}]")
+    for i, h in enumerate(ds["hic_pairs"]):
+        _need(h, "HiCPair", f"hic_pairs[{i}]")
+    for i, h in enumerate(ds["hic_edges"]):
+        _need(h, "HiCEdge", f"hic_edges[{i}]")
+    for i, c in enumerate(ds["selected_chunks"]):
+        _need(c, "Chunk", f"selected_chunks[{i}]")
+    for i, r in enumerate(ds["encoded_reads"]):
+        _need(r, "EncodedRead", f"encoded_reads[{i}]")
+        for j, e in enumerate(r["edges"]):
+            _need(e, "Edge", f"encoded_reads[{i}].edges[{j}]")
+        for j, n in enumerate(r["nodes"]):
+            _need(n, "Node", f"encoded_reads[{i}].nodes[{j}]")
+
+
 _OP_RE = re.compile(r"(\d+)([MDI])")
 _OP_CODE = {"M": ffi.OP_MATCH, "D": ffi.OP_DEL, "I": ffi.OP_INS}
 
@@ -126,8 +189,14 @@ def normalize_local_clustering(ds):
             n["posterior"] = post[i].tolist()
 
 
-def local_clustering_selected(ds, selection, gains=None, device=0):
-    """mod.rs:56-83 on the parsed JSON object `ds` (modified in place)."""
+def local_clustering_selected(ds, selection, gains=None, device=0, failed=None):
+    """mod.rs:56-83 on the parsed JSON object `ds` (modified in place).
+
+    The reference panics when a chunk hits one of its asserts; here such a chunk (and a chunk of a shape this build does
+    not take) comes back with a status.  With `failed` = a list, those chunks are left exactly as they were, their
+    (chunk id, status) pairs are appended to it and every other chunk is written back; with `failed` = None the call
+    raises like the reference, before touching `ds`."""
+    validate(ds)
     update_coverage(ds)                                                       # mod.rs:57
     params = ffi.Params()
     params.forward = _hmm(ds["model_param"]["forward"])                       # mod.rs:59 (no refit, see module doc)
@@ -156,9 +225,13 @@ def local_clustering_selected(ds, selection, gains=None, device=0):
         pileups.append((cid, int(chunk["copy_num"]), tmpl, [reads[i] for i in perm], [ops[i] for i in perm],
                         [1 if nodes[i]["is_forward"] else 0 for i in perm], None))
     batch = pack(pileups)
-    out = api.cluster_chunks(params, batch, device=device)                    # the hot loop of mod.rs:64-72
+    out = api.cluster_chunks(params, batch, device=device,                    # the hot loop of mod.rs:64-72
+                             raise_on_chunk_failure=failed is None)
     # update_by_clusterings (mod.rs:244-260) and the chunk write-back (mod.rs:74-81)
     for c, cid in enumerate(order):
+        if int(out["result"][c]["status"]) != 0:
+            failed.append((cid, int(out["result"][c]["status"])))
+            continue
         k = int(out["result"][c]["cluster_num"])
         for r, node in zip(batch.chunk_reads(c), piles[cid]):
             node["posterior"] = out["log_post"][r, :k].tolist()
@@ -172,9 +245,11 @@ def local_clustering_selected(ds, selection, gains=None, device=0):
     return ds
 
 
-def local_clustering(ds, gains=None, device=0):
+def local_clustering(ds, gains=None, device=0, failed=None):
     """mod.rs:23-26: every selected chunk."""
-    return local_clustering_selected(ds, [c["id"] for c in ds["selected_chunks"]], gains=gains, device=device)
+    validate(ds)
+    return local_clustering_selected(ds, [c["id"] for c in ds["selected_chunks"]], gains=gains, device=device,
+                                     failed=failed)
 
 
 def main(argv=None):
@@ -183,19 +258,27 @@ def main(argv=None):
     ap.add_argument("output", help="DataSet JSON ('-' = stdout)")
     ap.add_argument("--chunks", default="", help="comma-separated chunk ids (local_clustering_selected); default: all")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--keep-going", action="store_true",
+                    help="a chunk that fails (where the reference would panic, or an unsupported shape) is left untouched "
+                         "and listed on stderr instead of aborting the stage")
     args = ap.parse_args(argv)
     ds = json.load(sys.stdin if args.input == "-" else open(args.input))
+    failed = [] if args.keep_going else None
     if args.chunks:
-        local_clustering_selected(ds, [int(x) for x in args.chunks.split(",")], device=args.device)
+        local_clustering_selected(ds, [int(x) for x in args.chunks.split(",")], device=args.device, failed=failed)
     else:
-        local_clustering(ds, device=args.device)
+        local_clustering(ds, device=args.device, failed=failed)
+    for cid, status in failed or []:
+        sys.stderr.write(f"LC\tFAILED\t{cid}\t{status}\t{ffi.lib().jtk_lc_strerror(status).decode()}\n")
+    api.trim_cache(args.device)
     text = json.dumps(ds)
     if args.output == "-":
         sys.stdout.write(text + "\n")
     else:
         with open(args.output, "w") as f:
             f.write(text + "\n")
+    return 3 if failed else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,0 +1,50 @@
+// haplotyper/src/local_clustering/gpu_ffi.rs -- field-for-field #[repr(C)] mirrors of include/jtk_lc.h + the extern block
+// NOT compiled in this repository: the build image has no Rust toolchain (cargo, rustc: command not found) and the
+// reference's git dependencies are un-vendored.  Source a jtk maintainer adds to ban-m/jtk; INTEGRATION.md explains it and
+// tests/test_rust_shim_source.py keeps it in step with include/jtk_lc.h.  The same call sequence is exercised end to end
+// by the C++ host mirror (jtk_amd/csrc/host/local_clustering.hpp) and the Python harness (jtk_amd/api.py).
+use std::os::raw::{c_char, c_int};
+
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct JtkHmm {                       // == definitions::HMMParam (definitions/src/lib.rs:101-126)
+    pub mat_mat: f64, pub mat_ins: f64, pub mat_del: f64,
+    pub ins_mat: f64, pub ins_ins: f64, pub ins_del: f64,
+    pub del_mat: f64, pub del_ins: f64, pub del_del: f64,
+    pub mat_emit: [f64; 16], pub ins_emit: [f64; 20],
+}
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct JtkGainProfile { pub gain: f64, pub prob: f64 }     // likelihood_gains.rs:41-47
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct JtkGains {                                           // likelihood_gains.rs:55-61
+    pub max_homopolymer_len: u32, pub reserved: u32,
+    pub subst: [JtkGainProfile; 8], pub deletions: [JtkGainProfile; 8], pub insertions: [JtkGainProfile; 8],
+}
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct JtkLcParams {
+    pub forward: JtkHmm, pub reverse: JtkHmm, pub gains: JtkGains,
+    pub haploid_coverage: f64, pub band_frac: f64,
+}
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct JtkLcChunk {
+    pub chunk_id: u64, pub copy_num: u32, pub n_reads: u32,
+    pub tmpl_off: u64, pub tmpl_len: u64, pub read_first: u64,
+}
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct JtkLcResult {
+    pub score: f64, pub cluster_num: u32, pub status: i32, pub polish_rounds: u32, pub n_variants: u32,
+}
+
+extern "C" {
+    pub fn jtk_lc_cluster_chunks(
+        params: *const JtkLcParams, n_chunks: usize, chunks: *const JtkLcChunk,
+        tmpl_bases: *const u8, read_bases: *const u8, read_off: *const u64,
+        ops: *const u8, ops_off: *const u64, strand: *const u8,
+        label: *mut u32, log_post: *mut f64, post_stride: u32, result: *mut JtkLcResult,
+        cons_out: *mut u8, cons_off: *mut u64, cons_cap: u64,
+        ops_out: *mut u8, ops_out_off: *mut u64, ops_cap: u64, device: c_int) -> c_int;
+    pub fn jtk_lc_estimate_gains(forward: *const JtkHmm, reverse: *const JtkHmm, seed: u64, seq_len: u32, band: u32,
+                                 homop_len: u32, out: *mut JtkGains, device: c_int) -> c_int;   // likelihood_gains.rs:162-192
+    pub fn jtk_lc_trim_cache(device: c_int) -> c_int;          // hand pooled device workspaces back to the driver
+    pub fn jtk_lc_strerror(status: c_int) -> *const c_char;
+    pub fn jtk_lc_last_error() -> *const c_char;
+}

@@ -66,9 +66,49 @@ def synthetic_dataset(n_chunks, tmpl_len, rph):
     return {"input_file": "synthetic", "masked_kmers": {"k": 0, "thr": 0}, "coverage": {"Protected": float(rph)},
             "raw_reads": [], "hic_pairs": [], "selected_chunks": chunks, "encoded_reads": reads, "hic_edges": [],
             "read_type": "ONT", "model_param": {"forward": hmm, "reverse": copy.deepcopy(hmm)},
-            "error_rate": {"del": 0.01, "del_sd": 0.0, "ins": 0.01, "ins_sd": 0.0, "mismatch": 0.01, "mismatch_sd": 0.0,
+            "error_rate": {"del": 0.01, "del_sd": 0.0, "ins": 0.01, "ins_sd": 0.0, "mismatch": 0.01, "mism_sd": 0.0,
                            "total": 0.03, "total_sd": 0.0},
             "processed_stages": [{"stage_name": "encode", "arg": []}]}
+
+
+def test_synthetic_dataset_has_exactly_the_reference_fields():
+    """every struct of the wire format carries exactly the fields of its serde derive (definitions/src/lib.rs), in
+    particular ErrorRate's `mism_sd` (:906); a missing field or an unknown enum variant is rejected like serde does"""
+    ds = synthetic_dataset(2, 120, 2)
+    D.validate(ds)
+    assert tuple(ds) == D.SCHEMA["DataSet"]
+    assert set(ds["error_rate"]) == set(D.SCHEMA["ErrorRate"])
+    assert set(ds["selected_chunks"][0]) == set(D.SCHEMA["Chunk"])
+    assert set(ds["encoded_reads"][0]) == set(D.SCHEMA["EncodedRead"])
+    assert set(ds["encoded_reads"][0]["nodes"][0]) == set(D.SCHEMA["Node"])
+    assert set(ds["model_param"]["forward"]) == set(D.SCHEMA["HMMParam"])
+    assert set(ds["processed_stages"][0]) == set(D.SCHEMA["ProcessedStage"])
+    assert set(ds["masked_kmers"]) == set(D.SCHEMA["MaskInfo"])
+    # the derive field lists themselves, against the reference source when it is there (not on the GPU box)
+    ref = "/root/reference/definitions/src/lib.rs"
+    if os.path.exists(ref):
+        import re
+        src = open(ref).read()
+        for struct, fields in D.SCHEMA.items():
+            body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, src, flags=re.S).group(1)
+            assert tuple(re.findall(r"^\s*pub ([a-z_0-9]+):", body, flags=re.M)) == fields, struct
+    for breakage in ("error_rate.mism_sd", "model_param.reverse", "selected_chunks.0.copy_num", "encoded_reads.1.nodes.0.cigar"):
+        bad = copy.deepcopy(ds)
+        path = breakage.split(".")
+        obj = bad
+        for k in path[:-1]:
+            obj = obj[int(k)] if isinstance(obj, list) else obj[k]
+        del obj[path[-1]]
+        with pytest.raises(ValueError):
+            D.validate(bad)
+    bad = copy.deepcopy(ds)
+    bad["read_type"] = "PacBio"
+    with pytest.raises(ValueError):
+        D.validate(bad)
+    bad = copy.deepcopy(ds)
+    bad["coverage"] = {"Guessed": 3.0}
+    with pytest.raises(ValueError):
+        D.validate(bad)
 
 
 def test_untouched_fields_survive_the_json_round_trip(tmp_path):
