@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- chunks clustered per second on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (polish -> variant search -> clustering, jtk_lc_session_run) over one
-resident batch of synthetic pile-ups.  At N = 1 the workload is BASELINE.json configs[1]: a synthetic 1 Mb
-2-haplotype region, 60x ONT error model, 500 chunks x 2 kbp, copy number 2.  With N > 1 every rank (one
-process per GPU) clusters its own 500 chunks (weak scaling, chunk ids rank*500..), there is no data-path
-collective, and the cluster labels are all-gathered over RCCL at the end of every step.
+A "step" is ONE PASS of the hot path (polish -> variant search -> clustering, jtk_lc_session_run, then the fetch of
+labels / posteriors / cluster counts / scores to the host) over the whole synthetic dataset, inputs resident in HBM.
+The default workload is the configuration BASELINE.json's metric is quoted on: the 5 Mb diploid 60x ONT dataset,
+2,500 chunks x 60 reads x 2 kbp (configs[2]; it fits one GPU).  `--gpus N` is STRONG scaling on that fixed dataset:
+one process per GPU, the chunks dealt to the ranks longest-processing-time-first (jtk_amd/sharding.py), no data-path
+collective, and ONE RCCL all-gather of (label, log_post, cluster_num, score) per step.
+`--scaling weak` gives every rank its own `--chunks` chunks instead.
 
-Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement" for how each field is obtained.
+Inside a rank the shard is cut into `--streams` slices, each a resident session with its own HIP stream and host
+thread: one slice's pair-HMM passes fill the CUs another slice's chain kernel leaves idle.  Memory is that of ONE copy
+of the shard.  There is no barrier between steps inside the timed region (slice i of step s+1 starts when slice i of
+step s has been fetched); the region is bracketed by barrier + torch.cuda.synchronize() on both sides.
+
+Prints ONE JSON line on rank 0.  DESIGN.md "Measurement" says how each field is obtained.
 """
 import argparse
+import hashlib
 import json
 import os
-import sys
 import queue
+import sys
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -28,80 +36,120 @@ sys.path.insert(0, ROOT)
 
 from jtk_amd import api, batch as jb, build as jbuild, ffi, sharding, synth  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CLOCK_HZ = 2.4e9         # MI355X_MICROARCH.md: max clock
 WORKLOADS = {
     "cfg2_ont_diploid_500x60x2kbp": dict(config="ont_diploid", chunks=500),
     "cfg3_ont_diploid_2500x60x2kbp": dict(config="ont_diploid", chunks=2500),
     "cfg4_ont_4copy_2500x160x2kbp": dict(config="ont_4copy", chunks=2500),
     "cfg5_hifi_diploid_2500x40x2kbp": dict(config="hifi_diploid", chunks=2500),
 }
+# f64 operations of the pair-HMM specification per band cell and pass (an fma counts 2):
+# forward 2 emission products + 3 x (mul + 2 fma) = 17, backward the same, 22 fma into the row accumulators = 44
+PHMM_FLOP_PER_CELL = 17 + 17 + 44
 
 
-def make_batch_parallel(config, n_chunks, first_chunk_id, threads=8):
+def make_batch_parallel(config, chunk_ids, threads=8):
     cfg = dict(synth.CONFIGS[config])
     with ThreadPoolExecutor(max_workers=threads) as ex:   # ctypes releases the GIL inside jtk_synth_pileup
-        pile = list(ex.map(lambda c: synth.make_pileup(first_chunk_id + c, cfg), range(n_chunks)))
+        pile = list(ex.map(lambda c: synth.make_pileup(int(c), cfg), chunk_ids))
     return jb.pack(pile), cfg
 
 
-def cpu_baseline(params, batch, sample_chunks, threads):
-    """The oracle (CPU restatement, OpenMP over chunks like the reference's rayon loop) on a bounded sample of
-    the same workload, on this box's host cores."""
+def lib_sha16():
+    h = hashlib.sha256()
+    with open(ffi.LIB_PATH, "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(params, batch, threads):
+    """The oracle (CPU restatement of the path, OpenMP over chunks like the reference's rayon loop, mod.rs:64-72) on a
+    bounded sample of the same workload on this box's host cores: one chunk per core with every core busy, and a
+    one-thread figure (the reference's own harness pins one thread, benchmark_clustering.rs:45-48)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi as O
     import helpers
-    sub = batch.subset(range(sample_chunks))
     po = helpers.oracle_params(params)
+    n_all = max(1, min(batch.n_chunks, threads))
+    sub = batch.subset(range(n_all))
     t0 = time.perf_counter()
     r = O.cluster_chunks(po, sub, skip_polish=False, n_threads=threads, want_record=True)
     dt = time.perf_counter() - t0
-    return dict(value=sample_chunks / dt, unit="chunks/s", cores=threads, kind="port",
-                sample=f"first {sample_chunks} chunks of the same batch, full path (polish+search+clustering), "
-                       f"{dt:.1f} s wall, mean RECORD {float(r['record_ms'][:, 0].mean()):.0f} ms/chunk"), sub, r
+    n_one = max(1, min(3, batch.n_chunks))
+    one = batch.subset(range(n_one))
+    t1 = time.perf_counter()
+    O.cluster_chunks(po, one, skip_polish=False, n_threads=1)
+    dt1 = time.perf_counter() - t1
+    return dict(value=n_all / dt, unit="chunks/s", cores=threads, kind="port",
+                sample=f"first {n_all} chunks of the same dataset (one per core, all {threads} cores busy), full path "
+                       f"(polish + variant search + clustering), {dt:.1f} s wall, mean RECORD "
+                       f"{float(r['record_ms'][:, 0].mean()):.0f} ms/chunk/thread under that load",
+                one_thread=dict(value=n_one / dt1, unit="chunks/s", cores=1,
+                                sample=f"first {n_one} chunks, {dt1:.1f} s wall on an otherwise idle host")), sub, r
 
 
-def pmc_traffic(family, workload, n_chunks):
-    """HBM bytes per launch of the dominant kernel family from the rocprofv3 PMC passes committed under profiles/
-    (scripts/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction).  None when no profile of this
-    workload is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def pmc_traffic(workload, sha):
+    """HBM bytes per launch per kernel family from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
+    doubled per the gfx950 correction), but only when they were taken on THIS build of the library and this workload;
+    otherwise None: a stale profile says nothing about the kernels being timed."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         prof = json.load(open(path))
-    except OSError:
-        return None
-    if prof.get("workload") != workload or n_chunks != WORKLOADS[workload]["chunks"]:
-        return None
-    total = 0.0
-    for k in prof["kernel_family"].get(family, []):
-        e = prof["kernels"].get(k)
-        if e:
-            total += (2.0 * e.get("FETCH_SIZE_KiB_per_launch", 0.0) + e.get("WRITE_SIZE_KiB_per_launch", 0.0)) * 1024.0
-    return total
+    except (OSError, ValueError):
+        return None, "no profiles/r02_pmc_traffic.json"
+    if prof.get("lib_sha16") != sha:
+        return None, f"profiles/r02_pmc_traffic.json was taken on library {prof.get('lib_sha16')}, this is {sha}"
+    if prof.get("workload") != workload:
+        return None, f"profiles/r02_pmc_traffic.json is for workload {prof.get('workload')}"
+    out = {}
+    for fam, kernels in prof["kernel_family"].items():
+        tot = 0.0
+        for k in kernels:
+            e = prof["kernels"].get(k)
+            if e:
+                tot += (2.0 * e.get("FETCH_SIZE_KiB_per_launch", 0.0) + e.get("WRITE_SIZE_KiB_per_launch", 0.0)) * 1024.0
+        out[fam] = tot
+    return out, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg2_ont_diploid_500x60x2kbp", choices=sorted(WORKLOADS))
-    ap.add_argument("--chunks", type=int, default=0, help="override chunks per GPU (diagnostic runs only)")
+    ap.add_argument("--workload", default="cfg3_ont_diploid_2500x60x2kbp", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
+                    help="strong: the workload's fixed dataset is sharded over the ranks; weak: every rank its own chunks")
+    ap.add_argument("--chunks", type=int, default=0, help="override the dataset size (strong) / chunks per GPU (weak)")
     ap.add_argument("--streams", type=int, default=4,
-                    help="resident batches in flight, each on its own HIP stream and host thread (1 = strictly serial steps)")
+                    help="slices of the rank's shard in flight, each a resident session on its own HIP stream and host thread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="chunks in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the one-shot (host buffers in, host buffers out) timing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # diagnostic only: JTK_BENCH_BACKEND=gloo runs the multi-rank path with every rank on GPU 0 (1-GPU boxes)
+    # diagnostic / CPU-box tests: JTK_BENCH_BACKEND=gloo runs the multi-rank path with every rank on GPU 0
     backend = os.environ.get("JTK_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = 0
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    jbuild.build()
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} (one rank per GPU)")
+    # The library is built by __graft_entry__.build() BEFORE the bench (never inside a timed or profiled process, never
+    # by N ranks at once).  Only a missing library is built here, by local rank 0.
+    if not os.path.exists(ffi.LIB_PATH) or not os.path.exists(ffi.SYNTH_LIB_PATH):
+        if local_rank == 0:
+            jbuild.build()
+        else:
+            while not (os.path.exists(ffi.LIB_PATH) and os.path.exists(ffi.SYNTH_LIB_PATH)):
+                time.sleep(1.0)
+    elif rank == 0 and jbuild.is_stale():
+        sys.stderr.write("bench.py: WARNING: a source is newer than libjtk_lc.so; timing the library as built "
+                         "(run __graft_entry__.build() first)\n")
+    sha = lib_sha16()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU (torch sees none)")
     torch.cuda.set_device(local_rank)
@@ -113,18 +161,24 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(local_rank)
 
     wl = WORKLOADS[args.workload]
-    n_chunks = args.chunks or wl["chunks"]
-    batch, cfg = make_batch_parallel(wl["config"], n_chunks, first_chunk_id=sharding.weak_chunk_ids(rank, n_chunks)[0])
+    cfg0 = synth.CONFIGS[wl["config"]]
+    n_total = args.chunks or wl["chunks"]
+    reads_per_chunk = cfg0["n_haps"] * cfg0["reads_per_hap"]
+    if args.scaling == "strong":
+        parts = sharding.strong_shards(n_total, reads_per_chunk, cfg0["tmpl_len"], cfg0["copy_num"], world)
+    else:
+        parts = [np.array(sharding.weak_chunk_ids(r, n_total), dtype=np.int64) for r in range(world)]
+        n_total = n_total * world
+    my_ids = parts[rank]
+    batch, cfg = make_batch_parallel(wl["config"], my_ids)
     params = jb.default_params(haploid_coverage=cfg["coverage"], band_frac=cfg["band_frac"])
+    stride = batch.post_stride
 
     def barrier():
         torch.cuda.synchronize()
@@ -132,62 +186,69 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # A step is one pass of the hot path over one resident 500-chunk batch.  Up to --streams batches are in flight:
-    # each has its own session (HIP stream, workspaces) and host thread, so one batch's pair-HMM passes fill the
-    # CUs that another batch's chain kernel leaves idle during its long tail.  Step s runs on session s % streams;
-    # every session holds the same synthetic batch, so every step does the same work as with --streams 1.
-    n_streams = max(1, min(args.streams, args.steps))
-    free0 = torch.cuda.mem_get_info(local_rank)[0]
-    sessions = [api.Session(params, batch, device=local_rank)]
-    per_session = free0 - torch.cuda.mem_get_info(local_rank)[0]      # every workspace is allocated up front
-    while len(sessions) < n_streams and torch.cuda.mem_get_info(local_rank)[0] > 1.25 * per_session:
-        sessions.append(api.Session(params, batch, device=local_rank))
-    n_streams = len(sessions)                                         # fewer in flight when HBM is the limit (cfg 3/4)
-    sess = sessions[0]
-    gathered = None
+    # ---- the rank's shard as `streams` resident slices (equal shares of the reads, contiguous chunk ranges)
+    n_streams = max(1, min(args.streams, batch.n_chunks))
+    bounds = [round(i * batch.n_chunks / n_streams) for i in range(n_streams + 1)]
+    slices = [batch.subset(range(bounds[i], bounds[i + 1])) for i in range(n_streams)]
+    sessions = [api.Session(params, sl, device=local_rank) for sl in slices]
+    read_bounds = np.cumsum([0] + [sl.n_reads for sl in slices])
+    gather = None
+    if dist is not None:
+        sizes = [(len(p) * reads_per_chunk, len(p)) for p in parts]
+        gather = sharding.ResultGather(dist, sizes, stride,
+                                       device=torch.device("cuda", local_rank) if backend == "nccl" else None)
     ktime = {n: 0.0 for n in ffi.KERNEL_NAMES}
     klaunch = {n: 0 for n in ffi.KERNEL_NAMES}
-    dev_ms = 0.0
+    state = dict(dev_ms=0.0, gathered=None, last=None)
 
-    def run_steps(n_steps, timed):
-        nonlocal gathered, dev_ms
+    def run_steps(n_steps, timed, serial=False):
+        """n_steps passes over the shard.  serial: the slices run one after another (kernel breakdown pass)."""
         done = queue.Queue()
 
         def worker(i):
             try:
-                for s in range(i, n_steps, n_streams):
-                    sessions[i].run(skip_polish=False)   # synchronous: returns when the device has finished this pass
+                for s in range(n_steps):
+                    sessions[i].run(skip_polish=False)   # returns when the device has finished this slice's pass
                     t = api.last_timing()                # thread-local: the pass this thread just ran
-                    lab = sessions[i].fetch()["label"] if dist is not None else None
-                    done.put((s, t, lab))
+                    out = sessions[i].fetch_results()    # labels, posteriors, k, score -> host (inside the step)
+                    done.put((s, i, t, out))
             except BaseException as e:  # noqa: BLE001 -- handed to the main thread
-                done.put((-1, e, None))
+                done.put((-1, i, e, None))
 
-        threads = [threading.Thread(target=worker, args=(i,)) for i in range(n_streams)]
-        for th in threads:
-            th.start()
-        finished, nxt = {}, 0
-        while nxt < n_steps:
-            s, t, lab = done.get()
+        if serial:
+            for i in range(n_streams):
+                worker(i)
+            threads = []
+        else:
+            threads = [threading.Thread(target=worker, args=(i,)) for i in range(n_streams)]
+            for th in threads:
+                th.start()
+        pending = {}
+        for _ in range(n_steps * n_streams):
+            s, i, t, out = done.get()
             if s < 0:
                 raise t
-            finished[s] = (t, lab)
-            while nxt in finished:       # in step order on every rank
-                t, lab = finished.pop(nxt)
-                if dist is not None:     # the only exchange of the path: labels, RCCL all-gather
-                    gathered = sharding.all_gather_labels(
-                        dist, lab, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
-                if timed:
-                    dev_ms += t["total_ms"]
-                    for n in ffi.KERNEL_NAMES:
-                        ktime[n] += t["kernel_ms"][n]
-                        klaunch[n] += t["kernel_launches"][n]
-                nxt += 1
+            pending.setdefault(s, {})[i] = out
+            if timed:
+                state["dev_ms"] += t["total_ms"]
+                for n in ffi.KERNEL_NAMES:
+                    ktime[n] += t["kernel_ms"][n]
+                    klaunch[n] += t["kernel_launches"][n]
+            if len(pending[s]) == n_streams:             # step s is complete on this rank
+                outs = [pending[s][j] for j in range(n_streams)]
+                del pending[s]
+                merged = dict(label=np.concatenate([o["label"] for o in outs]),
+                              log_post=np.concatenate([o["log_post"] for o in outs]),
+                              result=np.concatenate([o["result"] for o in outs]))
+                state["last"] = merged
+                if gather is not None:                   # the only exchange of the path: one all-gather per step
+                    state["gathered"] = gather.gather(merged["label"], merged["log_post"],
+                                                      merged["result"]["cluster_num"], merged["result"]["score"])
         for th in threads:
             th.join()
 
     for _ in range(args.warmup):
-        run_steps(n_streams, timed=False)      # one untimed pass on every session
+        run_steps(1, timed=False)
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps, timed=True)
@@ -197,63 +258,122 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
-    out = sess.fetch()
-    streams_agree = all(np.array_equal(s.fetch()["label"], out["label"]) for s in sessions[1:])
+    value = n_total * args.steps / elapsed
+    out = state["last"]
     ok = int((out["result"]["status"] == 0).sum())
-    total_chunks = n_chunks * world * args.steps
-    value = total_chunks / elapsed
+    overl_k = {n: ktime[n] / args.steps for n in ffi.KERNEL_NAMES}
+    overl_slice_ms = state["dev_ms"] / (args.steps * n_streams)
 
-    # ---- roofline of the dominant kernel family (HIP events on the library's own stream, summed over the
-    #      timed steps): algorithmic bytes of the chunks one launch sequence processes / its device time
-    dom = max(ktime, key=lambda n: ktime[n])
-    alg_bytes_per_step = batch.algorithmic_bytes(k_per_chunk=out["result"]["cluster_num"])
-    dom_ms_per_step = ktime[dom] / args.steps
-    achieved = alg_bytes_per_step / 1e9 / (dom_ms_per_step / 1e3) if dom_ms_per_step > 0 else 0.0
-    roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s", frac=achieved / HBM_PEAK_GBPS,
-                    traffic=pmc_traffic(dom, args.workload, n_chunks), kernel=dom, kernel_ms_per_step=dom_ms_per_step,
-                    launches_per_step=klaunch[dom] / args.steps,
-                    algorithmic_bytes_per_step=alg_bytes_per_step,
-                    all_kernels_ms_per_step={n: ktime[n] / args.steps for n in ffi.KERNEL_NAMES},
-                    # measured HBM traffic (committed PMC passes) of every kernel family against its live device time:
-                    # what each family actually moves, as opposed to the algorithmic bytes above
-                    hbm_traffic_by_kernel={
-                        n: dict(ms_per_step=ktime[n] / args.steps, launches_per_step=klaunch[n] / args.steps,
-                                traffic_bytes_per_launch=pmc_traffic(n, args.workload, n_chunks),
-                                traffic_GBps=(pmc_traffic(n, args.workload, n_chunks) * klaunch[n] / 1e9 / (ktime[n] / 1e3)
-                                              if pmc_traffic(n, args.workload, n_chunks) and ktime[n] > 0 else None))
-                        for n in ffi.KERNEL_NAMES},
-                    note="byte/integer + f64 scan work: HBM-compulsory traffic is ~126 KB/chunk, so the HBM fraction "
-                         "is tiny by construction; the binding limits are the serial Metropolis chain latency and "
-                         "FP64 VALU in the banded pair-HMM (DESIGN.md).  kernel_ms_per_step is the mean duration of the "
-                         "kernel's launches; with several batches in flight launches of different batches overlap, so it "
-                         "can exceed ms_per_step")
+    # ---- a serial pass (slices one after another, nothing overlapped): per-kernel device time that adds up
+    for n in ffi.KERNEL_NAMES:
+        ktime[n], klaunch[n] = 0.0, 0
+    state["dev_ms"] = 0.0
+    torch.cuda.synchronize()
+    ts = time.perf_counter()
+    run_steps(1, timed=True, serial=True)
+    serial_ms = (time.perf_counter() - ts) * 1e3
+    serial_k = dict(ktime)
+    serial_launch = dict(klaunch)
+    serial_out = state["last"]
+    steps_agree = bool(np.array_equal(serial_out["label"], out["label"]))
+
+    # ---- roofline: achieved = chunks/s (whole job) x algorithmic bytes per chunk; frac against 8 TB/s per GPU
+    alg_bytes_shard = batch.algorithmic_bytes(k_per_chunk=out["result"]["cluster_num"])
+    alg_bytes_per_chunk = alg_bytes_shard / max(1, batch.n_chunks)
+    achieved = value * alg_bytes_per_chunk / 1e9
+    dom = max(serial_k, key=lambda n: serial_k[n])
+    traffic, traffic_note = pmc_traffic(args.workload, sha)
+    # secondary bounds: f64 rate of the banded pair-HMM and the chain's cycles per proposal
+    res = out["result"]
+    passes = np.minimum(res["polish_rounds"].astype(np.int64) + (res["polish_rounds"] >= 20), 21)
+    cells = 0.0
+    for c in range(batch.n_chunks):
+        ch = batch.chunks[c]
+        r0, r1 = int(ch["read_first"]), int(ch["read_first"]) + int(ch["n_reads"])
+        diag = int(ch["n_reads"]) * int(ch["tmpl_len"]) + int(batch.read_off[r1] - batch.read_off[r0])   # sum of L + n
+        radius = int(np.ceil(int(ch["tmpl_len"]) * cfg["band_frac"])) // 2
+        cells += float(passes[c]) * diag * (2 * radius + 1)
+    phmm_s = serial_k["phmm"] / 1e3
+    k_tried = np.maximum(1, np.minimum(int(cfg["copy_num"]), 1 + 2 * res["n_variants"].astype(np.int64)) - 1)
+    proposals_max = float((20 * 2000 * batch.chunks["n_reads"].astype(np.int64) * k_tried * (res["n_variants"] > 0)).max())
+    mcmc_launches = max(1, serial_launch["mcmc"])
+    secondary = dict(
+        fp64_tflops=(cells * PHMM_FLOP_PER_CELL / phmm_s / 1e12) if phmm_s > 0 else None,
+        fp64_peak_tflops=78.6,
+        chain_cycles_per_proposal=(serial_k["mcmc"] / mcmc_launches * 1e-3 * CLOCK_HZ / proposals_max) if proposals_max else None,
+        note="fp64_tflops: f64 operations of the pair-HMM specification (78 per band cell and pass, fma = 2) over the "
+             "serial pass's pair-HMM device time, vs the 78.6 TFLOP/s vector f64 peak; chain_cycles_per_proposal: the "
+             "chain kernel's launch duration (set by its slowest chunk) x 2.4 GHz / that chunk's 20 x 2000 x n x "
+             "(#k tried) proposals")
+    roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS * world, unit="GB/s",
+                    frac=achieved / (HBM_PEAK_GBPS * world),
+                    traffic=(traffic or {}).get(dom) if traffic else None, traffic_note=traffic_note,
+                    algorithmic_bytes_per_chunk=alg_bytes_per_chunk,
+                    dominant_kernel=dict(
+                        name=dom, launches_per_pass=serial_launch[dom], ms_per_pass=serial_k[dom],
+                        avg_launch_ms=serial_k[dom] / max(1, serial_launch[dom]),
+                        # per-launch form: the algorithmic bytes of the chunks one launch processes / its mean duration
+                        achieved_GBps_per_launch=(alg_bytes_shard / n_streams / 1e9) /
+                        (serial_k[dom] / max(1, serial_launch[dom]) / 1e3) if serial_k[dom] > 0 else None),
+                    serial_pass=dict(wall_ms=serial_ms, kernel_ms=serial_k, kernel_launches=serial_launch,
+                                     kernel_ms_sum=sum(serial_k.values()),
+                                     note="slices run one after another: the kernel times add up to <= wall_ms"),
+                    overlapped_kernel_ms_per_step=overl_k,
+                    hbm_traffic_by_kernel=traffic, secondary=secondary,
+                    note="achieved = value x algorithmic bytes per chunk (SURVEY.md 8d: packed 4-bit bases, 2-bit ops, u32 "
+                         "labels, f64 posteriors), frac = achieved / (8 TB/s x n_gpus).  Byte/integer + f64 scan work: the "
+                         "compulsory HBM traffic is ~126 KB/chunk, so the HBM fraction is tiny by construction; the binding "
+                         "limits are the `secondary` ones.  traffic = PMC-measured HBM bytes per launch of the dominant "
+                         "kernel family, only when the committed profile was taken on this exact library build")
 
     line = dict(metric="chunks clustered/sec (whole node), 60x ONT 2kbp chunks", value=value, unit="chunks/s",
                 n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
-                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-                config=dict(workload=args.workload, chunks_per_gpu=n_chunks, reads_per_chunk=int(batch.chunks["n_reads"][0]),
-                            chunk_len=int(cfg["tmpl_len"]), copy_num=int(cfg["copy_num"]), band_frac=cfg["band_frac"],
-                            sharding=f"chunks/{world}gpu, labels all-gathered over RCCL" if world > 1 else "1 gpu",
-                            batches_in_flight=n_streams),
-                roofline=roofline, pass_latency_ms=dev_ms / args.steps, streams_agree=bool(streams_agree), chunks_ok=ok,
+                higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f64", data="synthetic",
+                config=dict(workload=args.workload, chunks_total=int(n_total), chunks_this_rank=int(batch.n_chunks),
+                            reads_per_chunk=int(reads_per_chunk), chunk_len=int(cfg["tmpl_len"]),
+                            copy_num=int(cfg["copy_num"]), band_frac=cfg["band_frac"],
+                            sharding=(f"{args.scaling}: chunks dealt LPT to {world} ranks, one all-gather of "
+                                      "(label, log_post, k, score) per step over RCCL") if world > 1 else "1 gpu",
+                            slices_in_flight=n_streams, step="one pass over the dataset incl. fetch of the results"),
+                roofline=roofline, slice_pass_latency_ms=overl_slice_ms,
+                serial_step_agrees=steps_agree, chunks_ok=ok, lib_sha16=sha,
                 mean_polish_rounds=float(out["result"]["polish_rounds"].mean()),
                 mean_cluster_num=float(out["result"]["cluster_num"].mean()))
+    if gather is not None and rank == 0:
+        g = state["gathered"]
+        line["gathered_reads"] = int(sum(len(x["label"]) for x in g))
+        line["gather_ok"] = bool(np.array_equal(g[0]["label"], out["label"]))
+
+    for s in sessions:
+        s.close()
+    # ---- end to end: what one stage call costs a host that hands over HOST buffers (encode + allocate + H2D + run +
+    #      fetch + free): jtk_lc_cluster_chunks on this rank's shard.  PCIe-inclusive; never `value`.
+    if not args.no_e2e:
+        api.trim_cache(local_rank)
+        t1 = time.perf_counter()
+        api.cluster_chunks(params, batch, device=local_rank)
+        cold = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        one = api.cluster_chunks(params, batch, device=local_rank)
+        warm = time.perf_counter() - t2
+        tm = api.last_timing()
+        line["e2e"] = dict(chunks_per_s=batch.n_chunks / warm, seconds=warm, first_call_seconds=cold,
+                           h2d_ms=tm["h2d_ms"], d2h_ms=tm["d2h_ms"], matches_resident=bool(np.array_equal(one["label"], out["label"])),
+                           note="jtk_lc_cluster_chunks on this rank's shard from host buffers to host buffers; the first call "
+                                "also maps the device workspaces, the second reuses the pooled blocks")
+    api.trim_cache(local_rank)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = os.cpu_count() or 1
-        sample = args.cpu_sample or max(2, min(n_chunks, threads // 2 if threads >= 16 else 4))
-        cb, sub, ora = cpu_baseline(params, batch, sample, threads)
+        cb, sub, ora = cpu_baseline(params, batch, threads)
         line["cpu_baseline"] = cb
         # the checker doing its job on the sample: labels bit-exact, posteriors within 1e-4
         nr = int(sub.n_reads)
         line["parity_on_cpu_sample"] = dict(
-            labels_equal=bool(np.array_equal(out["label"][:nr], ora["label"])),
+            chunks=int(sub.n_chunks), labels_equal=bool(np.array_equal(out["label"][:nr], ora["label"])),
             max_abs_dlogpost=float(np.abs(out["log_post"][:nr] - ora["log_post"]).max()))
     elif rank == 0:
         line["cpu_baseline"] = None
-    for s in sessions:
-        s.close()
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:

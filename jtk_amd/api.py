@@ -135,6 +135,18 @@ class Session:
         o["rc"] = rc
         return o
 
+    def fetch_results(self, raise_on_chunk_failure=True):
+        """labels, log-posteriors and the per-chunk records only (no consensus / ops): the payload of the label gather"""
+        b = self.batch
+        label = np.zeros(b.n_reads, dtype=np.uint32)
+        post = np.zeros((b.n_reads, b.post_stride), dtype=np.float64)
+        result = np.zeros(b.n_chunks, dtype=ffi.RESULT_DT)
+        rc = self._lib.jtk_lc_session_fetch(self._h, u32p(label), f64p(post), result.ctypes.data, None, None, 0, None,
+                                            None, 0)
+        if rc != 0 and (raise_on_chunk_failure or rc != -6):
+            check(rc)
+        return dict(rc=rc, label=label, log_post=post, result=result)
+
     def close(self):
         if self._h:
             self._lib.jtk_lc_session_destroy(self._h)

@@ -24,6 +24,8 @@
 //    ((tg - x) + x, not a restore); get_lk's left-to-right sum visits only the non-zero terms.
 // Sums that the reference evaluates left to right are evaluated left to right here -- integer labels only
 // match if every f64 rounding matches.
+#include <cstdlib>
+#include <type_traits>
 #include <mutex>
 #include <vector>
 
@@ -61,15 +63,22 @@ __device__ __forceinline__ uint32_t ring_slot(uint32_t pos) {
 struct RCtl {
     uint32_t rd, quit;  // written by the consumer (read together, 8-byte aligned)
     uint32_t wr, wp;    // written by the producer: draws produced / stream positions whose proposal record exists
-    uint32_t parse_n;   // written once by the consumer before the producer starts: n of the diploid chain, 0 = no records
-    uint32_t pad[3];
+    // Proposal records are parsed for ONE (format, K) at a time.  The consumer announces a new mode by writing parse_from
+    // (the stream position from which it will read records), parse_n and then pmode = epoch << 16 | mode; the producer
+    // re-parses from parse_from and acknowledges with wp_epoch = epoch (after resetting wp).
+    uint32_t parse_n;     // reads in the pile-up
+    uint32_t parse_from;
+    uint32_t pmode;       // mode: 0 = no records, PM_K2 = the diploid chain's format, otherwise K of the general format
+    uint32_t wp_epoch;
 };
+#define PM_K2 0x100u
 // The consumer's view of the generator: a position in the stream of Xoshiro256StarStar::seed_from_u64(id * 3490)
 // (local_clustering/mod.rs:97).  next_u64 == rand_xoshiro's next_u64, one stream position later.
 struct Rng {
     uint32_t pos;      // next draw to take (absolute stream position)
     uint32_t wr_seen;  // producer progress last observed
     uint32_t wp_seen;  // record progress last observed
+    uint32_t pmode;    // the parse mode last announced (epoch << 16 | mode)
     uint32_t win_base; // stream position of the draw held by lane 0 of `win`
     uint64_t win;      // per lane: the raw draw at win_base + lane (one LDS read serves 64 sequential draws)
 #ifdef JTK_MCMC_STATS
@@ -101,6 +110,21 @@ __device__ __forceinline__ void rng_wait_rec(Rng &r, uint32_t upto) {  // until 
 #endif
         if ((int32_t)(r.wp_seen - upto) < 0) __builtin_amdgcn_s_sleep(1);
     }
+}
+// The records from stream position r.pos on are wanted in `mode` (see RCtl); returns once the producer has switched.
+__device__ __forceinline__ void rng_set_parse_mode(Rng &r, uint32_t mode, uint32_t lane) {
+    if ((r.pmode & 0xffffu) == mode) return;  // the producer parses every position: nothing to re-synchronise
+    const uint32_t word = (((r.pmode >> 16) + 1u) << 16) | mode;
+    r.pmode = word;
+    if (lane == 0) {
+        lds_st32(&r.ctl->rd, r.pos);
+        lds_st32(&r.ctl->parse_from, r.pos);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) lds_st32(&r.ctl->pmode, word);
+    while (uni(lds_ld32(&r.ctl->wp_epoch)) != (word >> 16)) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    r.wp_seen = r.pos;  // progress of the old mode says nothing about the new one
 }
 __device__ __forceinline__ void rng_release(Rng &r, uint32_t lane) {  // draws before r.pos may be overwritten
     if (lane == 0) lds_st32(&r.ctl->rd, r.pos);
@@ -200,6 +224,30 @@ struct Lds {
     uint8_t *prev_used;  // D
     uint8_t *tmp_asn;    // n
     uint8_t *tmp_used;   // D
+    // tables of the table-driven chain (mcmc_chain_tab)
+    float *thr;                 // (lds_k - 1) x npad rejection thresholds, by (pick, read)
+    struct StEnt *st;           // D x K: the LKCount of (column, cluster) as the threshold build gathers it
+    struct ColEnt *col;         // D per-column totals
+    struct SzEnt *sz;           // K per-cluster size terms
+    uint32_t npad;              // row stride of thr
+    uint32_t flags;             // bit 0: take the one-proposal-per-iteration chain (mcmc_chain) instead of mcmc_chain_tab
+};
+struct StEnt {   // 16 bytes: one ds_read_b128
+    double T;    // total_gain
+    int P;       // num_pos | fragile << 16
+    int W;       // 3 num_pos - 7 num_neg
+};
+struct ColEnt {  // 32 bytes
+    double G;    // sum_c max(T, 0)
+    int IU;      // sum_c [T > 0] num_pos
+    int AN;      // number of clusters that are informative
+    int TP;      // reads with a positive value in the column
+    int FR;      // clusters whose `T > 0` could flip by rounding drift
+    int pad[2];
+};
+struct SzEnt {
+    double sz0, szm, szp;  // size_to_lk of the cluster's size, of one read less, of one read more
+    double pad;
 };
 
 // slice.choose_weighted over weights w[0..n) in LDS; cum is scratch. Returns -1 on WeightedError.
@@ -563,6 +611,41 @@ __device__ __forceinline__ void producer_parse(const uint64_t *ring, uint32_t *r
         if (lane < PKEEP) lds_st32(&rec[(base + r * PKEEP + lane) & (RN - 1)], v);
     }
 }
+// Records of the general chain (any K).  A proposal is gen_range(0..n) -- the first draw at or after its start whose
+// widening product passes the zone test -- then gen_index(i) for i = 1..K-1 on the upper halves of the following draws,
+// each with its own zone test (IteratorRandom::choose over the K-1 other clusters, pseudo_mcmc.rs:732: the pick is the
+// last i whose index came out 0), and the next draw is the one a Bernoulli test would compare:
+//   rec[q] = idx (10 bits) | pick << 10 (3) | len << 13 (6: draws used incl. the Bernoulli draw) | top 13 bits of that draw << 19
+// rec == 0: not parsed (needs more look-ahead than the window gives).  `keep` positions are kept per round, so every kept
+// start had 64 - keep draws of look-ahead.
+__device__ __forceinline__ void producer_parse_gen(const uint64_t *ring, uint32_t *rec, uint32_t base, uint32_t n, uint32_t K,
+                                                   uint32_t keep, uint32_t lane) {
+    const uint64_t zone = ((uint64_t)n << __clzll((long long)n)) - 1;
+    const uint64_t draw = lds_ld64(&ring[ring_slot(base + lane)]);
+    const uint32_t v32 = (uint32_t)(draw >> 32);
+    const uint32_t hi = (uint32_t)__umul64hi(draw, (uint64_t)n);
+    const unsigned long long ok0 = __ballot(draw * (uint64_t)n <= zone);
+    const unsigned long long m0 = ok0 >> lane;
+    bool good = m0 != 0ull;
+    uint32_t p = lane + (uint32_t)__builtin_ctzll(m0 | (1ull << 63));  // window offset of the gen_range draw
+    const uint32_t idx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((p & 63u) << 2), (int)hi);
+    uint32_t pick = 0;
+    for (uint32_t i = 1; i < K; i++) {
+        const uint32_t zi = (i << __builtin_clz(i)) - 1u;
+        const uint64_t mi = (uint64_t)v32 * i;
+        const unsigned long long okm = __ballot((uint32_t)mi <= zi);
+        const unsigned long long zm = __ballot((uint32_t)(mi >> 32) == 0u);
+        const unsigned long long mm = (good && p < 63u) ? okm >> (p + 1u) : 0ull;
+        good = good && mm != 0ull;
+        p = (p + 1u + (uint32_t)__builtin_ctzll(mm | (1ull << 63))) & 127u;
+        if (good && ((zm >> (p & 63u)) & 1ull)) pick = i - 1u;
+    }
+    const uint32_t pv = p + 1u;  // the Bernoulli draw
+    good = good && pv < 64u;
+    const uint32_t vhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pv & 63u) << 2), (int)v32);
+    const uint32_t v = good ? (idx | (pick << 10) | ((pv + 1u - lane) << 13) | (vhi & 0xfff80000u)) : 0u;
+    if (lane < keep) lds_st32(&rec[(base + lane) & (RN - 1)], v);
+}
 __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_t *rec, const ulonglong2 *jump, uint64_t seed,
                                               const uint64_t *resume, uint32_t lane) {
     uint64_t z = seed;
@@ -579,7 +662,7 @@ __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_
         x.s3 = splitmix64(z);
     }
     for (uint32_t j = 0; j < lane * SEG; j++) xo_step(x);  // lane l starts at stream position l * SEG
-    const uint32_t parse_n = uni(lds_ld32(&ctl->parse_n));
+    uint32_t parse_n = 0, pmode = 0;
     uint32_t wr = 0, wp = 0;
 #ifdef JTK_MCMC_STATS
     uint32_t st_sleeps = 0;
@@ -592,6 +675,49 @@ __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_
             if (lane == 0) printf("K2PROD wr %u sleeps %u cyc_gen %llu cyc_parse %llu cyc_jump %llu\n", wr, st_sleeps, st_gen, st_parse, st_jump);
 #endif
             return;
+        }
+        {   // a new parse mode: records are re-parsed from the position the consumer names
+            const uint32_t pm = uni(lds_ld32(&ctl->pmode));
+            if (pm != pmode) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                pmode = pm;
+                parse_n = uni(lds_ld32(&ctl->parse_n));
+                wp = uni(lds_ld32(&ctl->parse_from));
+                if (lane == 0) lds_st32(&ctl->wp, wp);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) lds_st32(&ctl->wp_epoch, pm >> 16);
+            }
+        }
+        const uint32_t mode = pmode & 0xffffu;
+        if (mode) {
+#ifdef JTK_MCMC_STATS
+            const unsigned long long tq0 = __builtin_readcyclecounter();
+#endif
+            // a start at q needs draws up to q + 63: the last positions wait for the next superblock
+            bool parsed = false;
+            while ((int32_t)(wr - (wp + 64)) >= 0) {
+                if (mode == PM_K2) {
+                    if ((int32_t)(wr - (wp + 3 * PKEEP + 64)) >= 0) {
+                        producer_parse<4>(ring, rec, wp, parse_n, lane);
+                        wp += 4 * PKEEP;
+                    } else {
+                        producer_parse<1>(ring, rec, wp, parse_n, lane);
+                        wp += PKEEP;
+                    }
+                } else {
+                    const uint32_t keep = mode <= 4u ? 44u : 32u;  // K - 1 more rejection loops need more look-ahead
+                    producer_parse_gen(ring, rec, wp, parse_n, mode, keep, lane);
+                    wp += keep;
+                }
+                parsed = true;
+            }
+            if (parsed) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) lds_st32(&ctl->wp, wp);
+            }
+#ifdef JTK_MCMC_STATS
+            st_parse += __builtin_readcyclecounter() - tq0;
+#endif
         }
         if ((int32_t)(wr + SBLK - (uint32_t)c) > RN) {
 #ifdef JTK_MCMC_STATS
@@ -617,23 +743,8 @@ __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_
         const unsigned long long tp1 = __builtin_readcyclecounter();
         st_gen += tp1 - tp0;
 #endif
-        if (parse_n) {
-            // a start at q needs draws up to q + 63: the last positions wait for the next superblock
-            while ((int32_t)(wr - (wp + 64)) >= 0) {
-                if ((int32_t)(wr - (wp + 3 * PKEEP + 64)) >= 0) {
-                    producer_parse<4>(ring, rec, wp, parse_n, lane);
-                    wp += 4 * PKEEP;
-                } else {
-                    producer_parse<1>(ring, rec, wp, parse_n, lane);
-                    wp += PKEEP;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) lds_st32(&ctl->wp, wp);
-            }
-        }
 #ifdef JTK_MCMC_STATS
         const unsigned long long tp2 = __builtin_readcyclecounter();
-        st_parse += tp2 - tp1;
 #endif
         xo_jump(x, jump);
 #ifdef JTK_MCMC_STATS
@@ -988,6 +1099,537 @@ __device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t 
     return max;
 }
 
+// The rejection threshold from the order-free estimate dA of proposed - lk.  u is the Bernoulli draw truncated to
+// 19 bits (so the true uniform is < u + 2^-19); exp in f32 is good to ~1e-5 relative: 1.001 and 1.3e-6 cover both.
+__device__ __forceinline__ float reject_threshold(double dA, bool pert) {
+    float thr = 2.0f;  // cannot tell: the proposal becomes an event
+    if (!pert && dA < -1e-3) thr = dA <= -44.5 ? -1.0f : __expf((float)dA) * 1.001f + 1.3e-6f;
+    return thr;
+}
+// LDS accessors for the tables of the table-driven chains (generic pointers would make these flat accesses; structs
+// travel as 16-byte vectors: one ds_read_b128 / ds_write_b128 each)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4 lds_c_u32x4;
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+typedef __attribute__((address_space(3))) const double lds_c_f64;
+typedef __attribute__((address_space(3))) float lds_f32;
+__device__ __forceinline__ u32x4 pack_f64_2i(double a, int b, int c) {
+    const uint64_t u = jtk_f64_bits(a);
+    u32x4 v;
+    v.x = (uint32_t)u;
+    v.y = (uint32_t)(u >> 32);
+    v.z = (uint32_t)b;
+    v.w = (uint32_t)c;
+    return v;
+}
+__device__ __forceinline__ double lo_f64(u32x4 v) { return jtk_bits_f64(((uint64_t)v.y << 32) | v.x); }
+__device__ __forceinline__ double hi_f64(u32x4 v) { return jtk_bits_f64(((uint64_t)v.w << 32) | v.z); }
+__device__ __forceinline__ void lds_store_st(StEnt *p, const StEnt &e) { *(lds_u32x4 *)p = pack_f64_2i(e.T, e.P, e.W); }
+__device__ __forceinline__ StEnt lds_load_st(const StEnt *p) {
+    const u32x4 v = *(lds_c_u32x4 *)p;
+    StEnt e;
+    e.T = lo_f64(v);
+    e.P = (int)v.z;
+    e.W = (int)v.w;
+    return e;
+}
+__device__ __forceinline__ void lds_store_col(ColEnt *p, const ColEnt &e) {
+    lds_u32x4 *q = (lds_u32x4 *)p;
+    q[0] = pack_f64_2i(e.G, e.IU, e.AN);
+    u32x4 v;
+    v.x = (uint32_t)e.TP;
+    v.y = (uint32_t)e.FR;
+    v.z = v.w = 0;
+    q[1] = v;
+}
+__device__ __forceinline__ ColEnt lds_load_col(const ColEnt *p) {
+    lds_c_u32x4 *q = (lds_c_u32x4 *)p;
+    const u32x4 a = q[0], b = q[1];
+    ColEnt e;
+    e.G = lo_f64(a);
+    e.IU = (int)a.z;
+    e.AN = (int)a.w;
+    e.TP = (int)b.x;
+    e.FR = (int)b.y;
+    e.pad[0] = e.pad[1] = 0;
+    return e;
+}
+__device__ __forceinline__ void lds_store_sz(SzEnt *p, const SzEnt &e) {
+    lds_u32x4 *q = (lds_u32x4 *)p;
+    const uint64_t a = jtk_f64_bits(e.sz0), b = jtk_f64_bits(e.szm), c = jtk_f64_bits(e.szp);
+    u32x4 v, w;
+    v.x = (uint32_t)a;
+    v.y = (uint32_t)(a >> 32);
+    v.z = (uint32_t)b;
+    v.w = (uint32_t)(b >> 32);
+    w.x = (uint32_t)c;
+    w.y = (uint32_t)(c >> 32);
+    w.z = w.w = 0;
+    q[0] = v;
+    q[1] = w;
+}
+__device__ __forceinline__ SzEnt lds_load_sz(const SzEnt *p) {
+    lds_c_u32x4 *q = (lds_c_u32x4 *)p;
+    const u32x4 a = q[0], b = q[1];
+    SzEnt e;
+    e.sz0 = lo_f64(a);
+    e.szm = hi_f64(a);
+    e.szp = lo_f64(b);
+    e.pad = 0.0;
+    return e;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The table-driven chain for any K (mcmc_chain_tab): K > 2, and the diploid pile-ups the fast path below does not take.
+//
+// As in the diploid chain, more than 96 % of the proposals are rejected and the fate of "move read i to cluster c" is
+// a function of the state: LDS holds a REJECTION THRESHOLD per (pick, read) -- from an order-free evaluation of get_lk
+// for that move, all reads in parallel (lane = read) -- and the producer wave has parsed the proposal that WOULD start
+// at every stream position into a record (producer_parse_gen).  A window of 64 records is one LDS read plus one gather
+// of thresholds; the consumer then steps from proposal to proposal with one v_readlane each:
+//  * certainly rejected (the uniform behind its Bernoulli draw exceeds the threshold): the step is the reference's
+//    flip + flip-back on the two touched clusters' sums -- (tg - x) + x and (tg + x) - x, rounding residue included --
+//    and nothing else.  Residues move the sums by ulps; thresholds carry a 1e-3 guard band and are rebuilt at every
+//    accept (and at least every 65,536 steps), and a move is never classified as certainly rejected when a sum it
+//    depends on is so close to zero that such drift could flip its sign;
+//  * anything else is an EVENT: one exact step with the reference's arithmetic (ordered left-to-right get_lk, exact exp
+//    only if the guarded f32 test cannot decide), exactly as mcmc_chain does it.
+// Bit-identical to the one-step-at-a-time chain by construction; checked against the oracle.
+struct GenWindow {
+    uint32_t base;
+    uint32_t nxt;   // per lane: window offset of the following proposal (Bernoulli draw taken), 255 = not in this window
+    uint32_t ip;    // per lane: read index | pick << 10
+    float u;        // per lane: the draw its Bernoulli test compares, / 2^64, truncated to 13 bits
+};
+__device__ __forceinline__ void gwindow_load(GenWindow &wd, Rng &rng, uint32_t base, uint32_t lane) {
+    rng.pos = base;
+    rng_release(rng, lane);
+    rng_wait_rec(rng, base + 64);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wd.base = base;
+    const uint32_t r = lds_ld32(&rng.rec[(base + lane) & (RN - 1)]);
+    const uint32_t len = (r >> 13) & 63u;
+    wd.ip = r & 0x1fffu;
+    wd.nxt = (len != 0 && lane + len < 64) ? lane + len : 255u;
+    wd.u = (float)(r >> 19) * 0x1p-13f;
+}
+// per window position: nxt (6 bits) | certainly rejected << 6 | in-window << 7 | read index << 8 | pick << 18 |
+// the read's current cluster << 21 | the cluster the proposal moves it to << 24
+typedef __attribute__((address_space(3))) const volatile uint8_t lds_cvu8;
+__device__ __forceinline__ uint32_t ghop_words(const GenWindow &wd, const float *thr, uint32_t npad, const uint8_t *labels) {
+    const uint32_t idx = wd.ip & 1023u, pick = wd.ip >> 10;
+    const float t = __int_as_float((int)lds_ld32(reinterpret_cast<const uint32_t *>(thr) + pick * npad + idx));
+    const uint32_t old = *(lds_cvu8 *)(labels + idx);
+    const uint32_t nw = pick < old ? pick : pick + 1u;
+    const bool in = wd.nxt != 255u;
+    return (wd.nxt & 63u) | ((in && wd.u > t) ? 64u : 0u) | (in ? 128u : 0u) | (idx << 8) | (pick << 18) | (old << 21) | (nw << 24);
+}
+__device__ __forceinline__ double lds_ld_f64(const double *p) { return jtk_bits_f64(lds_ld64(reinterpret_cast<const uint64_t *>(p))); }
+// A pointer into LDS that reached this function through memory (a struct passed by reference, an argument register of an
+// out-of-line call) looks divergent to the compiler: every use becomes a flat access with a null check and every branch
+// on a value loaded through it an exec-mask region.  Rebuilt from its wave-uniform 32-bit LDS offset it is a scalar.
+template <typename T>
+__device__ __forceinline__ T *lds_uni(T *p) {
+    typedef __attribute__((address_space(3))) char lds_char;
+    const uint32_t off = uni((uint32_t)(uintptr_t)(lds_char *)const_cast<typename std::remove_const<T>::type *>(p));
+    return (T *)(lds_char *)(uintptr_t)off;
+}
+
+template <int K>
+__device__ __attribute__((noinline)) double mcmc_chain_tab(const Lds &m_in, uint32_t n_in, uint32_t D_in, double cov_in,
+                                                           Rng *rng_io, uint32_t lane) {
+    // everything that steers control flow or addresses LDS is made provably wave-uniform first (see lds_uni)
+    const uint32_t n = uni(n_in), D = uni(D_in);
+    const double cov = unif64(cov_in);
+    Lds m;
+    m.data = lds_uni(m_in.data);
+    m.size_to_lk = lds_uni(m_in.size_to_lk);
+    m.lfact = lds_uni(m_in.lfact);
+    m.assign = lds_uni(m_in.assign);
+    m.argmax = lds_uni(m_in.argmax);
+    m.thr = lds_uni(m_in.thr);
+    m.st = lds_uni(m_in.st);
+    m.col = lds_uni(m_in.col);
+    m.sz = lds_uni(m_in.sz);
+    m.npad = uni(m_in.npad);
+    Rng rng;
+    rng.pos = uni(rng_io->pos);
+    rng.wr_seen = uni(rng_io->wr_seen);
+    rng.wp_seen = uni(rng_io->wp_seen);
+    rng.win_base = uni(rng_io->win_base);
+    rng.pmode = uni(rng_io->pmode);
+    rng.win = rng_io->win;
+#ifdef JTK_MCMC_STATS
+    rng.waits = rng_io->waits;
+#endif
+    rng.ctl = lds_uni(rng_io->ctl);
+    rng.ring = lds_uni(rng_io->ring);
+    rng.rec = lds_uni(rng_io->rec);
+    const bool small = n <= 63u, big = n > 255u;
+    // size_to_lk[x] = max_{c=1..K} poisson_lk(x, cov*c): registers up to 255 reads, LDS beyond (as mcmc_chain)
+    LaneTab size_to_lk;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t x = lane + 64 * r;
+        double mx = -__builtin_inf();
+        if (x <= n)
+            for (int c = 1; c <= K; c++) {
+                const double lam = cov * (double)c;
+                mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
+            }
+        size_to_lk.v[r] = mx;
+    }
+    if (big) {
+        for (uint32_t x = lane; x <= n; x += 64) {
+            double mx = -__builtin_inf();
+            for (int c = 1; c <= K; c++) {
+                const double lam = cov * (double)c;
+                mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
+            }
+            m.size_to_lk[x] = mx;
+        }
+        wsync();
+    }
+    auto size_lk = [&](uint32_t x) -> double {
+        return big ? unif64(m.size_to_lk[x]) : (small ? tab_get<true>(size_to_lk, x) : tab_get<false>(size_to_lk, x));
+    };
+    // ---- initial LKCounts in the reference's order (reads outer); lane = column
+    double tg[K];
+    int np[K], w[K], cl[K];
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        tg[c] = 0.0;
+        np[c] = 0;
+        w[c] = 0;
+        cl[c] = 0;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t c = uni(m.assign[i]);
+        Elem el = {0.0, 0, 0};
+        if (lane < D) el = elem_of(m.data[i * D + lane]);
+#pragma unroll
+        for (int cc = 0; cc < K; cc++)
+            if ((uint32_t)cc == c) {
+                tg[cc] += el.x;
+                np[cc] += el.dp;
+                w[cc] += el.pw;
+                cl[cc]++;
+            }
+    }
+    int totp = 0;
+    const unsigned long long colm = D >= 64 ? ~0ull : ((1ull << D) - 1ull);
+#pragma unroll
+    for (int c = 0; c < K; c++) totp += np[c];
+    // labels live in LDS (m.assign, with the best-seen copy in m.argmax): the walk reads a proposal's cluster from its
+    // hop word, so only events and the threshold build look labels up
+    for (uint32_t i = lane; i < n; i += 64) m.argmax[i] = m.assign[i];
+    wsync();
+    auto label_of = [&](uint32_t i) -> uint32_t { return uni((uint32_t) * (lds_cvu8 *)(m.assign + i)); };
+    // get_lk (:785-795) on a (tentative) state: size terms first, then clusters outer / columns inner, left to right;
+    // exactly-zero terms leave the f64 sum unchanged and are skipped
+    auto get_lk = [&](const double *T, const int *P, const int *Wt, const int *cls) -> double {
+        double S = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; c++) S += size_lk((uint32_t)cls[c]);
+        int in_use = 0;
+        unsigned long long anym = 0, pm[K];
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            pm[c] = __ballot(0.0 < T[c]) & colm;
+            in_use += (0.0 < T[c]) ? P[c] : 0;
+            anym |= pm[c] & __ballot(Wt[c] > 0);  // some cluster is_informative (:818-822) on this column
+        }
+        const unsigned long long usedm = __ballot(3 * in_use > 2 * totp) & anym;  // get_used_columns (:847-869)
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            unsigned long long mm = usedm & pm[c];
+            while (mm) {
+                const uint32_t d = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1;
+                S += readlane_f64(T[c], d);
+            }
+        }
+        return S;
+    };
+    double sz0[K], szm[K], szp[K];
+    auto size_terms = [&](int c) {
+        const uint32_t x = (uint32_t)cl[c];
+        sz0[c] = size_lk(x);
+        szm[c] = x > 0 ? size_lk(x - 1) : 0.0;
+        szp[c] = x < n ? size_lk(x + 1) : 0.0;
+    };
+#pragma unroll
+    for (int c = 0; c < K; c++) size_terms(c);
+    double lk = get_lk(tg, np, w, cl);
+    double max = lk;
+    // ---- thresholds.  publish(): the state as the per-proposal estimate gathers it (per (column, cluster) sums and
+    //      counters, per-column totals, per-cluster size terms).  pair_thr(): the order-free estimate of proposed - lk
+    //      for "move read i (now in cluster a) to its pick-th other cluster" and the rejection threshold that follows
+    //      from it.  Thresholds are evaluated for the 64 proposals of a window at a time, one per lane (hop_words),
+    //      from the state last published: at every accept, and at least every 65,536 steps.
+    const uint32_t npad = m.npad;
+    (void)npad;
+    double S0 = 0.0;
+    auto publish = [&]() {
+        if (lane < D) {
+            double G = 0.0;
+            int IU = 0, AN = 0, FR = 0;
+#pragma unroll
+            for (int c = 0; c < K; c++) {
+                const bool pos = 0.0 < tg[c];
+                const bool frag = fabs(tg[c]) < 1e-6 && (np[c] != 0 || w[c] > 0);
+                G += pos ? tg[c] : 0.0;
+                IU += pos ? np[c] : 0;
+                AN += (pos && w[c] > 0) ? 1 : 0;
+                FR += frag ? 1 : 0;
+                StEnt e;
+                e.T = tg[c];
+                e.P = np[c] | (frag ? 65536 : 0);
+                e.W = w[c];
+                lds_store_st(&m.st[lane * K + c], e);
+            }
+            ColEnt ce;
+            ce.G = G;
+            ce.IU = IU;
+            ce.AN = AN;
+            ce.TP = totp;
+            ce.FR = FR;
+            ce.pad[0] = ce.pad[1] = 0;
+            lds_store_col(&m.col[lane], ce);
+        }
+        S0 = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            S0 += sz0[c];
+            if (lane == 0) {
+                SzEnt e;
+                e.sz0 = sz0[c];
+                e.szm = szm[c];
+                e.szp = szp[c];
+                e.pad = 0.0;
+                lds_store_sz(&m.sz[c], e);
+            }
+        }
+        wsync();
+    };
+    typedef __attribute__((address_space(3))) const double lds_cd;
+    lds_cd *const data_l = (lds_cd *)m.data;  // 32-bit LDS addressing for the hot gathers
+    auto pair_thr = [&](uint32_t i, uint32_t a, uint32_t pick) -> float {  // per lane
+        const uint32_t cb = pick < a ? pick : pick + 1u;
+        double sum = 0.0;
+        bool cant = false;
+        for (uint32_t d = 0; d < D; d++) {
+            const Elem el = elem_of(data_l[i * D + d]);
+            const ColEnt ce = lds_load_col(&m.col[d]);
+            const StEnt ea = lds_load_st(&m.st[d * K + a]);
+            const StEnt eb = lds_load_st(&m.st[d * K + cb]);
+            const bool fa0 = (ea.P >> 16) & 1, fb0 = (eb.P >> 16) & 1;
+            const int Pa = ea.P & 0xffff, Pb = eb.P & 0xffff;
+            const bool pa = 0.0 < ea.T, pb = 0.0 < eb.T;
+            const double Ta = ea.T - el.x, Tb = eb.T + el.x;
+            const int Pa2 = Pa - el.dp, Wa2 = ea.W - el.pw, Pb2 = Pb + el.dp, Wb2 = eb.W + el.pw;
+            const bool pa2 = 0.0 < Ta, pb2 = 0.0 < Tb;
+            const double G2 = (ce.G - (pa ? ea.T : 0.0) - (pb ? eb.T : 0.0)) + ((pa2 ? Ta : 0.0) + (pb2 ? Tb : 0.0));
+            const int IU2 = ce.IU - (pa ? Pa : 0) - (pb ? Pb : 0) + (pa2 ? Pa2 : 0) + (pb2 ? Pb2 : 0);
+            const int AN2 = ce.AN - ((pa && ea.W > 0) ? 1 : 0) - ((pb && eb.W > 0) ? 1 : 0) + ((pa2 && Wa2 > 0) ? 1 : 0) +
+                            ((pb2 && Wb2 > 0) ? 1 : 0);
+            const bool used = AN2 > 0 && 3 * IU2 > 2 * ce.TP;
+            sum += used ? G2 : 0.0;
+            // a sum near zero with counts behind it: rounding drift could flip its sign, and with it `used`
+            const bool fa2 = fabs(Ta) < 1e-6 && (Pa2 != 0 || Wa2 > 0);
+            const bool fb2 = fabs(Tb) < 1e-6 && (Pb2 != 0 || Wb2 > 0);
+            cant = cant || fa2 || fb2 || (ce.FR - (fa0 ? 1 : 0) - (fb0 ? 1 : 0)) > 0;
+        }
+        const SzEnt sa = lds_load_sz(&m.sz[a]), sb = lds_load_sz(&m.sz[cb]);
+        const double dA = ((S0 - sa.sz0 - sb.sz0 + sa.szm + sb.szp) + sum) - lk;
+        return cant ? 2.0f : reject_threshold(dA, false);
+    };
+    // per window position: nxt (6 bits) | certainly rejected << 6 | in-window << 7 | read index << 8 | pick << 18 |
+    // the read's current cluster << 21 | the cluster the proposal moves it to << 24
+    const uint32_t n1 = n - 1;
+    auto hop_words = [&](const GenWindow &wd) -> uint32_t {
+        uint32_t idx = wd.ip & 1023u;
+        const uint32_t pick = wd.ip >> 10;
+        const bool in = wd.nxt != 255u;
+        idx = idx < n1 ? idx : n1;  // a position that is not a parsed proposal may hold anything
+        const uint32_t old = *(lds_cvu8 *)(m.assign + idx);
+        const uint32_t nw = pick < old ? pick : pick + 1u;
+        const float t = pair_thr(idx, old, pick < (uint32_t)(K - 1) ? pick : 0u);
+        return (wd.nxt & 63u) | ((in && wd.u > t) ? 64u : 0u) | (in ? 128u : 0u) | (idx << 8) | (pick << 18) | (old << 21) | (nw << 24);
+    };
+#ifdef JTK_MCMC_STATS
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // fast, events, accepts, reloads, scalars, cyc rebuild, cyc event, cyc total
+    const unsigned long long ts_t0 = __builtin_readcyclecounter();
+#define TS_ADD(k, v) ts[k] += (v)
+#else
+#define TS_ADD(k, v)
+#endif
+    publish();
+    const uint32_t total = 2000u * n;
+    uint32_t t = 0, p = 0, since_rebuild = 0;
+    GenWindow wd;
+    gwindow_load(wd, rng, rng.pos, lane);
+    uint32_t hopw = hop_words(wd);
+    auto row_of = [&](uint32_t hvv) -> double {  // the column values of the read a hop word names (lanes >= D: 0.0)
+        uint32_t i = (hvv >> 8) & 1023u;
+        i = i < n1 ? i : n1;  // a word that is not a proposal may hold anything
+        return lane < D ? data_l[i * D + lane] : 0.0;
+    };
+    while (t < total) {
+        uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
+        if ((hv & 192u) == 192u && since_rebuild < 65536u) {
+            // ---- certainly rejected proposals, one after the other: flip + flip back (:739,:746) on the two touched
+            //      clusters and nothing else.  The next proposal's hop word and row are fetched before this one's
+            //      arithmetic (an LDS round trip costs a lone wave ~100 cycles).
+            double x = row_of(hv);
+            uint32_t budget = total - t;
+            if (budget > 65536u - since_rebuild) budget = 65536u - since_rebuild;
+            uint32_t done = 0;
+            do {
+                const uint32_t pn = hv & 63u;
+                const uint32_t hn = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)pn));
+                const double xn = row_of(hn);
+                const uint32_t old = (hv >> 21) & 7u, nw = (hv >> 24) & 7u;
+#pragma unroll
+                for (int c = 0; c < K; c++) {
+                    if ((uint32_t)c == old) {
+                        asm volatile("" : "+v"(tg[c]));  // keep this a branch: only two of the K sums move
+                        tg[c] = (tg[c] - x) + x;
+                    }
+                    if ((uint32_t)c == nw) {
+                        asm volatile("" : "+v"(tg[c]));
+                        tg[c] = (tg[c] + x) - x;
+                    }
+                }
+                p = pn;
+                hv = hn;
+                x = xn;
+                done++;
+            } while ((hv & 192u) == 192u && done < budget);
+            t += done;
+            since_rebuild += done;
+            TS_ADD(0, done);
+            continue;
+        }
+        uint32_t idx, pick, pos_v;
+        bool reload = false;
+        if (hv & 128u) {
+            idx = (hv >> 8) & 1023u;
+            pick = (hv >> 18) & 7u;
+            pos_v = wd.base + (hv & 63u) - 1;
+        } else if (p != 0) {  // the proposal does not end inside this window: move the window there
+            gwindow_load(wd, rng, wd.base + p, lane);
+            p = 0;
+            hopw = hop_words(wd);
+            TS_ADD(3, 1);
+            continue;
+        } else {  // not even at the window start: the producer could not parse this one -- scalar draws
+            TS_ADD(4, 1);
+            rng.pos = wd.base;
+            idx = (uint32_t)gen_range_usize(rng, n);
+            pick = choose_pos(rng, K);
+            pos_v = rng.pos;
+            reload = true;
+        }
+        // ---- the event: one exact step (as mcmc_chain)
+#ifdef JTK_MCMC_STATS
+        const unsigned long long ev_t0 = __builtin_readcyclecounter();
+#endif
+        TS_ADD(1, 1);
+        const uint32_t old = label_of(idx);
+        const uint32_t nw = pick < old ? pick : pick + 1;
+        Elem el = {0.0, 0, 0};
+        if (lane < D) el = elem_of(lds_ld_f64(&m.data[idx * D + lane]));
+        double T[K];
+        int P[K], W[K], ncl[K];
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            const bool o = (uint32_t)c == old, a = (uint32_t)c == nw;
+            T[c] = o ? tg[c] - el.x : (a ? tg[c] + el.x : tg[c]);
+            P[c] = o ? np[c] - el.dp : (a ? np[c] + el.dp : np[c]);
+            W[c] = o ? w[c] - el.pw : (a ? w[c] + el.pw : w[c]);
+            ncl[c] = o ? cl[c] - 1 : (a ? cl[c] + 1 : cl[c]);
+        }
+        const double proposed = get_lk(T, P, W, ncl);
+        const double diff = unif64(proposed - lk);
+        // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0 exactly
+        // when diff >= -2^-54
+        const bool no_draw = ubool(diff >= -0x1p-54);
+        bool accept = true;
+        if (!no_draw) {
+            const float u = reload ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd.u), (int)p));
+            const float pe = __expf((float)diff);
+            const bool in_range = u >= 0.0f && diff < -1e-3 && diff > -44.4;
+            if (ubool(diff <= -44.4 || (in_range && u > pe * 1.001f + 1.3e-6f))) {
+                accept = false;
+            } else if (!ubool(in_range && u + 0x1p-13f < pe * 0.999f - 3e-7f)) {
+                rng_wait(rng, pos_v + 1);
+                accept = ubool(bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff));
+            }
+        }
+        if (accept) {
+#pragma unroll
+            for (int c = 0; c < K; c++) {
+                tg[c] = T[c];
+                np[c] = P[c];
+                w[c] = W[c];
+                cl[c] = ncl[c];
+                if ((uint32_t)c == old || (uint32_t)c == nw) size_terms(c);
+            }
+            if (lane == 0) m.assign[idx] = (uint8_t)nw;
+            wsync();
+            lk = proposed;
+            if (ubool(max < lk)) {
+                max = proposed;
+                for (uint32_t i = lane; i < n; i += 64) m.argmax[i] = m.assign[i];
+                wsync();
+            }
+        } else {
+            // flip back (:746): the reference re-adds / re-subtracts, which leaves rounding residue
+#pragma unroll
+            for (int c = 0; c < K; c++) {
+                if ((uint32_t)c == old) tg[c] = T[c] + el.x;
+                if ((uint32_t)c == nw) tg[c] = T[c] - el.x;
+            }
+        }
+        t++;
+        since_rebuild++;
+        const bool rebuilt = accept || since_rebuild >= 65536u;
+        TS_ADD(2, accept ? 1 : 0);
+        if (rebuilt) {
+#ifdef JTK_MCMC_STATS
+            const unsigned long long rb_t0 = __builtin_readcyclecounter();
+#endif
+            publish();
+            since_rebuild = 0;
+            TS_ADD(5, __builtin_readcyclecounter() - rb_t0);
+        }
+        TS_ADD(6, __builtin_readcyclecounter() - ev_t0);
+        const uint32_t pos_next = no_draw ? pos_v : pos_v + 1;
+        if (reload || pos_next - wd.base >= 64) {
+            gwindow_load(wd, rng, pos_next, lane);
+            p = 0;
+            hopw = hop_words(wd);
+        } else {
+            p = pos_next - wd.base;
+            if (rebuilt) hopw = hop_words(wd);
+        }
+    }
+#ifdef JTK_MCMC_STATS
+    if (lane == 0)
+        printf("TABSTAT K %d n %u D %u steps %u fast %llu events %llu accepts %llu reloads %llu scalars %llu cyc_rebuild %llu cyc_event %llu cyc_total %llu\n",
+               K, n, D, total, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], __builtin_readcyclecounter() - ts_t0);
+#endif
+#undef TS_ADD
+    rng.pos = wd.base + p;
+    rng_release(rng, lane);
+    wsync();
+    for (uint32_t i = lane; i < n; i += 64) m.assign[i] = m.argmax[i];
+    wsync();
+    *rng_io = rng;
+    return max;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // The diploid chain (K == 2, n <= 127, D <= 8) as a table-driven walk.
 //
@@ -1038,13 +1680,6 @@ __device__ __forceinline__ uint32_t hop_words(const Window &wd, const float *thr
         thr = wd.idx >= 64u ? hi : thr;
     }
     return (wd.nxt & 63u) | ((wd.nxt != 255u && wd.u > thr) ? 64u : 0u);
-}
-// The rejection threshold from the order-free estimate dA of proposed - lk.  u is the Bernoulli draw truncated to
-// 19 bits (so the true uniform is < u + 2^-19); exp in f32 is good to ~1e-5 relative: 1.001 and 1.3e-6 cover both.
-__device__ __forceinline__ float reject_threshold(double dA, bool pert) {
-    float thr = 2.0f;  // cannot tell: the proposal becomes an event
-    if (!pert && dA < -1e-3) thr = dA <= -44.5 ? -1.0f : __expf((float)dA) * 1.001f + 1.3e-6f;
-    return thr;
 }
 // Walks from window position p over certainly rejected proposals; returns the number of steps taken (<= limit).
 // Straight-line hops with forward exits: a taken branch costs a lone wave far more than the hop itself.
@@ -1538,6 +2173,7 @@ __device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uin
 template <int K>
 __device__ __forceinline__ double mcmc_chain_dispatch(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
     if (K == 2 && n <= 127 && D >= 1 && D <= 8) {
+        rng_set_parse_mode(rng, PM_K2, lane);
         const K2Mem km = {m.data, m.lfact, m.assign, m.k2_stats};
         if (n <= 63) {
             if (D == 1) return mcmc_chain_k2<1, true, 1>(km, n, D, cov, &rng, lane);
@@ -1548,8 +2184,12 @@ __device__ __forceinline__ double mcmc_chain_dispatch(const Lds &m, uint32_t n, 
         if (D <= 4) return mcmc_chain_k2<4, true, 2>(km, n, D, cov, &rng, lane);
         return mcmc_chain_k2<8, false, 2>(km, n, D, cov, &rng, lane);
     }
-    if (n <= 63) return mcmc_chain<K, true>(m, n, D, cov, rng, lane);
-    return mcmc_chain<K, false>(m, n, D, cov, rng, lane);
+    if (m.flags & 1u) {  // JTK_MCMC_LEGACY: the one-proposal-per-iteration chain, kept for differential testing
+        if (n <= 63) return mcmc_chain<K, true>(m, n, D, cov, rng, lane);
+        return mcmc_chain<K, false>(m, n, D, cov, rng, lane);
+    }
+    rng_set_parse_mode(rng, (uint32_t)K, lane);
+    return mcmc_chain_tab<K>(m, n, D, cov, &rng, lane);
 }
 
 // get_read_lk_gains (:381-408): used columns -> used[], per-read gain -> fbuf[]
@@ -1678,8 +2318,8 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
                                                   const uint32_t *vtype_all, const uint64_t *vt_off_all,
                                                   uint32_t vt_stride_mode, uint32_t *label_all, double *post_all,
                                                   uint32_t post_stride, double *lg_all, const uint64_t *lg_off,
-                                                  uint32_t lds_n, uint32_t lds_d, uint32_t jump_in_lds,
-                                                  const uint64_t *rng_resume) {
+                                                  uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, uint32_t jump_in_lds,
+                                                  uint32_t flags, const uint64_t *rng_resume) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t ci = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     ChunkState *st = &state[ci];
@@ -1704,7 +2344,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         }
         return;
     }
-    if (copy_num > JTK_MAX_COPY || n > JTK_MAX_PILEUP || n > lds_n || D > lds_d) {
+    if (copy_num > JTK_MAX_COPY || copy_num > lds_k || n > JTK_MAX_PILEUP || n > lds_n || D > lds_d) {
         if (threadIdx.x == 0) st->status = JTK_ERR_UNSUPPORTED;
         return;
     }
@@ -1737,6 +2377,12 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         m.used = (uint8_t *)take(lds_d);
         m.prev_used = (uint8_t *)take(lds_d);
         m.tmp_used = (uint8_t *)take(lds_d);
+        m.npad = (lds_n + 63u) & ~63u;
+        m.thr = (float *)take((size_t)(lds_k - 1) * m.npad * 4);
+        m.st = (StEnt *)take((size_t)lds_d * lds_k * sizeof(StEnt));
+        m.col = (ColEnt *)take((size_t)lds_d * sizeof(ColEnt));
+        m.sz = (SzEnt *)take((size_t)lds_k * sizeof(SzEnt));
+        m.flags = flags;
     }
     if (jump_in_lds)
         for (uint32_t e = threadIdx.x; e < JUMP_TAB_BYTES / 16; e += blockDim.x) m.jump[e] = g_jump_tab[e];
@@ -1745,7 +2391,10 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         lds_st32(&m.ctl->quit, 0);
         lds_st32(&m.ctl->wr, 0);
         lds_st32(&m.ctl->wp, 0);
-        lds_st32(&m.ctl->parse_n, n <= 127 ? n : 0);  // the diploid chain (and its records) exists for n <= 127
+        lds_st32(&m.ctl->parse_n, n);
+        lds_st32(&m.ctl->parse_from, 0);
+        lds_st32(&m.ctl->pmode, 0);      // no records until a chain asks for them (rng_set_parse_mode)
+        lds_st32(&m.ctl->wp_epoch, 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
@@ -1791,6 +2440,7 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
     rng.pos = 0;
     rng.wr_seen = 0;
     rng.wp_seen = 0;
+    rng.pmode = 0;
     rng.win_base = 0xffffff00u;  // nothing held yet
     rng.win = 0;
 #ifdef JTK_MCMC_STATS
@@ -1907,15 +2557,22 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
 
 // LDS work area of one chunk.  Two workgroups share a CU as long as each stays under 80 KiB: the producer's jump
 // table (16 KiB) is staged in LDS only when that still holds, larger pile-ups read it from global memory.
-static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d) {
+static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t npad = (lds_n + 63u) & ~63u;
     return al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) +
            al(16 * 8) + al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) +
-           2 * al((size_t)JTK_MAX_COPY * lds_d * 8) + 2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d);
+           2 * al((size_t)JTK_MAX_COPY * lds_d * 8) + 2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d) +
+           al((size_t)(lds_k - 1) * npad * 4) + al((size_t)lds_d * lds_k * sizeof(StEnt)) + al((size_t)lds_d * sizeof(ColEnt)) +
+           al((size_t)lds_k * sizeof(SzEnt));
 }
-static bool mcmc_jump_in_lds(uint32_t lds_n, uint32_t lds_d) { return mcmc_lds_core(lds_n, lds_d) + JUMP_TAB_BYTES <= 80 * 1024; }
-size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d) {
-    return mcmc_lds_core(lds_n, lds_d) + (mcmc_jump_in_lds(lds_n, lds_d) ? JUMP_TAB_BYTES : 0);
+static uint32_t clamp_k(uint32_t lds_k) { return lds_k < 2 ? 2 : (lds_k > JTK_MAX_COPY ? JTK_MAX_COPY : lds_k); }
+static bool mcmc_jump_in_lds(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
+    return mcmc_lds_core(lds_n, lds_d, lds_k) + JUMP_TAB_BYTES <= 80 * 1024;
+}
+size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
+    lds_k = clamp_k(lds_k);
+    return mcmc_lds_core(lds_n, lds_d, lds_k) + (mcmc_jump_in_lds(lds_n, lds_d, lds_k) ? JUMP_TAB_BYTES : 0);
 }
 
 // ---- host: the two-bit-digit table of M^(63*SEG), from nothing but the generator's own step function
@@ -2001,12 +2658,14 @@ int mcmc_upload_jump_table(hipStream_t s) {
 int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
                 const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
                 uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
-                const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, const uint64_t *rng_resume) {
+                const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, const uint64_t *rng_resume) {
     if (n_chunks == 0) return 0;
-    const size_t lds = mcmc_lds_bytes(lds_n, lds_d);
+    lds_k = clamp_k(lds_k);
+    const size_t lds = mcmc_lds_bytes(lds_n, lds_d, lds_k);
     if (mcmc_upload_jump_table(s) != 0) return -1;  // the caller fails the call: nothing was launched
+    static const uint32_t flags = getenv("JTK_MCMC_LEGACY") ? 1u : 0u;  // differential testing only
     mcmc_kernel<<<n_chunks, 128, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
-                                          post_stride, lg, lg_off, lds_n, lds_d, mcmc_jump_in_lds(lds_n, lds_d) ? 1u : 0u,
-                                          rng_resume);
+                                          post_stride, lg, lg_off, lds_n, lds_d, lds_k,
+                                          mcmc_jump_in_lds(lds_n, lds_d, lds_k) ? 1u : 0u, flags, rng_resume);
     return 0;
 }

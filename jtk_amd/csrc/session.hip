@@ -36,11 +36,11 @@ void launch_filter(hipStream_t s, uint32_t n_chunks, const ReadMeta *reads, cons
                    ChunkState *state, DevBufs bufs, const jtk_lc_params_t *params, const double *table,
                    uint16_t *homop, const uint64_t *homop_off, double *aux, const uint64_t *aux_off, double *cand,
                    uint32_t *list, uint8_t *sel, double *feat, uint32_t *vtype, uint32_t *pos, uint32_t max_tmpl);
-size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d);
+size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k);
 int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
                 const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
                 uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
-                const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, const uint64_t *rng_resume);
+                const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, const uint64_t *rng_resume);
 
 namespace {
 
@@ -598,7 +598,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                 s->post_stride, s->d_lg.as<double>(), s->d_lg_off.as<uint64_t>(), s->max_n,
                 // a chunk picks at most ROUND * max(copy_num, 2) columns (pseudo_mcmc.rs:421,527,532): size the
                 // LDS work area for the batch, so that two chunks share a CU whenever they can
-                std::min<uint32_t>(JTK_MAX_DIM, 3u * std::max<uint32_t>(s->max_copy, 2u)),
+                std::min<uint32_t>(JTK_MAX_DIM, 3u * std::max<uint32_t>(s->max_copy, 2u)), s->max_copy,
                 s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr);
     tstop(s);
     if (mcmc_rc != 0) {
@@ -1291,9 +1291,10 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
     std::vector<ChunkState> sts(n_chunks);
     std::vector<uint64_t> vt_off(n_chunks), lg_off(n_chunks);
     uint64_t n_reads = 0, n_var = 0, n_vt = 0, lgo = 0;
-    uint32_t max_n = 1, max_d = 1;
+    uint32_t max_n = 1, max_d = 1, max_k = 2;
     for (size_t c = 0; c < n_chunks; c++) {
         const jtk_lc_feature_chunk_t &fc = chunks[c];
+        if (fc.copy_num > max_k && fc.copy_num <= JTK_MAX_COPY) max_k = fc.copy_num;
         if (fc.read_first != n_reads) return fail(JTK_ERR_INVALID_ARG, "chunks must list their reads contiguously in order");
         memset(&cms[c], 0, sizeof(ChunkMeta));
         memset(&sts[c], 0, sizeof(ChunkState));
@@ -1330,7 +1331,7 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
     if ((rc = dev_alloc<uint32_t>(d_label, n_reads))) return rc;
     if ((rc = dev_alloc<double>(d_post, n_reads * post_stride))) return rc;
     if ((rc = dev_alloc<double>(d_lg, lgo))) return rc;
-    if (mcmc_lds_bytes(max_n, max_d) > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "feature matrix too large for LDS");
+    if (mcmc_lds_bytes(max_n, max_d, max_k) > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "feature matrix too large for LDS");
     hipEvent_t ev0, ev1;
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
@@ -1338,7 +1339,7 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
     if (launch_mcmc(s->stream, (uint32_t)n_chunks, d_chunks.as<ChunkMeta>(), d_state.as<ChunkState>(),
                     d_params.as<jtk_lc_params_t>(), d_var.as<double>(), d_vt.as<uint32_t>(), d_vtoff.as<uint64_t>(), 1,
                     d_label.as<uint32_t>(), d_post.as<double>(), post_stride, d_lg.as<double>(), d_lgoff.as<uint64_t>(),
-                    max_n, max_d, nullptr) != 0)
+                    max_n, max_d, max_k, nullptr) != 0)
         return fail(JTK_ERR_INTERNAL, "the chain kernel could not be launched (jump table upload failed)");
     HIP_TRY(hipEventRecord(ev1, s->stream));
     HIP_TRY(hipMemcpyAsync(sts.data(), d_state.p, sts.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, s->stream));

@@ -1,0 +1,73 @@
+"""bench.py's contract on a small dataset: the one-rank line carries every field the driver reads, and the N > 1 path
+(strong scaling, LPT shards, one result all-gather per step) runs as two gloo ranks sharing GPU 0
+(JTK_BENCH_BACKEND=gloo; the real launch uses RCCL with one rank per GPU)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def last_json(stdout):
+    return json.loads([l for l in stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_one_rank_line_has_the_contract_fields(jtk_lib):
+    assert jtk_lib.jtk_lc_device_ok(0) == 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--chunks", "32", "--steps", "2", "--warmup", "1",
+                        "--streams", "2"], capture_output=True, text=True, cwd=ROOT, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = last_json(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "e2e"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["unit"] == "chunks/s" and line["vs_baseline"] is None
+    assert line["config"]["workload"].startswith("cfg3") and line["config"]["chunks_total"] == 32
+    assert abs(line["value"] - 32 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    # achieved = chunks/s x algorithmic bytes per chunk (B(60, 2000, 2) = 126,216 B nominal)
+    assert abs(rf["achieved"] - line["value"] * rf["algorithmic_bytes_per_chunk"] / 1e9) < 1e-9
+    assert abs(rf["algorithmic_bytes_per_chunk"] - 126216) < 0.03 * 126216
+    sp = rf["serial_pass"]
+    assert sp["kernel_ms_sum"] <= sp["wall_ms"]                       # the numbers used for attribution add up
+    assert rf["secondary"]["fp64_tflops"] > 0 and rf["secondary"]["chain_cycles_per_proposal"] > 0
+    assert line["serial_step_agrees"] and line["chunks_ok"] == 32
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["one_thread"]["cores"] == 1
+    assert line["parity_on_cpu_sample"]["labels_equal"] and line["parity_on_cpu_sample"]["max_abs_dlogpost"] < 1e-4
+    assert line["e2e"]["matches_resident"] and line["e2e"]["chunks_per_s"] > 0
+
+
+def test_two_rank_strong_scaling_path(jtk_lib):
+    env = dict(os.environ, JTK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--chunks", "24", "--steps", "2", "--warmup", "1", "--streams", "2", "--no-e2e"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["chunks_total"] == 24
+    assert line["config"]["chunks_this_rank"] == 12
+    assert line["gather_ok"] and line["gathered_reads"] == 24 * 60
+    assert line["roofline"]["peak"] == 16000.0
+    assert line["cpu_baseline"] is None
+
+
+def test_gpus_flag_must_match_the_launch():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True,
+                       cwd=ROOT, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

@@ -70,3 +70,39 @@ def test_lpt_partition_balances_and_covers():
         loads = [costs[p].sum() for p in parts]
         assert max(loads) - min(loads) <= costs.max() + 1e-9
     assert list(sharding.weak_chunk_ids(3, 500))[:2] == [1500, 1501]
+
+
+def _gather_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jtk_amd import sharding
+    # ragged shards: sizes follow from the partition every rank computes for itself, nothing is exchanged beforehand
+    parts = sharding.strong_shards(7, [4, 9, 3, 6, 5, 8, 2], 100, 2, world)
+    stride = 3
+    sizes = [(int(sum([4, 9, 3, 6, 5, 8, 2][c] for c in p)), len(p)) for p in parts]
+    g = sharding.ResultGather(dist, sizes, stride)
+
+    def payload(r, step):
+        n, c = sizes[r]
+        rng = np.random.default_rng(100 * step + r)
+        return (rng.integers(0, 3, n).astype(np.uint32), rng.normal(size=(n, stride)), rng.integers(1, 4, c).astype(np.uint32),
+                rng.normal(size=c))
+    ok = True
+    for step in range(3):                      # the buffers are reused from step to step
+        got = g.gather(*payload(rank, step))
+        for r in range(world):
+            lab, post, k, sc = payload(r, step)
+            ok = ok and np.array_equal(got[r]["label"], lab) and np.array_equal(got[r]["log_post"], post)
+            ok = ok and np.array_equal(got[r]["cluster_num"], k) and np.array_equal(got[r]["score"], sc)
+    np.save(os.path.join(outdir, f"gather{rank}.npy"), np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_result_gather_is_one_collective_of_labels_posteriors_k_and_score(tmp_path):
+    """(label, log_post, cluster_num, score) of every rank to every rank in ONE all_gather_into_tensor on
+    sizes known from the partition"""
+    world = 2
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(np.load(tmp_path / f"gather{r}.npy")[0] == 1 for r in range(world))
