@@ -40,7 +40,7 @@ typedef enum jtk_status {
     JTK_OK = 0,
     JTK_ERR_INVALID_ARG = -1,     /* null pointer, inconsistent offsets, non-ACGT base, bad op code    */
     JTK_ERR_NO_DEVICE = -2,       /* no usable MI355X / HIP runtime failure (message via last_error)   */
-    JTK_ERR_UNSUPPORTED = -3,     /* band radius > 30 (one wavefront per anti-diagonal), pile-up of more than 511 reads */
+    JTK_ERR_UNSUPPORTED = -3,     /* band radius > 127, pile-up of more than 511 reads                  */
     JTK_ERR_ALLOC = -4,           /* hipMalloc / host allocation failed                                */
     JTK_ERR_OPS_MISMATCH = -5,    /* ops do not consume exactly the template and the read              */
     JTK_ERR_CHUNK_FAILED = -6,    /* >=1 chunk hit a condition on which the reference panics; see      */
@@ -138,6 +138,20 @@ int jtk_lc_cluster_polished(const jtk_lc_params_t *params, size_t n_chunks, cons
                             const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
                             uint32_t *label, double *log_post, uint32_t post_stride,
                             jtk_lc_result_t *result, int device);
+
+/* ---- the polishing step on its own -------------------------------------------------------------------
+ * kiley `polish_until_converge_antidiagonal(template, seqs, ops, strands, &HMMPolishConfig::new(radius, take_num,
+ * ignore_edge))` for a batch of independent windows (one jtk_lc_chunk_t each; copy_num is ignored): the call
+ * `consensus::polish_seg` makes on 2 kbp windows of contigs (haplotyper/src/consensus/mod.rs:476-483 with
+ * (radius / 2, max_coverage, 0)) and the one this stage makes per pile-up (local_clustering/mod.rs:105-106 with
+ * (band / 2, N, 3)).  Only the first take_num reads of a window vote in a round (0 = all); every read's ops are
+ * re-threaded.  radius 0 derives the radius from the window length and params->band_frac as mod.rs:96 does.
+ * result[c].polish_rounds / .status are filled; cons_out / ops_out as in jtk_lc_cluster_chunks. */
+int jtk_lc_polish_chunks(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                         const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                         const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t radius,
+                         uint32_t take_num, uint32_t ignore_edge, uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap,
+                         uint8_t *ops_out, uint64_t *ops_out_off, uint64_t ops_cap, jtk_lc_result_t *result, int device);
 
 /* ---- resident-batch form of the same call ----------------------------------------------------------
  * jtk_lc_cluster_chunks == session_create + session_run(0) + session_fetch + session_destroy.

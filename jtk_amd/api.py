@@ -52,6 +52,21 @@ def cluster_polished(params, batch, device=0, raise_on_chunk_failure=True):
     return o
 
 
+def polish_chunks(params, batch, radius=0, take_num=0, ignore_edge=0, device=0, raise_on_chunk_failure=True):
+    """jtk_lc_polish_chunks: polish_until_converge_antidiagonal on every window of `batch` (no clustering)."""
+    L = ffi.lib()
+    o = _outputs(batch)
+    rc = L.jtk_lc_polish_chunks(C.byref(params), batch.n_chunks, batch.chunks.ctypes.data, u8p(batch.tmpl_bases),
+                                u8p(batch.read_bases), u64p(batch.read_off), u8p(batch.ops), u64p(batch.ops_off),
+                                u8p(batch.strand), radius, take_num, ignore_edge, u8p(o["cons"]), u64p(o["cons_off"]),
+                                len(o["cons"]), u8p(o["ops_out"]), u64p(o["ops_out_off"]), len(o["ops_out"]),
+                                o["result"].ctypes.data, device)
+    if rc != 0 and (raise_on_chunk_failure or rc != -6):
+        check(rc)
+    o["rc"] = rc
+    return o
+
+
 def modification_table(params, tmpl, reads, ops, strands, device=0):
     """jtk_lc_modification_table for one pile-up -> (table [n, 14*(L+1)] minus lk, lk [n])."""
     L = ffi.lib()

@@ -7,7 +7,8 @@
 #include "jtk_math.h"
 
 #define JTK_WAVE 64
-#define JTK_MAX_RADIUS 30        // 2r+1 <= 61 lanes: 3 spare lanes make the lane ring unambiguous
+#define JTK_MAX_RADIUS 30        // 2r+1 <= 61 lanes: 3 spare lanes make the lane ring unambiguous (phmm_kernel)
+#define JTK_WIDE_MAX_RADIUS 127  // wider bands (CLR / None reads, long ONT chunks) take phmm_wide_kernel
 #define JTK_SCALE_BLOCK 64       // one power-of-two exponent per 64 anti-diagonals (oracle/phmm.c)
 #define JTK_ACC_N 16             // accumulators per template row (see phmm_kernels.hip)
 #define JTK_LOG_ZERO (-1.0e300)
@@ -51,6 +52,8 @@ struct ChunkMeta {
     uint64_t feat_off;   // into d_feat (doubles): n_reads * JTK_MAX_DIM
     uint64_t cand_off;   // into d_cand (doubles): JTK_NUM_ROW * (tmpl_cap + 1) candidate scores
     double local_coverage;  // ClusteringConfig.local_coverage (mod.rs:108-112)
+    uint32_t take_num;   // HMMPolishConfig take_num: only the first take_num reads vote in a polish round (0 = all)
+    uint32_t pad0;
 };
 
 // Mutable per-chunk state (device resident).
@@ -98,6 +101,13 @@ void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const C
 void launch_finalize(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                      const ChunkState *state, const HmmDev *hmm2, const double *raw, const int *rawG,
                      const double *lk, double *table, uint32_t max_tmpl, int only_active);
+// phmm_wide.hip: the reads of chunks whose band radius exceeds JTK_MAX_RADIUS (phmm_kernel skips them)
+size_t phmm_wide_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
+uint64_t phmm_wide_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius);
+void launch_phmm_wide(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
+                      const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
+                      double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *raw,
+                      int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active);
 // polish_kernels.hip
 void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, const ReadMeta *reads,
                          const ChunkMeta *chunks, ChunkState *state, DevBufs bufs, const uint8_t *ey,

@@ -12,7 +12,7 @@ const char *jtk_lc_strerror(int status) {
         case JTK_OK: return "ok";
         case JTK_ERR_INVALID_ARG: return "invalid argument";
         case JTK_ERR_NO_DEVICE: return "no usable gfx950 device / HIP runtime error";
-        case JTK_ERR_UNSUPPORTED: return "unsupported configuration (band radius > 30, or pile-up too large)";
+        case JTK_ERR_UNSUPPORTED: return "unsupported configuration (band radius > 127, or pile-up too large)";
         case JTK_ERR_ALLOC: return "allocation failed";
         case JTK_ERR_OPS_MISMATCH: return "alignment ops do not consume exactly the template and the read";
         case JTK_ERR_CHUNK_FAILED: return "a chunk failed where the reference would panic";

@@ -203,6 +203,7 @@ __device__ __forceinline__ Elem elem_of(double x) {
     el.pw = 3 * el.dp - 7 * (x < -JTK_POS_THR ? 1 : 0);
     return el;
 }
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 struct Lds {
     RCtl *ctl;
     uint64_t *ring;      // RN raw draws
@@ -225,29 +226,20 @@ struct Lds {
     uint8_t *tmp_asn;    // n
     uint8_t *tmp_used;   // D
     // tables of the table-driven chain (mcmc_chain_tab)
-    float *thr;                 // (lds_k - 1) x npad rejection thresholds, by (pick, read)
-    struct StEnt *st;           // D x K: the LKCount of (column, cluster) as the threshold build gathers it
-    struct ColEnt *col;         // D per-column totals
-    struct SzEnt *sz;           // K per-cluster size terms
-    uint32_t npad;              // row stride of thr
+    double *stab;               // lds_k x npad: s[c][i] = sum over the columns cluster c is paid for of x[i][d]
+    uint32_t *nz;               // npad: bit d set iff x[i][d] != 0.0
+    struct SzEnt *sz;           // K per-cluster terms: size deltas and the columns where a move involving c is not certified
+    u32x4_t *st;                // D x K: (total_gain, num_pos, 3 num_pos - 7 num_neg) of (column, cluster), 16 bytes each
+    u32x4_t *col;               // D: (pos_in_use, informative clusters, total pos, -) of the column
+    uint32_t npad;              // row stride of stab
     uint32_t flags;             // bit 0: take the one-proposal-per-iteration chain (mcmc_chain) instead of mcmc_chain_tab
 };
-struct StEnt {   // 16 bytes: one ds_read_b128
-    double T;    // total_gain
-    int P;       // num_pos | fragile << 16
-    int W;       // 3 num_pos - 7 num_neg
-};
-struct ColEnt {  // 32 bytes
-    double G;    // sum_c max(T, 0)
-    int IU;      // sum_c [T > 0] num_pos
-    int AN;      // number of clusters that are informative
-    int TP;      // reads with a positive value in the column
-    int FR;      // clusters whose `T > 0` could flip by rounding drift
-    int pad[2];
-};
-struct SzEnt {
-    double sz0, szm, szp;  // size_to_lk of the cluster's size, of one read less, of one read more
-    double pad;
+struct SzEnt {     // 32 bytes, read as two 16-byte vectors
+    double rem;    // size_to_lk[size - 1] - size_to_lk[size]: what the size terms gain when a read leaves the cluster
+    double add;    // size_to_lk[size + 1] - size_to_lk[size]
+    uint32_t nr;   // columns where this cluster's `total_gain > 0` could flip under a single move
+    uint32_t um;   // columns this cluster is paid for (used and total_gain > 0): what s[c][.] sums over
+    uint32_t pad[2];
 };
 
 // slice.choose_weighted over weights w[0..n) in LDS; cum is scratch. Returns -1 on WeightedError.
@@ -1113,87 +1105,56 @@ typedef __attribute__((address_space(3))) const u32x4 lds_c_u32x4;
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) const double lds_c_f64;
 typedef __attribute__((address_space(3))) float lds_f32;
-__device__ __forceinline__ u32x4 pack_f64_2i(double a, int b, int c) {
-    const uint64_t u = jtk_f64_bits(a);
-    u32x4 v;
-    v.x = (uint32_t)u;
-    v.y = (uint32_t)(u >> 32);
-    v.z = (uint32_t)b;
-    v.w = (uint32_t)c;
-    return v;
-}
 __device__ __forceinline__ double lo_f64(u32x4 v) { return jtk_bits_f64(((uint64_t)v.y << 32) | v.x); }
 __device__ __forceinline__ double hi_f64(u32x4 v) { return jtk_bits_f64(((uint64_t)v.w << 32) | v.z); }
-__device__ __forceinline__ void lds_store_st(StEnt *p, const StEnt &e) { *(lds_u32x4 *)p = pack_f64_2i(e.T, e.P, e.W); }
-__device__ __forceinline__ StEnt lds_load_st(const StEnt *p) {
-    const u32x4 v = *(lds_c_u32x4 *)p;
-    StEnt e;
-    e.T = lo_f64(v);
-    e.P = (int)v.z;
-    e.W = (int)v.w;
-    return e;
-}
-__device__ __forceinline__ void lds_store_col(ColEnt *p, const ColEnt &e) {
-    lds_u32x4 *q = (lds_u32x4 *)p;
-    q[0] = pack_f64_2i(e.G, e.IU, e.AN);
-    u32x4 v;
-    v.x = (uint32_t)e.TP;
-    v.y = (uint32_t)e.FR;
-    v.z = v.w = 0;
-    q[1] = v;
-}
-__device__ __forceinline__ ColEnt lds_load_col(const ColEnt *p) {
-    lds_c_u32x4 *q = (lds_c_u32x4 *)p;
-    const u32x4 a = q[0], b = q[1];
-    ColEnt e;
-    e.G = lo_f64(a);
-    e.IU = (int)a.z;
-    e.AN = (int)a.w;
-    e.TP = (int)b.x;
-    e.FR = (int)b.y;
-    e.pad[0] = e.pad[1] = 0;
-    return e;
-}
 __device__ __forceinline__ void lds_store_sz(SzEnt *p, const SzEnt &e) {
     lds_u32x4 *q = (lds_u32x4 *)p;
-    const uint64_t a = jtk_f64_bits(e.sz0), b = jtk_f64_bits(e.szm), c = jtk_f64_bits(e.szp);
+    const uint64_t a = jtk_f64_bits(e.rem), b = jtk_f64_bits(e.add);
     u32x4 v, w;
     v.x = (uint32_t)a;
     v.y = (uint32_t)(a >> 32);
     v.z = (uint32_t)b;
     v.w = (uint32_t)(b >> 32);
-    w.x = (uint32_t)c;
-    w.y = (uint32_t)(c >> 32);
+    w.x = e.nr;
+    w.y = e.um;
     w.z = w.w = 0;
     q[0] = v;
     q[1] = w;
 }
 __device__ __forceinline__ SzEnt lds_load_sz(const SzEnt *p) {
     lds_c_u32x4 *q = (lds_c_u32x4 *)p;
-    const u32x4 a = q[0], b = q[1];
+    const u32x4 a = q[0];
     SzEnt e;
-    e.sz0 = lo_f64(a);
-    e.szm = hi_f64(a);
-    e.szp = lo_f64(b);
-    e.pad = 0.0;
+    e.rem = lo_f64(a);
+    e.add = hi_f64(a);
+    e.nr = ((__attribute__((address_space(3))) const uint32_t *)p)[4];  // byte 16
+    e.um = ((__attribute__((address_space(3))) const uint32_t *)p)[5];
+    e.pad[0] = e.pad[1] = 0;
     return e;
 }
 
 // ------------------------------------------------------------------------------------------------------
 // The table-driven chain for any K (mcmc_chain_tab): K > 2, and the diploid pile-ups the fast path below does not take.
 //
-// As in the diploid chain, more than 96 % of the proposals are rejected and the fate of "move read i to cluster c" is
-// a function of the state: LDS holds a REJECTION THRESHOLD per (pick, read) -- from an order-free evaluation of get_lk
-// for that move, all reads in parallel (lane = read) -- and the producer wave has parsed the proposal that WOULD start
-// at every stream position into a record (producer_parse_gen).  A window of 64 records is one LDS read plus one gather
-// of thresholds; the consumer then steps from proposal to proposal with one v_readlane each:
+// As in the diploid chain, more than 96 % of the proposals are rejected, and the fate of "move read i from cluster a to
+// cluster b" is a function of the state.  The producer wave has parsed the proposal that WOULD start at every stream
+// position into a record (producer_parse_gen); for a window of 64 records the consumer evaluates, one proposal per lane,
+// a REJECTION THRESHOLD and then steps from proposal to proposal with one v_readlane each:
 //  * certainly rejected (the uniform behind its Bernoulli draw exceeds the threshold): the step is the reference's
 //    flip + flip-back on the two touched clusters' sums -- (tg - x) + x and (tg + x) - x, rounding residue included --
-//    and nothing else.  Residues move the sums by ulps; thresholds carry a 1e-3 guard band and are rebuilt at every
-//    accept (and at least every 65,536 steps), and a move is never classified as certainly rejected when a sum it
-//    depends on is so close to zero that such drift could flip its sign;
+//    and nothing else;
 //  * anything else is an EVENT: one exact step with the reference's arithmetic (ordered left-to-right get_lk, exact exp
 //    only if the guarded f32 test cannot decide), exactly as mcmc_chain does it.
+// The threshold comes from an estimate of proposed - lk that is SEPARABLE: as long as the move flips no `0 < total_gain`
+// and no column's used / unused status, get_lk changes by  s[b][i] - s[a][i]  (s[c][i] = sum of x[i][d] over the columns d
+// that are used and where cluster c has a positive sum: LDS, rebuilt only when that column set changes) plus two size
+// terms.  Whether a move can flip anything is certified per column with margins that hold for EVERY read: |total_gain|
+// above the column's largest |x|, 3 pos_in_use - 2 total_pos away from 0 by more than one read, an informative cluster that
+// stays informative under any +-7 change of its counter.  Columns that fail are collected in per-cluster / global bit
+// masks; a proposal whose read has a non-zero value in such a column is never classified (it becomes an event), and
+// neither is any proposal while a sum with counts behind it is within 1e-6 of zero (rounding residues, which move sums by
+// ulps, could flip its sign).  Thresholds carry a 1e-3 guard band; the masks and s are republished at every accept and at
+// least every 65,536 steps.
 // Bit-identical to the one-step-at-a-time chain by construction; checked against the oracle.
 struct GenWindow {
     uint32_t base;
@@ -1213,17 +1174,7 @@ __device__ __forceinline__ void gwindow_load(GenWindow &wd, Rng &rng, uint32_t b
     wd.nxt = (len != 0 && lane + len < 64) ? lane + len : 255u;
     wd.u = (float)(r >> 19) * 0x1p-13f;
 }
-// per window position: nxt (6 bits) | certainly rejected << 6 | in-window << 7 | read index << 8 | pick << 18 |
-// the read's current cluster << 21 | the cluster the proposal moves it to << 24
 typedef __attribute__((address_space(3))) const volatile uint8_t lds_cvu8;
-__device__ __forceinline__ uint32_t ghop_words(const GenWindow &wd, const float *thr, uint32_t npad, const uint8_t *labels) {
-    const uint32_t idx = wd.ip & 1023u, pick = wd.ip >> 10;
-    const float t = __int_as_float((int)lds_ld32(reinterpret_cast<const uint32_t *>(thr) + pick * npad + idx));
-    const uint32_t old = *(lds_cvu8 *)(labels + idx);
-    const uint32_t nw = pick < old ? pick : pick + 1u;
-    const bool in = wd.nxt != 255u;
-    return (wd.nxt & 63u) | ((in && wd.u > t) ? 64u : 0u) | (in ? 128u : 0u) | (idx << 8) | (pick << 18) | (old << 21) | (nw << 24);
-}
 __device__ __forceinline__ double lds_ld_f64(const double *p) { return jtk_bits_f64(lds_ld64(reinterpret_cast<const uint64_t *>(p))); }
 // A pointer into LDS that reached this function through memory (a struct passed by reference, an argument register of an
 // out-of-line call) looks divergent to the compiler: every use becomes a flat access with a null check and every branch
@@ -1247,10 +1198,11 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(const Lds &m_in, uint
     m.lfact = lds_uni(m_in.lfact);
     m.assign = lds_uni(m_in.assign);
     m.argmax = lds_uni(m_in.argmax);
-    m.thr = lds_uni(m_in.thr);
+    m.stab = lds_uni(m_in.stab);
+    m.nz = lds_uni(m_in.nz);
+    m.sz = lds_uni(m_in.sz);
     m.st = lds_uni(m_in.st);
     m.col = lds_uni(m_in.col);
-    m.sz = lds_uni(m_in.sz);
     m.npad = uni(m_in.npad);
     Rng rng;
     rng.pos = uni(rng_io->pos);
@@ -1362,99 +1314,161 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(const Lds &m_in, uint
     for (int c = 0; c < K; c++) size_terms(c);
     double lk = get_lk(tg, np, w, cl);
     double max = lk;
-    // ---- thresholds.  publish(): the state as the per-proposal estimate gathers it (per (column, cluster) sums and
-    //      counters, per-column totals, per-cluster size terms).  pair_thr(): the order-free estimate of proposed - lk
-    //      for "move read i (now in cluster a) to its pick-th other cluster" and the rejection threshold that follows
-    //      from it.  Thresholds are evaluated for the 64 proposals of a window at a time, one per lane (hop_words),
-    //      from the state last published: at every accept, and at least every 65,536 steps.
+    // ---- thresholds (see the header comment).  Per-column constants first: the largest |x| and, per read, the columns
+    //      with a non-zero value.
     const uint32_t npad = m.npad;
-    (void)npad;
-    double S0 = 0.0;
-    auto publish = [&]() {
-        if (lane < D) {
-            double G = 0.0;
-            int IU = 0, AN = 0, FR = 0;
+    typedef __attribute__((address_space(3))) const double lds_cd;
+    typedef __attribute__((address_space(3))) double lds_d;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    lds_cd *const data_l = (lds_cd *)m.data;  // 32-bit LDS addressing for the hot gathers
+    lds_d *const stab_l = (lds_d *)m.stab;
+    lds_u32 *const nz_l = (lds_u32 *)m.nz;
+    double xmax = 0.0;  // lane = column
+    for (uint32_t i = 0; i < n; i++) {
+        const double x = lane < D ? data_l[i * D + lane] : 0.0;
+        xmax = fabs(x) > xmax ? fabs(x) : xmax;
+    }
+    for (uint32_t i = lane; i < n; i += 64) {
+        uint32_t z = 0;
+        for (uint32_t d = 0; d < D; d++) z |= data_l[i * D + d] != 0.0 ? 1u << d : 0u;
+        nz_l[i] = z;
+    }
+    uint32_t umask[K];  // columns cluster c is paid for: used and total_gain > 0 (what s[c][.] is summed over)
 #pragma unroll
-            for (int c = 0; c < K; c++) {
-                const bool pos = 0.0 < tg[c];
-                const bool frag = fabs(tg[c]) < 1e-6 && (np[c] != 0 || w[c] > 0);
-                G += pos ? tg[c] : 0.0;
-                IU += pos ? np[c] : 0;
-                AN += (pos && w[c] > 0) ? 1 : 0;
-                FR += frag ? 1 : 0;
-                StEnt e;
-                e.T = tg[c];
-                e.P = np[c] | (frag ? 65536 : 0);
-                e.W = w[c];
-                lds_store_st(&m.st[lane * K + c], e);
-            }
-            ColEnt ce;
-            ce.G = G;
-            ce.IU = IU;
-            ce.AN = AN;
-            ce.TP = totp;
-            ce.FR = FR;
-            ce.pad[0] = ce.pad[1] = 0;
-            lds_store_col(&m.col[lane], ce);
-        }
-        S0 = 0.0;
+    for (int c = 0; c < K; c++) umask[c] = 0xffffffffu;  // "never built"
+    uint32_t nrcol = 0;   // columns whose used / unused status a single move could flip
+    uint32_t nrun = 0;    // nrcol | every cluster's uncertified columns
+    bool fragile = false; // some sum with counts behind it is within 1e-6 of zero
+    double C0 = 0.0;      // (order-free get_lk of the current state) - lk: what every estimate starts from
+    auto publish = [&]() {
+        int IU = 0, AN = 0, RB = 0;
+        bool alloff = true, frag = false;
+        double G = 0.0;
+        uint32_t nr[K], pm[K];
 #pragma unroll
         for (int c = 0; c < K; c++) {
-            S0 += sz0[c];
+            const bool pos = 0.0 < tg[c];
+            IU += pos ? np[c] : 0;
+            AN += (pos && w[c] > 0) ? 1 : 0;
+            RB += (pos && w[c] > 7) ? 1 : 0;
+            alloff = alloff && (!pos || w[c] <= -7);
+            frag = frag || (fabs(tg[c]) < 1e-6 && (np[c] != 0 || w[c] > 0));
+            pm[c] = (uint32_t)(__ballot(pos) & colm);
+            // `0 < total_gain` of this cluster cannot flip under any single move iff the sum clears the column's largest |x|
+            nr[c] = (uint32_t)(__ballot(!(fabs(tg[c]) > xmax + 1e-6)) & colm);
+        }
+        if (lane < D) {  // the exact state, for the columns a proposal is not certified on (see hop_words)
+#pragma unroll
+            for (int c = 0; c < K; c++) {
+                const uint64_t tb = jtk_f64_bits(tg[c]);
+                u32x4 e;
+                e.x = (uint32_t)tb;
+                e.y = (uint32_t)(tb >> 32);
+                e.z = (uint32_t)np[c];
+                e.w = (uint32_t)w[c];
+                ((lds_u32x4 *)m.st)[lane * K + c] = e;
+            }
+            u32x4 e;
+            e.x = (uint32_t)IU;
+            e.y = (uint32_t)AN;
+            e.z = (uint32_t)totp;
+            e.w = 0;
+            ((lds_u32x4 *)m.col)[lane] = e;
+        }
+        const int v = 3 * IU - 2 * totp;  // used needs v >= 1; one move changes 3 IU by at most 3
+        const bool iu_rob = v >= 4 || v <= -3;
+        const bool an_rob = RB >= 1 || alloff;  // an informative cluster that stays one, or none that could become one
+        const bool used = AN > 0 && v >= 1;
+        nrcol = (uint32_t)(__ballot(!(iu_rob && an_rob)) & colm);
+        nrun = nrcol;
+#pragma unroll
+        for (int c = 0; c < K; c++) nrun |= nr[c];
+        fragile = __ballot(lane < D && frag) != 0ull;
+        const uint32_t usedm = (uint32_t)(__ballot(used) & colm);
+#pragma unroll
+        for (int c = 0; c < K; c++) G += (used && 0.0 < tg[c]) ? tg[c] : 0.0;
+        double S0 = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; c++) S0 += sz0[c];
+        C0 = unif64((S0 + wave_sum_f64(lane < D ? G : 0.0)) - lk);
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            const uint32_t um = usedm & pm[c];
+            if (um != umask[c]) {  // rare once the clusters have formed: rebuild s[c][.]
+                umask[c] = um;
+                for (uint32_t i = lane; i < n; i += 64) {
+                    double sc = 0.0;
+                    uint32_t mm = um;
+                    while (mm) {
+                        const uint32_t d = (uint32_t)__builtin_ctz(mm);
+                        mm &= mm - 1;
+                        sc += data_l[i * D + d];
+                    }
+                    stab_l[(uint32_t)c * npad + i] = sc;
+                }
+            }
             if (lane == 0) {
                 SzEnt e;
-                e.sz0 = sz0[c];
-                e.szm = szm[c];
-                e.szp = szp[c];
-                e.pad = 0.0;
+                e.rem = szm[c] - sz0[c];
+                e.add = szp[c] - sz0[c];
+                e.nr = nr[c];
+                e.um = um;
+                e.pad[0] = e.pad[1] = 0;
                 lds_store_sz(&m.sz[c], e);
             }
         }
         wsync();
-    };
-    typedef __attribute__((address_space(3))) const double lds_cd;
-    lds_cd *const data_l = (lds_cd *)m.data;  // 32-bit LDS addressing for the hot gathers
-    auto pair_thr = [&](uint32_t i, uint32_t a, uint32_t pick) -> float {  // per lane
-        const uint32_t cb = pick < a ? pick : pick + 1u;
-        double sum = 0.0;
-        bool cant = false;
-        for (uint32_t d = 0; d < D; d++) {
-            const Elem el = elem_of(data_l[i * D + d]);
-            const ColEnt ce = lds_load_col(&m.col[d]);
-            const StEnt ea = lds_load_st(&m.st[d * K + a]);
-            const StEnt eb = lds_load_st(&m.st[d * K + cb]);
-            const bool fa0 = (ea.P >> 16) & 1, fb0 = (eb.P >> 16) & 1;
-            const int Pa = ea.P & 0xffff, Pb = eb.P & 0xffff;
-            const bool pa = 0.0 < ea.T, pb = 0.0 < eb.T;
-            const double Ta = ea.T - el.x, Tb = eb.T + el.x;
-            const int Pa2 = Pa - el.dp, Wa2 = ea.W - el.pw, Pb2 = Pb + el.dp, Wb2 = eb.W + el.pw;
-            const bool pa2 = 0.0 < Ta, pb2 = 0.0 < Tb;
-            const double G2 = (ce.G - (pa ? ea.T : 0.0) - (pb ? eb.T : 0.0)) + ((pa2 ? Ta : 0.0) + (pb2 ? Tb : 0.0));
-            const int IU2 = ce.IU - (pa ? Pa : 0) - (pb ? Pb : 0) + (pa2 ? Pa2 : 0) + (pb2 ? Pb2 : 0);
-            const int AN2 = ce.AN - ((pa && ea.W > 0) ? 1 : 0) - ((pb && eb.W > 0) ? 1 : 0) + ((pa2 && Wa2 > 0) ? 1 : 0) +
-                            ((pb2 && Wb2 > 0) ? 1 : 0);
-            const bool used = AN2 > 0 && 3 * IU2 > 2 * ce.TP;
-            sum += used ? G2 : 0.0;
-            // a sum near zero with counts behind it: rounding drift could flip its sign, and with it `used`
-            const bool fa2 = fabs(Ta) < 1e-6 && (Pa2 != 0 || Wa2 > 0);
-            const bool fb2 = fabs(Tb) < 1e-6 && (Pb2 != 0 || Wb2 > 0);
-            cant = cant || fa2 || fb2 || (ce.FR - (fa0 ? 1 : 0) - (fb0 ? 1 : 0)) > 0;
-        }
-        const SzEnt sa = lds_load_sz(&m.sz[a]), sb = lds_load_sz(&m.sz[cb]);
-        const double dA = ((S0 - sa.sz0 - sb.sz0 + sa.szm + sb.szp) + sum) - lk;
-        return cant ? 2.0f : reject_threshold(dA, false);
     };
     // per window position: nxt (6 bits) | certainly rejected << 6 | in-window << 7 | read index << 8 | pick << 18 |
     // the read's current cluster << 21 | the cluster the proposal moves it to << 24
     const uint32_t n1 = n - 1;
     auto hop_words = [&](const GenWindow &wd) -> uint32_t {
         uint32_t idx = wd.ip & 1023u;
-        const uint32_t pick = wd.ip >> 10;
+        uint32_t pick = wd.ip >> 10;
         const bool in = wd.nxt != 255u;
         idx = idx < n1 ? idx : n1;  // a position that is not a parsed proposal may hold anything
+        pick = pick < (uint32_t)(K - 1) ? pick : 0u;
         const uint32_t old = *(lds_cvu8 *)(m.assign + idx);
         const uint32_t nw = pick < old ? pick : pick + 1u;
-        const float t = pair_thr(idx, old, pick < (uint32_t)(K - 1) ? pick : 0u);
+        const SzEnt ea = lds_load_sz(&m.sz[old]), eb = lds_load_sz(&m.sz[nw]);
+        const uint32_t z = ((lds_cu32 *)nz_l)[idx];
+        // columns this proposal is not certified on: there the change of get_lk is evaluated from the exact state
+        const uint32_t F = z & (ea.nr | eb.nr | nrcol);
+        bool cant = fragile;
+        double corr = 0.0;
+        uint32_t any = nrun;  // the columns some proposal could be uncertified on (wave-uniform)
+        while (any) {
+            const uint32_t d = (uint32_t)__builtin_ctz(any);
+            any &= any - 1;
+            if (!((F >> d) & 1u)) continue;
+            const Elem el = elem_of(data_l[idx * D + d]);
+            const u32x4 ce = ((lds_c_u32x4 *)m.col)[d];
+            const u32x4 qa = ((lds_c_u32x4 *)m.st)[d * K + old], qb = ((lds_c_u32x4 *)m.st)[d * K + nw];
+            const double Ta0 = lo_f64(qa), Tb0 = lo_f64(qb);
+            const int Pa = (int)qa.z, Wa = (int)qa.w, Pb = (int)qb.z, Wb = (int)qb.w;
+            const bool pa = 0.0 < Ta0, pb = 0.0 < Tb0;
+            const double Ta = Ta0 - el.x, Tb = Tb0 + el.x;
+            const int Pa2 = Pa - el.dp, Wa2 = Wa - el.pw, Pb2 = Pb + el.dp, Wb2 = Wb + el.pw;
+            const bool pa2 = 0.0 < Ta, pb2 = 0.0 < Tb;
+            const int IU = (int)ce.x, AN = (int)ce.y, TP = (int)ce.z;
+            const bool used0 = AN > 0 && 3 * IU > 2 * TP;
+            const int IU2 = IU - (pa ? Pa : 0) - (pb ? Pb : 0) + (pa2 ? Pa2 : 0) + (pb2 ? Pb2 : 0);
+            const int AN2 = AN - ((pa && Wa > 0) ? 1 : 0) - ((pb && Wb > 0) ? 1 : 0) + ((pa2 && Wa2 > 0) ? 1 : 0) +
+                            ((pb2 && Wb2 > 0) ? 1 : 0);
+            const bool used2 = AN2 > 0 && 3 * IU2 > 2 * TP;
+            // the two clusters' terms before and after; the other clusters' terms only matter if `used` flips
+            const double t0 = used0 ? ((pa ? Ta0 : 0.0) + (pb ? Tb0 : 0.0)) : 0.0;
+            const double t2 = used2 ? ((pa2 ? Ta : 0.0) + (pb2 ? Tb : 0.0)) : 0.0;
+            if (used0 != used2) cant = true;  // (every other cluster's term switches too: rare, left to the exact step)
+            // sums near zero with counts behind them: rounding residues could flip their sign
+            cant = cant || (fabs(Ta) < 1e-6 && (Pa2 != 0 || Wa2 > 0)) || (fabs(Tb) < 1e-6 && (Pb2 != 0 || Wb2 > 0));
+            // replace the separable contribution of this column by the exact one
+            const double sep = (((eb.um >> d) & 1u) ? el.x : 0.0) - (((ea.um >> d) & 1u) ? el.x : 0.0);
+            corr += (t2 - t0) - sep;
+        }
+        const double dA = (((stab_l[nw * npad + idx] - stab_l[old * npad + idx]) + corr) + (ea.rem + eb.add)) + C0;
+        const float t = cant ? 2.0f : reject_threshold(dA, false);
         return (wd.nxt & 63u) | ((in && wd.u > t) ? 64u : 0u) | (in ? 128u : 0u) | (idx << 8) | (pick << 18) | (old << 21) | (nw << 24);
     };
 #ifdef JTK_MCMC_STATS
@@ -1617,8 +1631,8 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(const Lds &m_in, uint
     }
 #ifdef JTK_MCMC_STATS
     if (lane == 0)
-        printf("TABSTAT K %d n %u D %u steps %u fast %llu events %llu accepts %llu reloads %llu scalars %llu cyc_rebuild %llu cyc_event %llu cyc_total %llu\n",
-               K, n, D, total, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], __builtin_readcyclecounter() - ts_t0);
+        printf("TABSTAT chunk %u K %d n %u D %u steps %u fast %llu events %llu accepts %llu reloads %llu scalars %llu cyc_rebuild %llu cyc_event %llu cyc_total %llu\n",
+               blockIdx.x, K, n, D, total, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], __builtin_readcyclecounter() - ts_t0);
 #endif
 #undef TS_ADD
     rng.pos = wd.base + p;
@@ -2378,10 +2392,11 @@ __global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, Chun
         m.prev_used = (uint8_t *)take(lds_d);
         m.tmp_used = (uint8_t *)take(lds_d);
         m.npad = (lds_n + 63u) & ~63u;
-        m.thr = (float *)take((size_t)(lds_k - 1) * m.npad * 4);
-        m.st = (StEnt *)take((size_t)lds_d * lds_k * sizeof(StEnt));
-        m.col = (ColEnt *)take((size_t)lds_d * sizeof(ColEnt));
+        m.stab = (double *)take((size_t)lds_k * m.npad * 8);
+        m.nz = (uint32_t *)take((size_t)m.npad * 4);
         m.sz = (SzEnt *)take((size_t)lds_k * sizeof(SzEnt));
+        m.st = (u32x4_t *)take((size_t)lds_d * lds_k * 16);
+        m.col = (u32x4_t *)take((size_t)lds_d * 16);
         m.flags = flags;
     }
     if (jump_in_lds)
@@ -2563,8 +2578,8 @@ static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
     return al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) +
            al(16 * 8) + al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) +
            2 * al((size_t)JTK_MAX_COPY * lds_d * 8) + 2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d) +
-           al((size_t)(lds_k - 1) * npad * 4) + al((size_t)lds_d * lds_k * sizeof(StEnt)) + al((size_t)lds_d * sizeof(ColEnt)) +
-           al((size_t)lds_k * sizeof(SzEnt));
+           al((size_t)lds_k * npad * 8) + al(npad * 4) + al((size_t)lds_k * sizeof(SzEnt)) + al((size_t)lds_d * lds_k * 16) +
+           al((size_t)lds_d * 16);
 }
 static uint32_t clamp_k(uint32_t lds_k) { return lds_k < 2 ? 2 : (lds_k > JTK_MAX_COPY ? JTK_MAX_COPY : lds_k); }
 static bool mcmc_jump_in_lds(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {

@@ -169,6 +169,8 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
         const ChunkState st = state[rm.chunk];
         if (st.status != 0) continue;
         if (only_active && !st.active) continue;
+        if (cm.take_num && item - cm.read_first >= cm.take_num) continue;  // this read does not vote (its ops are still re-threaded)
+        if (cm.radius > JTK_MAX_RADIUS) continue;                          // phmm_wide_kernel's read
         const int L = (int)st.tmpl_len, n = (int)rm.read_len, T = L + n, r = (int)cm.radius;
         const HmmDev *h = hmm2 + (rm.strand ? 0 : 1);
         const uint64_t *delta = delta_all + rm.delta_off;
@@ -510,6 +512,10 @@ __global__ void finalize_kernel(uint32_t n_reads, const ReadMeta *reads, const C
     const ChunkState st = state[rm.chunk];
     if (st.status != 0) return;
     if (only_active && !st.active) return;
+    {
+        const ChunkMeta &cm = chunks[rm.chunk];
+        if (cm.take_num && item - cm.read_first >= cm.take_num) return;
+    }
     const int L = (int)st.tmpl_len;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > L) return;

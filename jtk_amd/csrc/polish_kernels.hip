@@ -20,7 +20,8 @@ __global__ void sum_tables_kernel(const ReadMeta *reads, const ChunkMeta *chunks
     const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= cols) return;
     double s = 0.0;
-    for (uint32_t r = 0; r < cm.n_reads; r++) s += table_all[reads[cm.read_first + r].table_off + col];
+    const uint32_t voters = (cm.take_num && cm.take_num < cm.n_reads) ? cm.take_num : cm.n_reads;
+    for (uint32_t r = 0; r < voters; r++) s += table_all[reads[cm.read_first + r].table_off + col];
     total_all[cm.total_off + col] = s;
 }
 

@@ -159,6 +159,7 @@ struct ChunkExtra {
     uint32_t radius;        // config.band_width (mod.rs:112,142,153)
     double local_coverage;  // config.local_coverage (mod.rs:108-112)
     uint64_t rng[4];        // the chunk's generator, as the previous call left it (mod.rs:158)
+    uint32_t take_num;      // HMMPolishConfig take_num (0 = every read votes)
 };
 
 }  // namespace
@@ -192,6 +193,11 @@ struct jtk_lc_session {
     std::vector<SplitResult> split;      // per chunk; .k == 0: not a split chunk
     DevPtr d_rng;                        // 4 x u64 per chunk: where each chunk's RNG stream resumes (sub-problems only)
     bool resume_rng = false;
+    bool polish_only = false;            // jtk_lc_polish_chunks: no variant search, no clustering
+    // reads whose band is wider than one wavefront (radius > JTK_MAX_RADIUS) take phmm_wide_kernel
+    uint32_t n_wide_reads = 0, max_wide_radius = 0, n_wide_waves = 0;
+    uint64_t wide_stride = 0;
+    DevPtr d_wide_scratch, d_wide_counter;
     ~jtk_lc_session() {
         if (stream) (void)hipStreamSynchronize(stream);  // blocks go back to the pool, not through hipFree's implicit sync
         for (auto &t : timers) {
@@ -331,12 +337,18 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         const double pcc = (double)ch.n_reads / (double)ch.copy_num;
         cm.local_coverage = ch.copy_num <= 2 ? pcc : (pcc > params->haploid_coverage ? pcc : params->haploid_coverage);
         if (extra) cm.local_coverage = extra[c].local_coverage;
+        if (extra) cm.take_num = extra[c].take_num;
         ChunkState &st = s->h_state0[c];
         memset(&st, 0, sizeof st);
         st.tmpl_len = tl;
         st.active = 1;
         st.k = 1;
-        if (cm.radius > JTK_MAX_RADIUS) st.status = JTK_ERR_UNSUPPORTED;
+        if (cm.radius > JTK_WIDE_MAX_RADIUS) {
+            st.status = JTK_ERR_UNSUPPORTED;
+        } else if (cm.radius > JTK_MAX_RADIUS) {
+            s->n_wide_reads += ch.n_reads;
+            if (cm.radius > s->max_wide_radius) s->max_wide_radius = cm.radius;
+        }
         h_homop_off[c] = tmpl_off;
         h_aux_off[c] = aux_off;
         h_lg_off[c] = lg_off;
@@ -501,6 +513,21 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         s->scratch_stride = (uint64_t)(s->max_tmpl + s->max_read + 8) * 64 * 2;  // doubles
         if ((rc = dev_alloc<double>(s->d_scratch, s->scratch_stride * s->n_waves))) return rc;
     }
+    if (s->n_wide_reads) {
+        const size_t wl = phmm_wide_lds_bytes(s->max_tmpl, s->max_read);
+        if (wl > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "template + read too long for the LDS staging of phmm_wide_kernel");
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        uint32_t per_cu = (uint32_t)((160u * 1024u) / wl);
+        if (per_cu > 4) per_cu = 4;
+        s->wide_stride = phmm_wide_scratch_doubles(s->max_tmpl, s->max_read, s->max_wide_radius);
+        uint64_t want = (uint64_t)prop.multiProcessorCount * per_cu;
+        const uint64_t budget = (48ull << 30) / (s->wide_stride * 8);  // at most 48 GB of forward tables in flight
+        if (want > budget) want = budget ? budget : 1;
+        s->n_wide_waves = (uint32_t)std::min<uint64_t>(s->n_wide_reads, want);
+        if ((rc = dev_alloc<double>(s->d_wide_scratch, s->wide_stride * s->n_wide_waves))) return rc;
+        if ((rc = dev_alloc<uint32_t>(s->d_wide_counter, 4))) return rc;
+    }
     s->bufs.tmpl[0] = s->d_tmpl0.as<uint8_t>();
     s->bufs.tmpl[1] = s->d_tmpl1.as<uint8_t>();
     s->bufs.ops[0] = s->d_ops0.as<uint8_t>();
@@ -570,6 +597,11 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                     hmm2, s->d_scratch.as<double>(), s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(),
                     s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read,
                     only_active);
+        if (s->n_wide_reads)
+            launch_phmm_wide(st, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(),
+                             hmm2, s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves,
+                             s->d_wide_counter.as<uint32_t>(), s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                             s->d_lk.as<double>(), s->max_tmpl, s->max_read, only_active);
         launch_finalize(st, s->n_reads, reads, chunks, state, hmm2, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                         s->d_lk.as<double>(), s->d_table.as<double>(), s->max_tmpl, only_active);
         tstop(s);
@@ -585,6 +617,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
         HIP_TRY(hipMemcpyAsync(&n_active, s->d_nactive.p, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
+    if (!s->polish_only) {
     tstart(s, JTK_K_FILTER);
     launch_filter(st, s->n_chunks, reads, chunks, state, s->bufs, s->d_params.as<jtk_lc_params_t>(),
                   s->d_table.as<double>(), s->d_homop.as<uint16_t>(), s->d_homop_off.as<uint64_t>(),
@@ -605,6 +638,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
         (void)hipStreamSynchronize(st);
         return fail(JTK_ERR_INTERNAL, "the chain kernel could not be launched (jump table upload failed)");
     }
+    }  // !polish_only
     HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -970,6 +1004,7 @@ static int run_split(jtk_lc_session_t *s) {
             extra[b].radius = cm.radius;
             extra[b].local_coverage = cm.local_coverage;
             memcpy(extra[b].rng, w.rng, 32);
+            extra[b].take_num = 0;
             tmpl.insert(tmpl.end(), f.tmpl.begin(), f.tmpl.end());
             for (size_t i = 0; i < f.rid.size(); i++) {
                 const uint32_t g = f.rid[i];
@@ -1184,6 +1219,36 @@ int jtk_lc_cluster_polished(const jtk_lc_params_t *params, size_t n_chunks, cons
                     log_post, post_stride, result, nullptr, nullptr, 0, nullptr, nullptr, 0, device);
 }
 
+// kiley polish_until_converge_antidiagonal(template, seqs, ops, strands, HMMPolishConfig::new(radius, take_num, ignore_edge))
+// for a batch of independent windows: what consensus::polish_seg (haplotyper/src/consensus/mod.rs:445-496, :476-483) and
+// polish_segments.rs run on 2 kbp windows of contigs -- the same kernels as the stage's own polishing step.
+int jtk_lc_polish_chunks(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                         const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                         const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t radius,
+                         uint32_t take_num, uint32_t ignore_edge, uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap,
+                         uint8_t *ops_out, uint64_t *ops_out_off, uint64_t ops_cap, jtk_lc_result_t *result, int device) {
+    g_last_error.clear();
+    if (!cons_out || !cons_off || !ops_out || !ops_out_off) return fail(JTK_ERR_INVALID_ARG, "null output");
+    std::vector<ChunkExtra> extra(n_chunks);
+    std::vector<jtk_lc_chunk_t> ch(chunks, chunks + (chunks ? n_chunks : 0));
+    for (size_t c = 0; c < n_chunks; c++) {
+        memset(&extra[c], 0, sizeof extra[c]);
+        // radius 0: derive it from the window length like the stage does (mod.rs:96,105)
+        extra[c].radius = radius ? radius : (uint32_t)std::ceil((double)ch[c].tmpl_len * params->band_frac) / 2;
+        extra[c].take_num = take_num;
+        ch[c].copy_num = 1;  // no clustering happens; keeps every posterior row a single entry
+    }
+    jtk_lc_session_t *s = nullptr;
+    int rc = session_create_ex(params, n_chunks, ch.data(), tmpl_bases, read_bases, read_off, ops, ops_off, strand, 1, device,
+                               extra.data(), ignore_edge, &s);
+    if (rc) return rc;
+    std::unique_ptr<jtk_lc_session> guard(s);
+    s->polish_only = true;
+    s->resume_rng = false;
+    if ((rc = run_batch(s, 0))) return rc;
+    return jtk_lc_session_fetch(s, nullptr, nullptr, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap);
+}
+
 int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl, uint64_t tmpl_len,
                               uint32_t n_reads, const uint8_t *read_bases, const uint64_t *read_off,
                               const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, double *table,
@@ -1214,6 +1279,11 @@ int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl
                 s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(), s->d_scratch.as<double>(),
                 s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(), s->d_raw.as<double>(), s->d_rawG.as<int>(),
                 s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
+    if (s->n_wide_reads)
+        launch_phmm_wide(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
+                         s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(),
+                         s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves, s->d_wide_counter.as<uint32_t>(),
+                         s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
     launch_finalize(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state,
                     s->d_hmm2.as<HmmDev>(), s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(),
                     s->d_table.as<double>(), s->max_tmpl, 0);
@@ -1262,6 +1332,11 @@ int jtk_internal_likelihoods(const jtk_lc_params_t *params, size_t n_chunks, con
                 s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(), s->d_scratch.as<double>(),
                 s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(), s->d_raw.as<double>(), s->d_rawG.as<int>(),
                 s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
+    if (s->n_wide_reads)
+        launch_phmm_wide(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
+                         s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(),
+                         s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves, s->d_wide_counter.as<uint32_t>(),
+                         s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
     std::vector<ChunkState> cs(n_chunks);
     HIP_TRY(hipMemcpyAsync(cs.data(), state, cs.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(lk_out, s->d_lk.p, (size_t)s->n_reads * 8, hipMemcpyDeviceToHost, st));

@@ -181,6 +181,11 @@ int jo_cluster_chunks(const jtk_lc_params_t *params, size_t n_chunks, const jtk_
                       uint32_t *label, double *log_post, uint32_t post_stride, jtk_lc_result_t *result,
                       uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out,
                       uint64_t *ops_out_off, uint64_t ops_cap, int n_threads, double *record_ms);
+int jo_polish_chunks(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                     const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                     const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t radius,
+                     uint32_t take_num, uint32_t ignore_edge, uint8_t *cons_out, uint64_t *cons_off, uint8_t *ops_out,
+                     uint64_t *ops_out_off, jtk_lc_result_t *result, int n_threads);
 int jo_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_feature_chunk_t *chunks,
                         const double *variants, const uint32_t *variant_type, uint32_t *label,
                         double *log_post, uint32_t post_stride, jtk_lc_result_t *result, int n_threads);

@@ -346,6 +346,95 @@ int jo_cluster_chunks(const jtk_lc_params_t *params, size_t n_chunks, const jtk_
     return any_fail ? JTK_ERR_CHUNK_FAILED : 0;
 }
 
+/* kiley polish_until_converge_antidiagonal(template, seqs, ops, strands, HMMPolishConfig::new(radius, take_num,
+ * ignore_edge)) on a batch of independent windows: the call of consensus::polish_seg (consensus/mod.rs:476-483) and of the
+ * stage itself (mod.rs:105-106).  radius 0 = ceil(len * band_frac) / 2 (mod.rs:96,105); take_num 0 = all reads. */
+int jo_polish_chunks(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                     const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                     const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t radius,
+                     uint32_t take_num, uint32_t ignore_edge, uint8_t *cons_out, uint64_t *cons_off, uint8_t *ops_out,
+                     uint64_t *ops_out_off, jtk_lc_result_t *result, int n_threads) {
+    int any_fail = 0;
+    uint8_t **cons_tmp = (uint8_t **)calloc(n_chunks, sizeof(uint8_t *));
+    uint8_t ***ops_tmp = (uint8_t ***)calloc(n_chunks, sizeof(uint8_t **));
+    size_t **ops_len_tmp = (size_t **)calloc(n_chunks, sizeof(size_t *));
+    size_t *cons_len = (size_t *)calloc(n_chunks, sizeof(size_t));
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long ci = 0; ci < (long)n_chunks; ci++) {
+        const jtk_lc_chunk_t *ch = &chunks[ci];
+        size_t n = ch->n_reads, tl = (size_t)ch->tmpl_len;
+        const uint8_t **reads = (const uint8_t **)malloc((n ? n : 1) * sizeof(*reads));
+        size_t *rlen = (size_t *)malloc((n ? n : 1) * sizeof(size_t));
+        uint8_t **rops = (uint8_t **)malloc((n ? n : 1) * sizeof(*rops));
+        size_t *olen = (size_t *)malloc((n ? n : 1) * sizeof(size_t));
+        size_t slack = tl / 4 + 64, max_ops = 0;
+        for (size_t r = 0; r < n; r++) {
+            size_t g = (size_t)ch->read_first + r, l = (size_t)(ops_off[g + 1] - ops_off[g]);
+            if (l > max_ops) max_ops = l;
+        }
+        size_t ocap = max_ops + slack;
+        for (size_t r = 0; r < n; r++) {
+            size_t g = (size_t)ch->read_first + r;
+            reads[r] = read_bases + read_off[g];
+            rlen[r] = (size_t)(read_off[g + 1] - read_off[g]);
+            olen[r] = (size_t)(ops_off[g + 1] - ops_off[g]);
+            rops[r] = (uint8_t *)malloc(ocap + 8);
+            memcpy(rops[r], ops + ops_off[g], olen[r]);
+        }
+        size_t ccap = tl + slack;
+        uint8_t *cons = (uint8_t *)malloc(ccap + 8);
+        size_t rad = radius ? radius : band_width_of(params->band_frac, tl) / 2;
+        uint32_t rounds = 0;
+        int64_t cl = jo_phmm_polish(&params->forward, &params->reverse, tmpl_bases + ch->tmpl_off, tl, n, reads, rlen, rops,
+                                    olen, ocap, strand + ch->read_first, rad, take_num ? take_num : n, ignore_edge, cons,
+                                    ccap, &rounds);
+        memset(&result[ci], 0, sizeof result[ci]);
+        result[ci].cluster_num = 1;
+        result[ci].polish_rounds = rounds;
+        result[ci].status = cl < 0 ? JTK_ERR_CHUNK_FAILED : 0;
+        if (cl < 0) {
+#pragma omp atomic write
+            any_fail = 1;
+        }
+        cons_tmp[ci] = cons;
+        cons_len[ci] = cl < 0 ? 0 : (size_t)cl;
+        ops_tmp[ci] = rops;
+        ops_len_tmp[ci] = olen;
+        free(reads);
+        free(rlen);
+    }
+    uint64_t co = 0, oo = 0;
+    for (size_t ci = 0; ci < n_chunks; ci++) {
+        const jtk_lc_chunk_t *ch = &chunks[ci];
+        cons_off[ci] = co;
+        memcpy(cons_out + co, cons_tmp[ci], cons_len[ci]);
+        co += cons_len[ci];
+        for (size_t r = 0; r < ch->n_reads; r++) {
+            size_t g = (size_t)ch->read_first + r;
+            size_t l = result[ci].status == 0 ? ops_len_tmp[ci][r] : 0;
+            ops_out_off[g] = oo;
+            memcpy(ops_out + oo, ops_tmp[ci][r], l);
+            oo += l;
+            ops_out_off[g + 1] = oo;
+            free(ops_tmp[ci][r]);
+        }
+        free(ops_tmp[ci]);
+        free(ops_len_tmp[ci]);
+        free(cons_tmp[ci]);
+    }
+    cons_off[n_chunks] = co;
+    free(cons_tmp);
+    free(ops_tmp);
+    free(ops_len_tmp);
+    free(cons_len);
+    return any_fail ? JTK_ERR_CHUNK_FAILED : 0;
+}
+
 int jo_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_feature_chunk_t *chunks,
                         const double *variants, const uint32_t *variant_type, uint32_t *label,
                         double *log_post, uint32_t post_stride, jtk_lc_result_t *result, int n_threads) {

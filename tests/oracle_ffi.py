@@ -172,6 +172,8 @@ def lib():
     sig("jo_cluster_chunks", C.c_int, C.POINTER(Params), sz, p, PU8, PU8, C.POINTER(u64), PU8,
         C.POINTER(u64), PU8, C.c_int, C.POINTER(u32), PD, u32, p, PU8, C.POINTER(u64), u64, PU8,
         C.POINTER(u64), u64, C.c_int, PD)
+    sig("jo_polish_chunks", C.c_int, C.POINTER(Params), sz, p, PU8, PU8, C.POINTER(u64), PU8, C.POINTER(u64), PU8, u32, u32,
+        u32, PU8, C.POINTER(u64), PU8, C.POINTER(u64), p, C.c_int)
     sig("jo_cluster_features", C.c_int, C.POINTER(Params), sz, p, PD, C.POINTER(u32), C.POINTER(u32), PD,
         u32, p, C.c_int)
     sig("jo_modification_table", C.c_int, C.POINTER(Params), PU8, u64, u32, PU8, C.POINTER(u64), PU8,
@@ -235,3 +237,19 @@ def cluster_chunks(params, batch, skip_polish=False, n_threads=0, want_record=Fa
     if want_record:
         out["record_ms"] = rec
     return out
+
+
+def polish_chunks(params, batch, radius=0, take_num=0, ignore_edge=0, n_threads=0):
+    """jo_polish_chunks: polish_until_converge_antidiagonal on every window of `batch`."""
+    L = lib()
+    nchunks, nreads = len(batch.chunks), len(batch.strand)
+    result = np.zeros(nchunks, dtype=RESULT_DT)
+    cons = np.zeros(int(batch.chunks["tmpl_len"].sum()) * 2 + 64 * nchunks + 64, dtype=np.uint8)
+    cons_off = np.zeros(nchunks + 1, dtype=np.uint64)
+    ops_out = np.zeros(int(len(batch.ops)) * 2 + 64 * nreads + 64, dtype=np.uint8)
+    ops_out_off = np.zeros(nreads + 1, dtype=np.uint64)
+    rc = L.jo_polish_chunks(C.byref(params), nchunks, batch.chunks.ctypes.data, u8p(batch.tmpl_bases), u8p(batch.read_bases),
+                            u64p(batch.read_off), u8p(batch.ops), u64p(batch.ops_off), u8p(batch.strand), radius, take_num,
+                            ignore_edge, u8p(cons), u64p(cons_off), u8p(ops_out), u64p(ops_out_off), result.ctypes.data,
+                            n_threads)
+    return dict(rc=rc, result=result, cons=cons, cons_off=cons_off, ops_out=ops_out, ops_out_off=ops_out_off)

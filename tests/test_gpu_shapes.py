@@ -197,3 +197,75 @@ def test_device_chain_score_is_bounded_by_the_exact_optimum(lib, seed):
     best = O.lib().jo_cluster_filtered_variants_exact(O.f64p(np.ascontiguousarray(x)), 12, 3, 2, O.szp(asn), O.f64p(gain))
     assert abs(out["result"]["score"][0] - best) < 1e-9
     assert helpers.same_partition(out["label"], lab)
+
+
+@pytest.mark.parametrize("radius,take_num,ignore_edge", [(0, 0, 3), (20, 8, 0), (0, 5, 0), (12, 0, 0)])
+def test_window_polishing_matches_oracle(lib, radius, take_num, ignore_edge):
+    """jtk_lc_polish_chunks = polish_until_converge_antidiagonal(.., HMMPolishConfig::new(radius, take_num, ignore_edge)) on
+    independent windows: the call consensus::polish_seg makes with (radius / 2, max_coverage, 0) (consensus/mod.rs:476-483);
+    only the first take_num reads vote, every read's ops are re-threaded"""
+    b, cfg, p = helpers.small_batch(config="ont_noisy", n_chunks=4, tmpl_len=700, reads_per_hap=7, first=900, tmpl_err=8e-3)
+    dev = api.polish_chunks(p, b, radius=radius, take_num=take_num, ignore_edge=ignore_edge)
+    ora = O.polish_chunks(helpers.oracle_params(p), b, radius=radius, take_num=take_num, ignore_edge=ignore_edge)
+    assert ora["rc"] == 0 and dev["rc"] == 0
+    assert np.array_equal(dev["result"]["polish_rounds"], ora["result"]["polish_rounds"])
+    assert ora["result"]["polish_rounds"].max() >= 2, "the windows must need polishing"
+    assert np.array_equal(dev["cons_off"], ora["cons_off"])
+    n = int(dev["cons_off"][-1])
+    assert bytes(dev["cons"][:n]) == bytes(ora["cons"][:n])
+    assert np.array_equal(dev["ops_out_off"], ora["ops_out_off"])
+    m = int(dev["ops_out_off"][-1])
+    assert np.array_equal(dev["ops_out"][:m], ora["ops_out"][:m])
+    if take_num:                      # fewer voters -> (generally) a different consensus than the all-read one
+        full = O.polish_chunks(helpers.oracle_params(p), b, radius=radius, take_num=0, ignore_edge=ignore_edge)
+        assert full["rc"] == 0
+
+
+# ---- bands wider than one wavefront (phmm_wide_kernel): CLR / None reads, ONT chunks longer than 2,033 bp
+
+@pytest.mark.parametrize("tmpl_len,band_frac,radius", [(600, 0.11, 33), (2000, 0.05, 50), (2100, 0.03, 31), (1000, 0.254, 127)])
+def test_wide_band_modification_table_matches_oracle(lib, tmpl_len, band_frac, radius):
+    """ReadType::band_width (definitions/src/lib.rs:173-175,201-210): CLR / None = ceil(0.05 L) -> radius 50 at 2 kbp; an ONT
+    chunk of 2,100 bp -> radius 31.  Bit for bit the table of the oracle (and of phmm_kernel, where both take the read)."""
+    import test_gpu_parity as T
+    b, cfg, p = helpers.small_batch(config="ont_noisy", n_chunks=1, tmpl_len=tmpl_len, reads_per_hap=3, first=41)
+    p.band_frac = band_frac
+    L = len(b.template(0))
+    assert int(np.ceil(L * band_frac)) // 2 == radius or abs(int(np.ceil(L * band_frac)) // 2 - radius) <= 1
+    reads = list(b.chunk_reads(0))
+    tab, lk = api.modification_table(p, b.template(0), [b.read(r) for r in reads], [b.read_ops(r) for r in reads],
+                                     [b.strand[r] for r in reads])
+    otab, olk = T.oracle_table(p, b, 0)
+    assert np.array_equal(helpers.bits(lk), helpers.bits(olk))
+    assert np.array_equal(helpers.bits(tab), helpers.bits(otab))
+    assert (otab > -1e299).sum() > 10 * L
+
+
+def test_wide_and_narrow_bands_share_a_batch(lib):
+    """the radius follows each chunk's own length (mod.rs:96): 1,900 bp -> 28 (phmm_kernel), 2,100 bp -> 31
+    (phmm_wide_kernel); the full path on a batch that holds both, and on a CLR-band batch"""
+    piles = []
+    for cid, L in [(70, 1900), (71, 2100), (72, 2150)]:
+        cfg = dict(synth.CONFIGS["ont_diploid"])
+        cfg.update(tmpl_len=L, reads_per_hap=6)
+        piles.append(synth.make_pileup(cid, cfg, min_variants=1))
+    b = jb.pack(piles)
+    p = jb.default_params(haploid_coverage=6.0, band_frac=0.03)
+    radii = [int(np.ceil(int(t) * 0.03)) // 2 for t in b.chunks["tmpl_len"]]
+    assert min(radii) <= 30 < max(radii)
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b)
+    assert_full_parity(dev, ora, b)
+    b, cfg, p = helpers.small_batch(config="ont_noisy", n_chunks=2, tmpl_len=1200, reads_per_hap=6, first=88)
+    p.band_frac = 0.05                                   # CLR / None (definitions/src/lib.rs:173-175): radius 30 at 1.2 kbp
+    b2, cfg2, _ = helpers.small_batch(config="ont_noisy", n_chunks=2, tmpl_len=1500, reads_per_hap=6, first=90)
+    dev = api.cluster_chunks(p, b2)                      # radius 37
+    ora = O.cluster_chunks(helpers.oracle_params(p), b2)
+    assert_full_parity(dev, ora, b2)
+
+
+def test_band_wider_than_the_fallback_kernel_is_reported(lib):
+    b, cfg, p = helpers.small_batch(n_chunks=2, tmpl_len=1000, reads_per_hap=3)
+    p.band_frac = 0.26                                   # radius 130 > 127
+    out = api.cluster_chunks(p, b, raise_on_chunk_failure=False)
+    assert out["rc"] == -6 and (out["result"]["status"] == -3).all()
