@@ -216,6 +216,20 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks,
 int jtk_lc_estimate_gains(const jtk_hmm_t *forward, const jtk_hmm_t *reverse, uint64_t seed, uint32_t seq_len,
                           uint32_t band, uint32_t homop_len, jtk_gains_t *out, int device);
 
+/* ---- stage preamble: model refit ----------------------------------------------------------------------
+ * Replaces `estimate_model_parameters_on_both_strands` (haplotyper/src/model_tune.rs:119-152; entered through
+ * `update_models_on_both_strands`, local_clustering/mod.rs:58) on the training pile-ups the host has selected
+ * (model_tune.rs:99-118: coverage within 2 of the median, sorted by chunk id, the first TRAIN_UNIT_SIZE = 5):
+ * `rounds` (TRAIN_ROUND = 10) times [ polish every pile-up with HMMPolishConfig::new(band / 2, N, 0), then one
+ * Baum-Welch step over all of them with the largest band's radius ].  params->forward / reverse are the starting model
+ * (DataSet.model_param), params->band_frac the read type's; the refitted models are what jtk_lc_params_t.forward /
+ * .reverse then carry.  kiley's fit is not part of the reference tree: the step is this build's own specification
+ * (expected transition / emission counts of the banded pair-HMM, rows renormalised). */
+int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                     const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                     const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t rounds,
+                     jtk_hmm_t *forward_out, jtk_hmm_t *reverse_out, int device);
+
 /* Sort key of pileup_nodes (mod.rs:47-50): number of alignment columns that are not '|' in
  * Node::recover (definitions/src/lib.rs:773-813) for run-length cigar ops given per base. */
 int jtk_lc_pileup_sort_key(const uint8_t *tmpl, uint64_t tmpl_len, const uint8_t *read, uint64_t read_len,

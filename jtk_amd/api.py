@@ -94,6 +94,16 @@ def estimate_gains(hmm_forward, hmm_reverse, seed=309423, seq_len=100, band=10, 
     return out
 
 
+def fit_model(params, batch, rounds=10, device=0):
+    """jtk_lc_fit_model: the model refit of the stage preamble (model_tune.rs:119-152) on the training pile-ups `batch`;
+    returns (forward, reverse)."""
+    f, r = ffi.Hmm(), ffi.Hmm()
+    check(ffi.lib().jtk_lc_fit_model(C.byref(params), batch.n_chunks, batch.chunks.ctypes.data, u8p(batch.tmpl_bases),
+                                     u8p(batch.read_bases), u64p(batch.read_off), u8p(batch.ops), u64p(batch.ops_off),
+                                     u8p(batch.strand), rounds, C.byref(f), C.byref(r), device))
+    return f, r
+
+
 def cluster_features(params, feature_chunks, variants, variant_type, post_stride, device=0,
                      raise_on_chunk_failure=True):
     """jtk_lc_cluster_features: cluster_filtered_variants + posterior on caller-supplied feature matrices."""

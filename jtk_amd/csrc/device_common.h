@@ -108,6 +108,13 @@ void launch_phmm_wide(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, co
                       const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
                       double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *raw,
                       int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active);
+// expected transition / emission counts of every read of a batch (E-step of the model refit); 45 doubles per read
+size_t phmm_counts_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
+uint64_t phmm_counts_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius);
+void launch_phmm_counts(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
+                        const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
+                        double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *counts,
+                        double *lk, uint32_t max_tmpl, uint32_t max_read);
 // polish_kernels.hip
 void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, const ReadMeta *reads,
                          const ChunkMeta *chunks, ChunkState *state, DevBufs bufs, const uint8_t *ey,

@@ -11,8 +11,10 @@
 // 394-407) is exercised end to end (tests/test_host_mirror.py).
 //
 // The preambles of local_clustering_selected:
-//   ds.update_models_on_both_strands()   (mod.rs:58, model_tune.rs:96-156)  needs kiley's Baum-Welch and stays with
-//                                                                            the caller: ds.model_param is used as given
+//   ds.update_models_on_both_strands()   (mod.rs:58, model_tune.rs:96-156)  update_models_on_both_strands below: training
+//                                                                            pile-ups picked here, refit by jtk_lc_fit_model
+//                                                                            (LocalClusteringOptions::refit_model = false
+//                                                                            keeps ds.model_param as given)
 //   estimate_gain_default(&hmm)          (mod.rs:60)                        jtk_lc_estimate_gains on the device, unless
 //                                                                            LocalClusteringOptions::gains supplies them
 #pragma once
@@ -94,6 +96,7 @@ struct LocalClusteringOptions {
     // not take) are left exactly as they were, their (chunk id, jtk_status) pairs are appended here and every other chunk
     // is written back.
     std::vector<std::pair<uint64_t, int>> *failed = nullptr;
+    bool refit_model = true;  // run update_models_on_both_strands (mod.rs:58) before clustering, as the reference does
 };
 
 inline double band_frac(ReadType t) {  // definitions/src/lib.rs:173-175, 201-210
@@ -169,10 +172,74 @@ inline void normalize_local_clustering(DataSet &ds) {
     }
 }
 
+// ModelFit::update_models_on_both_strands (model_tune.rs:20-25 -> estimate_model_parameters_on_both_strands :96-156).
+// Training pile-ups (:99-118): every selected chunk's nodes in order of appearance; keep the pile-ups whose size is within
+// [max(cov, 2) - 2, cov + 2) of cov = the (len / 2)-th smallest size, sort them by chunk id, take the first
+// TRAIN_UNIT_SIZE = 5.  TRAIN_ROUND = 10 rounds of polish + fit run inside jtk_lc_fit_model.
+inline void update_models_on_both_strands(DataSet &ds, int device = 0) {
+    const size_t TRAIN_UNIT_SIZE = 5;
+    const uint32_t TRAIN_ROUND = 10;
+    std::unordered_map<uint64_t, std::vector<const Node *>> pileups;
+    std::unordered_map<uint64_t, const Chunk *> chunk_of;
+    for (const auto &c : ds.selected_chunks) {
+        pileups[c.id];
+        chunk_of[c.id] = &c;
+    }
+    for (const auto &r : ds.encoded_reads)
+        for (const auto &n : r.nodes) pileups[n.chunk].push_back(&n);
+    std::vector<size_t> covs;
+    for (const auto &kv : pileups) covs.push_back(kv.second.size());
+    if (covs.empty()) throw std::runtime_error("update_models_on_both_strands: no pile-up");
+    std::nth_element(covs.begin(), covs.begin() + covs.size() / 2, covs.end());
+    const size_t cov = covs[covs.size() / 2];
+    std::vector<uint64_t> ids;
+    for (const auto &kv : pileups) {
+        const size_t len = kv.second.size();
+        if (len >= std::max<size_t>(cov, 2) - 2 && len < cov + 2 && chunk_of.count(kv.first)) ids.push_back(kv.first);
+    }
+    std::sort(ids.begin(), ids.end());
+    if (ids.size() > TRAIN_UNIT_SIZE) ids.resize(TRAIN_UNIT_SIZE);
+    std::vector<jtk_lc_chunk_t> chunks;
+    std::vector<uint8_t> tmpl, reads, ops, strand;
+    std::vector<uint64_t> read_off{0}, ops_off{0};
+    for (uint64_t id : ids) {
+        const Chunk *c = chunk_of[id];
+        jtk_lc_chunk_t ch;
+        ch.chunk_id = id;
+        ch.copy_num = (uint32_t)c->copy_num;
+        ch.n_reads = (uint32_t)pileups[id].size();
+        ch.tmpl_off = tmpl.size();
+        ch.tmpl_len = c->seq.size();
+        ch.read_first = strand.size();
+        chunks.push_back(ch);
+        tmpl.insert(tmpl.end(), c->seq.begin(), c->seq.end());
+        for (const Node *n : pileups[id]) {
+            reads.insert(reads.end(), n->seq.begin(), n->seq.end());
+            read_off.push_back(reads.size());
+            const std::vector<uint8_t> k = ops_to_kiley(n->cigar);
+            ops.insert(ops.end(), k.begin(), k.end());
+            ops_off.push_back(ops.size());
+            strand.push_back(n->is_forward ? 1 : 0);
+        }
+    }
+    if (chunks.empty() || strand.empty()) throw std::runtime_error("update_models_on_both_strands: no training pile-up");  // :135
+    jtk_lc_params_t params{};
+    params.forward = ds.model_param.forward;
+    params.reverse = ds.model_param.reverse;
+    params.band_frac = band_frac(ds.read_type);
+    jtk_hmm_t f, r;
+    const int rc = jtk_lc_fit_model(&params, chunks.size(), chunks.data(), tmpl.data(), reads.data(), read_off.data(), ops.data(),
+                                    ops_off.data(), strand.data(), TRAIN_ROUND, &f, &r, device);
+    if (rc != 0) throw std::runtime_error(std::string("update_models_on_both_strands: ") + jtk_lc_strerror(rc) + ": " + jtk_lc_last_error());
+    ds.model_param.forward = f;
+    ds.model_param.reverse = r;
+}
+
 // mod.rs:56-83
 inline void local_clustering_selected(DataSet &ds, const std::unordered_set<uint64_t> &selection,
                                       const LocalClusteringOptions &opt = LocalClusteringOptions()) {
     update_coverage(ds);  // mod.rs:57
+    if (opt.refit_model) update_models_on_both_strands(ds, opt.device);  // mod.rs:58
     jtk_lc_params_t params;
     params.forward = ds.model_param.forward;  // mod.rs:59 (refit of mod.rs:58 is the caller's, see header)
     params.reverse = ds.model_param.reverse;

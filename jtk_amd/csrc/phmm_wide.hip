@@ -322,6 +322,239 @@ __global__ __launch_bounds__(64) void phmm_wide_kernel(uint32_t n_reads, const R
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Expected transition / emission counts of one read (the E-step of the stage's model refit, model_tune.rs:144-151;
+// kiley's fit is not under /root/reference: own specification, oracle/model_fit.c).  Same sweep structure as
+// phmm_wide_kernel; the forward sweep keeps F_M, F_I, F_D of every diagonal in the scratch stripe, the backward sweep
+// adds every cell's posterior-weighted transitions and emissions to the partial sums of its lane (band offset mod 64),
+// which lane 0 finally adds up in lane order.  out: 45 counts per read (9 transitions, mat_emit[16], ins_emit[20]) + lk.
+// ------------------------------------------------------------------------------------------------------
+#define NCNT 45
+__global__ __launch_bounds__(64) void phmm_counts_kernel(uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
+                                                         const ChunkState *state, DevBufs bufs, const uint8_t *ey_all,
+                                                         const uint64_t *delta_all, const HmmDev *hmm2, double *scratch_all,
+                                                         uint64_t scratch_stride, uint32_t *work_counter, double *counts_all,
+                                                         double *lk_all, uint32_t lds_tmpl, uint32_t lds_read) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *ring = reinterpret_cast<double *>(smem);
+    double *part = ring + 9 * WP;  // [64][NCNT]
+    const uint32_t n_blk = ((lds_tmpl + lds_read) >> 6) + 4;
+    int *s_EF = reinterpret_cast<int *>(part + 64 * NCNT + 1);
+    int *s_EB = s_EF + n_blk;
+    uint16_t *s_c = reinterpret_cast<uint16_t *>(s_EB + n_blk);
+    uint8_t *s_x = reinterpret_cast<uint8_t *>(s_c + ((lds_tmpl + lds_read + 8) & ~7u));
+    uint8_t *s_y = s_x + ((lds_tmpl + 16) & ~15u);
+    const int lane = threadIdx.x;
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(work_counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_reads) break;
+        const ReadMeta rm = reads[item];
+        const ChunkMeta cm = chunks[rm.chunk];
+        const ChunkState st = state[rm.chunk];
+        double *out = counts_all + (uint64_t)item * NCNT;
+        if (st.status != 0) {
+            if (lane < NCNT) out[lane] = 0.0;
+            if (lane == 0) lk_all[item] = JTK_LOG_ZERO;
+            continue;
+        }
+        const int L = (int)st.tmpl_len, n = (int)rm.read_len, T = L + n, r = (int)cm.radius, W = 2 * r + 1;
+        const int NP = (W + 63) >> 6;
+        const HmmDev *h = hmm2 + (rm.strand ? 0 : 1);
+        const double aMM = h->a[0], aMI = h->a[1], aMD = h->a[2], aIM = h->a[3], aII = h->a[4], aID = h->a[5], aDM = h->a[6],
+                     aDI = h->a[7], aDD = h->a[8];
+        double *gM = scratch_all + (uint64_t)blockIdx.x * scratch_stride;  // F_M[t][w]
+        double *gI = gM + (uint64_t)(T + 1) * W, *gD = gI + (uint64_t)(T + 1) * W;
+        __syncthreads();
+        {
+            const uint8_t *gx = bufs.tmpl[st.buf] + cm.tmpl_off;
+            for (int p = lane; p < L; p += 64) s_x[p] = gx[p] & 3;
+            const uint8_t *gy = ey_all + rm.ey_off;
+            for (int p = lane; p < n; p += 64) s_y[p] = gy[p + 1] & 3;
+            const uint64_t *delta = delta_all + rm.delta_off;
+            if (lane == 0) {
+                uint32_t c = 0;
+                for (int t = 0; t <= T; t++) {
+                    if (t >= 1) c += (uint32_t)((delta[t >> 6] >> (t & 63)) & 1ull);
+                    s_c[t] = (uint16_t)c;
+                }
+            }
+            for (int e = lane; e < 64 * NCNT; e += 64) part[e] = 0.0;
+        }
+        __syncthreads();
+        auto eMv = [&](int i, int j) -> double { return h->eM[4 * s_x[i - 1] + s_y[j - 1]]; };
+        auto eIv = [&](int j) -> double { return h->eI[4 * (j >= 2 ? (int)s_y[j - 2] : 4) + s_y[j - 1]]; };
+        double *rM = ring, *rI = ring + 3 * WP, *rD = ring + 6 * WP;  // toM / toI / toD, then hatM / hatI / b_D: depth 3 each
+        auto getw = [&](const double *row, int tt, int i) -> double {
+            if (tt < 0 || tt > T) return 0.0;
+            const int w = i - ((int)s_c[tt] - r);
+            return (w < 0 || w >= W) ? 0.0 : row[w];
+        };
+        // =========================== forward ===========================
+        double endM = 0, endI = 0, endD = 0;
+        for (int t = 0; t <= T; t++) {
+            const int E2 = t >= 2 ? s_EF[(t - 2) >> 6] : 0, E1 = t >= 1 ? s_EF[(t - 1) >> 6] : 0;
+            const double s2 = (t >= 2 && E2 != E1) ? pow2i_w(E2 - E1) : 1.0;
+            const int lo = (int)s_c[t] - r;
+            double fm[4], fi[4], fd[4];
+            double m = 0.0;
+            for (int ps = 0; ps < NP; ps++) {
+                const int w = ps * 64 + lane, i = lo + w, j = t - i;
+                double a = 0.0, b = 0.0, c = 0.0;
+                if (w < W && i >= 0 && i <= L && j >= 0 && j <= n) {
+                    if (t == 0) {
+                        a = 1.0;
+                    } else {
+                        if (i >= 1 && j >= 1) a = eMv(i, j) * (getw(rM + ((t - 2 + 3) % 3) * WP, t - 2, i - 1) * s2);
+                        if (j >= 1) b = eIv(j) * getw(rI + ((t - 1) % 3) * WP, t - 1, i);
+                        if (i >= 1) c = getw(rD + ((t - 1) % 3) * WP, t - 1, i - 1);
+                    }
+                }
+                fm[ps] = a;
+                fi[ps] = b;
+                fd[ps] = c;
+                m = a > m ? a : m;
+                m = b > m ? b : m;
+                m = c > m ? c : m;
+            }
+            int E = E1;
+            if (t > 0 && (t & (JTK_SCALE_BLOCK - 1)) == 0) {
+                m = wave_max_w(m);
+                if (m > 0.0) {
+                    const int e = jtk_ilogb_pos(m);
+                    const double sc = pow2i_w(-e);
+                    for (int ps = 0; ps < NP; ps++) {
+                        fm[ps] *= sc;
+                        fi[ps] *= sc;
+                        fd[ps] *= sc;
+                    }
+                    E += e;
+                }
+            }
+            if (lane == 0 && (t & 63) == 0) s_EF[t >> 6] = E;
+            __syncthreads();
+            double *oM = rM + (t % 3) * WP, *oI = rI + (t % 3) * WP, *oD = rD + (t % 3) * WP;
+            for (int ps = 0; ps < NP; ps++) {
+                const int w = ps * 64 + lane;
+                if (w < W) {
+                    oM[w] = fma(fd[ps], aDM, fma(fi[ps], aIM, fm[ps] * aMM));
+                    oI[w] = fma(fd[ps], aDI, fma(fi[ps], aII, fm[ps] * aMI));
+                    oD[w] = fma(fd[ps], aDD, fma(fi[ps], aID, fm[ps] * aMD));
+                    gM[(uint64_t)t * W + w] = fm[ps];
+                    gI[(uint64_t)t * W + w] = fi[ps];
+                    gD[(uint64_t)t * W + w] = fd[ps];
+                    if (t == T && w == r) {
+                        endM = fm[ps];
+                        endI = fi[ps];
+                        endD = fd[ps];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        double tot = (endM + endI) + endD;
+        tot = __shfl(tot, r & 63, 64);
+        const int ET = s_EF[T >> 6];
+        const double lk = tot > 0.0 ? jtk_log(tot) + (double)ET * JTK_LN2 : JTK_LOG_ZERO;
+        if (lane == 0) lk_all[item] = lk;
+        if (!(tot > 0.0)) {
+            if (lane < NCNT) out[lane] = 0.0;
+            continue;
+        }
+        // =========================== backward + counts ===========================
+        for (int e = lane; e < 9 * WP; e += 64) ring[e] = 0.0;
+        __syncthreads();
+        const double inv = 1.0 / tot;
+        double *mine = part + lane * NCNT;
+        for (int t = T; t >= 0; t--) {
+            const int lo = (int)s_c[t] - r;
+            const int Ecur0 = t < T ? s_EB[(t + 1) >> 6] : 0;
+            const int E2 = t + 2 <= T ? s_EB[(t + 2) >> 6] : 0;
+            const double s2 = (t + 2 <= T && E2 != Ecur0) ? pow2i_w(E2 - Ecur0) : 1.0;
+            const int EFt = s_EF[t >> 6];
+            const double wt = pow2i_w(EFt + Ecur0 - ET) * inv;
+            double vm[4], vi[4], vd[4];
+            double m = 0.0;
+            for (int ps = 0; ps < NP; ps++) {
+                const int w = ps * 64 + lane, i = lo + w, j = t - i;
+                double a = 0.0, b = 0.0, c = 0.0;
+                if (w < W && i >= 0 && i <= L && j >= 0 && j <= n) {
+                    if (t == T) {
+                        a = b = c = 1.0;
+                    } else {
+                        const double xm = getw(rM + ((t + 2) % 3) * WP, t + 2, i + 1) * s2;
+                        const double xi = getw(rI + ((t + 1) % 3) * WP, t + 1, i);
+                        const double xd = getw(rD + ((t + 1) % 3) * WP, t + 1, i + 1);
+                        a = fma(aMD, xd, fma(aMI, xi, aMM * xm));
+                        b = fma(aID, xd, fma(aII, xi, aIM * xm));
+                        c = fma(aDD, xd, fma(aDI, xi, aDM * xm));
+                        const double fm = gM[(uint64_t)t * W + w], fi = gI[(uint64_t)t * W + w], fd = gD[(uint64_t)t * W + w];
+                        mine[0] += ((fm * aMM) * xm) * wt;
+                        mine[1] += ((fm * aMI) * xi) * wt;
+                        mine[2] += ((fm * aMD) * xd) * wt;
+                        mine[3] += ((fi * aIM) * xm) * wt;
+                        mine[4] += ((fi * aII) * xi) * wt;
+                        mine[5] += ((fi * aID) * xd) * wt;
+                        mine[6] += ((fd * aDM) * xm) * wt;
+                        mine[7] += ((fd * aDI) * xi) * wt;
+                        mine[8] += ((fd * aDD) * xd) * wt;
+                    }
+                }
+                vm[ps] = a;
+                vi[ps] = b;
+                vd[ps] = c;
+                m = a > m ? a : m;
+                m = b > m ? b : m;
+                m = c > m ? c : m;
+            }
+            int EB = Ecur0;
+            if (t < T && (t & (JTK_SCALE_BLOCK - 1)) == JTK_SCALE_BLOCK - 1) {
+                m = wave_max_w(m);
+                if (m > 0.0) {
+                    const int e = jtk_ilogb_pos(m);
+                    const double sc = pow2i_w(-e);
+                    for (int ps = 0; ps < NP; ps++) {
+                        vm[ps] *= sc;
+                        vi[ps] *= sc;
+                        vd[ps] *= sc;
+                    }
+                    EB += e;
+                }
+            }
+            if (lane == 0) s_EB[t >> 6] = EB;
+            const double we = pow2i_w(EFt + EB - ET) * inv;
+            __syncthreads();
+            double *oM = rM + (t % 3) * WP, *oI = rI + (t % 3) * WP, *oD = rD + (t % 3) * WP;
+            for (int ps = 0; ps < NP; ps++) {
+                const int w = ps * 64 + lane, i = lo + w, j = t - i;
+                if (w >= W) continue;
+                double a = 0.0, b = 0.0;
+                if (i >= 1 && i <= L && j >= 1 && j <= n) {
+                    a = eMv(i, j) * vm[ps];
+                    mine[9 + 4 * s_x[i - 1] + s_y[j - 1]] += (gM[(uint64_t)t * W + w] * vm[ps]) * we;
+                }
+                if (i >= 0 && i <= L && j >= 1 && j <= n) {
+                    const int ctx = j >= 2 ? (int)s_y[j - 2] : 4;
+                    b = eIv(j) * vi[ps];
+                    mine[25 + 4 * ctx + s_y[j - 1]] += (gI[(uint64_t)t * W + w] * vi[ps]) * we;
+                }
+                oM[w] = a;
+                oI[w] = b;
+                oD[w] = vd[ps];
+            }
+            __syncthreads();
+        }
+        if (lane < NCNT) {  // the 64 partial sums, in lane order
+            double sum = 0.0;
+            for (int l = 0; l < 64; l++) sum += part[l * NCNT + lane];
+            out[lane] = sum;
+        }
+    }
+}
+#undef NCNT
+
 }  // namespace
 
 size_t phmm_wide_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
@@ -345,4 +578,24 @@ void launch_phmm_wide(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, co
     const size_t lds = phmm_wide_lds_bytes(max_tmpl, max_read);
     phmm_wide_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch, scratch_stride,
                                               work_counter, raw, rawG, lk, max_tmpl, max_read, only_active);
+}
+
+size_t phmm_counts_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
+    const uint32_t n_blk = ((max_tmpl + max_read) >> 6) + 4;
+    size_t b = (size_t)9 * WP * 8 + (size_t)(64 * 45 + 1) * 8 + (size_t)n_blk * 8;
+    b += (size_t)((max_tmpl + max_read + 8) & ~7u) * 2 + ((max_tmpl + 16) & ~15u) + max_read + 16;
+    return (b + 15) & ~(size_t)15;
+}
+uint64_t phmm_counts_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius) {
+    return (uint64_t)3 * (max_tmpl + max_read + 2) * (2 * max_radius + 1);
+}
+void launch_phmm_counts(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
+                        const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
+                        double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *counts,
+                        double *lk, uint32_t max_tmpl, uint32_t max_read) {
+    if (n_reads == 0 || n_waves == 0) return;
+    hipMemsetAsync(work_counter, 0, sizeof(uint32_t), s);
+    const size_t lds = phmm_counts_lds_bytes(max_tmpl, max_read);
+    phmm_counts_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch, scratch_stride,
+                                                work_counter, counts, lk, max_tmpl, max_read);
 }

@@ -1238,8 +1238,10 @@ int jtk_lc_polish_chunks(const jtk_lc_params_t *params, size_t n_chunks, const j
         extra[c].take_num = take_num;
         ch[c].copy_num = 1;  // no clustering happens; keeps every posterior row a single entry
     }
+    jtk_lc_params_t pp = *params;
+    if (pp.gains.max_homopolymer_len == 0) pp.gains.max_homopolymer_len = 1;  // polishing does not use the gains
     jtk_lc_session_t *s = nullptr;
-    int rc = session_create_ex(params, n_chunks, ch.data(), tmpl_bases, read_bases, read_off, ops, ops_off, strand, 1, device,
+    int rc = session_create_ex(&pp, n_chunks, ch.data(), tmpl_bases, read_bases, read_off, ops, ops_off, strand, 1, device,
                                extra.data(), ignore_edge, &s);
     if (rc) return rc;
     std::unique_ptr<jtk_lc_session> guard(s);
@@ -1247,6 +1249,140 @@ int jtk_lc_polish_chunks(const jtk_lc_params_t *params, size_t n_chunks, const j
     s->resume_rng = false;
     if ((rc = run_batch(s, 0))) return rc;
     return jtk_lc_session_fetch(s, nullptr, nullptr, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap);
+}
+
+// ---- the model refit of the stage preamble (model_tune.rs:96-156) ------------------------------------------------------
+namespace {
+const int FIT_COUNTS = 45;  // 9 transitions (M,I,D x M,I,D), mat_emit[16], ins_emit[20]
+
+// M-step on summed counts: every row is divided by its sum; rows without mass keep the old values
+void fit_mstep(const jtk_hmm_t &old, const double *cnt, jtk_hmm_t &out) {
+    out = old;
+    double *tr[3] = {&out.mat_mat, &out.ins_mat, &out.del_mat};
+    for (int st = 0; st < 3; st++) {
+        const double sum = (cnt[3 * st] + cnt[3 * st + 1]) + cnt[3 * st + 2];
+        if (sum > 0.0)
+            for (int q = 0; q < 3; q++) tr[st][q] = cnt[3 * st + q] / sum;
+    }
+    for (int x = 0; x < 4; x++) {
+        const double *e = cnt + 9 + 4 * x;
+        const double sum = ((e[0] + e[1]) + e[2]) + e[3];
+        if (sum > 0.0)
+            for (int q = 0; q < 4; q++) out.mat_emit[4 * x + q] = e[q] / sum;
+    }
+    for (int cx = 0; cx < 5; cx++) {
+        const double *e = cnt + 25 + 4 * cx;
+        const double sum = ((e[0] + e[1]) + e[2]) + e[3];
+        if (sum > 0.0)
+            for (int q = 0; q < 4; q++) out.ins_emit[4 * cx + q] = e[q] / sum;
+    }
+}
+}  // namespace
+
+// `rounds` x [ polish every training pile-up with HMMPolishConfig::new(band / 2, N, 0) (model_tune.rs:137-143), then one
+// Baum-Welch step on all of them with the LARGEST band (fit_antidiagonal_par_multiple(&packs, bw / 2), :136,:144-151) ].
+// Polishing and the expected counts run on the device; the M-step is a few dozen divisions on the host.
+int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks, const uint8_t *tmpl_bases,
+                     const uint8_t *read_bases, const uint64_t *read_off, const uint8_t *ops, const uint64_t *ops_off,
+                     const uint8_t *strand, uint32_t rounds, jtk_hmm_t *forward_out, jtk_hmm_t *reverse_out, int device) {
+    g_last_error.clear();
+    if (!params || !forward_out || !reverse_out || !chunks || !read_off || !ops_off || !strand)
+        return fail(JTK_ERR_INVALID_ARG, "null argument");
+    size_t n_reads = 0, tmpl_total = 0;
+    uint32_t max_bw = 0;
+    for (size_t c = 0; c < n_chunks; c++) {
+        n_reads += chunks[c].n_reads;
+        tmpl_total += (size_t)chunks[c].tmpl_len;
+        max_bw = std::max<uint32_t>(max_bw, (uint32_t)std::ceil((double)chunks[c].tmpl_len * params->band_frac));
+    }
+    if (n_chunks == 0 || n_reads == 0) return fail(JTK_ERR_INVALID_ARG, "no training pile-up");  // assert!, model_tune.rs:135
+    if (max_bw / 2 > JTK_WIDE_MAX_RADIUS) return fail(JTK_ERR_UNSUPPORTED, "band radius > 127");
+    jtk_lc_params_t cur = *params;
+    if (cur.gains.max_homopolymer_len == 0) cur.gains.max_homopolymer_len = 1;  // the gains play no part in the refit
+    // working copies: consensus and ops change from round to round; band_width stays that of the unpolished chunk (:123)
+    std::vector<jtk_lc_chunk_t> ch(chunks, chunks + n_chunks);
+    std::vector<uint8_t> cons(2 * tmpl_total + 64 * n_chunks + 64), cops(2 * (size_t)ops_off[n_reads] + 64 * n_reads + 64);
+    std::vector<uint64_t> coff(n_chunks + 1), ooff(ops_off, ops_off + n_reads + 1);
+    std::vector<ChunkExtra> extra(n_chunks);
+    memcpy(cops.data(), ops, (size_t)ops_off[n_reads]);
+    uint64_t o = 0;
+    for (size_t c = 0; c < n_chunks; c++) {
+        coff[c] = o;
+        memcpy(cons.data() + o, tmpl_bases + chunks[c].tmpl_off, (size_t)chunks[c].tmpl_len);
+        o += chunks[c].tmpl_len;
+        memset(&extra[c], 0, sizeof extra[c]);
+        extra[c].radius = (uint32_t)std::ceil((double)chunks[c].tmpl_len * params->band_frac) / 2;
+        ch[c].copy_num = 1;
+    }
+    coff[n_chunks] = o;
+    std::vector<uint8_t> cons2(cons.size()), cops2(cops.size());
+    std::vector<uint64_t> coff2(n_chunks + 1), ooff2(n_reads + 1);
+    std::vector<jtk_lc_result_t> res(n_chunks);
+    std::vector<double> counts((size_t)n_reads * FIT_COUNTS), lks(n_reads);
+    for (uint32_t round = 0; round < rounds; round++) {
+        for (size_t c = 0; c < n_chunks; c++) {
+            ch[c].tmpl_off = coff[c];
+            ch[c].tmpl_len = coff[c + 1] - coff[c];
+        }
+        jtk_lc_session_t *s = nullptr;
+        int rc = session_create_ex(&cur, n_chunks, ch.data(), cons.data(), read_bases, read_off, cops.data(), ooff.data(), strand,
+                                   1, device, extra.data(), 0 /* ignore_edge, model_tune.rs:140 */, &s);
+        if (rc) return rc;
+        std::unique_ptr<jtk_lc_session> guard(s);
+        s->polish_only = true;
+        s->resume_rng = false;
+        if ((rc = run_batch(s, 0))) return rc;
+        rc = jtk_lc_session_fetch(s, nullptr, nullptr, res.data(), cons2.data(), coff2.data(), cons2.size(), cops2.data(),
+                                  ooff2.data(), cops2.size());
+        if (rc) return rc;  // a training pile-up that fails fails the fit (the reference would panic)
+        // ---- E-step on the polished pile-ups, every read with the largest band's radius
+        {
+            std::vector<ChunkMeta> wide(s->h_chunks);
+            for (auto &cm : wide) {
+                cm.radius = max_bw / 2;
+                cm.take_num = 0;
+            }
+            DevPtr d_wide, d_counts, d_lk, d_scratch, d_counter;
+            if ((rc = dev_upload(s, d_wide, wide))) return rc;
+            if ((rc = dev_alloc<double>(d_counts, (size_t)n_reads * FIT_COUNTS))) return rc;
+            if ((rc = dev_alloc<double>(d_lk, n_reads))) return rc;
+            if ((rc = dev_alloc<uint32_t>(d_counter, 4))) return rc;
+            const size_t lds = phmm_counts_lds_bytes(s->max_tmpl, s->max_read);
+            if (lds > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "template + read too long for the LDS staging of phmm_counts_kernel");
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, device));
+            const uint64_t stride = phmm_counts_scratch_doubles(s->max_tmpl, s->max_read, max_bw / 2);
+            uint64_t waves = std::min<uint64_t>(n_reads, (uint64_t)prop.multiProcessorCount * 2);
+            waves = std::max<uint64_t>(1, std::min<uint64_t>(waves, (32ull << 30) / (stride * 8)));
+            if ((rc = dev_alloc<double>(d_scratch, stride * waves))) return rc;
+            launch_phmm_counts(s->stream, s->n_reads, s->d_reads.as<ReadMeta>(), d_wide.as<ChunkMeta>(),
+                               s->d_state.as<ChunkState>(), s->bufs, s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(),
+                               s->d_hmm2.as<HmmDev>(), d_scratch.as<double>(), stride, (uint32_t)waves,
+                               d_counter.as<uint32_t>(), d_counts.as<double>(), d_lk.as<double>(), s->max_tmpl, s->max_read);
+            HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * 8, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(lks.data(), d_lk.p, lks.size() * 8, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            HIP_TRY(hipGetLastError());
+        }
+        double sum[2][FIT_COUNTS];
+        memset(sum, 0, sizeof sum);
+        for (size_t g = 0; g < n_reads; g++) {  // reads in order, as the oracle adds them
+            const int st = strand[g] ? 0 : 1;
+            for (int k = 0; k < FIT_COUNTS; k++) sum[st][k] += counts[g * FIT_COUNTS + k];
+        }
+        jtk_hmm_t nf, nr;
+        fit_mstep(cur.forward, sum[0], nf);
+        fit_mstep(cur.reverse, sum[1], nr);
+        cur.forward = nf;
+        cur.reverse = nr;
+        cons.swap(cons2);
+        cops.swap(cops2);
+        coff.swap(coff2);
+        ooff.swap(ooff2);
+    }
+    *forward_out = cur.forward;
+    *reverse_out = cur.reverse;
+    return 0;
 }
 
 int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl, uint64_t tmpl_len,

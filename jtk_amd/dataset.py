@@ -16,9 +16,9 @@ Wire format of the fields the stage reads or writes (serde derives of definition
   encoded_reads    [{.., "nodes": [{"position_from_start", "chunk", "cluster", "seq": "ACGT..", "is_forward",
                    "cigar": "10M2D3I", "posterior": [f64]}]}]                          (:672-683, Ops as a string :825-877)
 
-One preamble is NOT run here: `update_models_on_both_strands` (mod.rs:58, model_tune.rs:96-156) needs kiley's
-Baum-Welch; `model_param` is used as found in the file.  The gains calibration (mod.rs:60) runs on the device
-(`jtk_lc_estimate_gains`).  This is the same host logic as the C++ mirror `csrc/host/local_clustering.hpp`; the two
+Both preambles run on the device: `update_models_on_both_strands` (mod.rs:58, model_tune.rs:96-156: training pile-ups
+picked here, ten rounds of polish + Baum-Welch in `jtk_lc_fit_model`; `--no-refit` keeps `model_param` as found in the
+file) and the gains calibration (mod.rs:60, `jtk_lc_estimate_gains`).  This is the same host logic as the C++ mirror `csrc/host/local_clustering.hpp`; the two
 are tested against each other (tests/test_dataset_json.py)."""
 import argparse
 import ctypes as C
@@ -165,6 +165,37 @@ def _seq(s):
     return np.frombuffer(s.encode("ascii"), dtype=np.uint8)
 
 
+def update_models_on_both_strands(ds, device=0):
+    """ModelFit::update_models_on_both_strands (model_tune.rs:20-25, :96-156): pick the training pile-ups (:99-118) and
+    refit the model on both strands with jtk_lc_fit_model (TRAIN_ROUND = 10)."""
+    piles = {c["id"]: [] for c in ds["selected_chunks"]}
+    chunk_of = {c["id"]: c for c in ds["selected_chunks"]}
+    for read in ds["encoded_reads"]:
+        for node in read["nodes"]:
+            piles.setdefault(node["chunk"], []).append(node)
+    if not piles:
+        raise ValueError("update_models_on_both_strands: no pile-up")
+    covs = sorted(len(v) for v in piles.values())
+    cov = covs[len(covs) // 2]                                       # select_nth_unstable(len / 2)
+    ids = sorted(cid for cid, v in piles.items() if max(cov, 2) - 2 <= len(v) < cov + 2 and cid in chunk_of)[:5]
+    pile = [(cid, int(chunk_of[cid]["copy_num"]), _seq(chunk_of[cid]["seq"]), [_seq(n["seq"]) for n in piles[cid]],
+             [cigar_to_ops(n["cigar"]) for n in piles[cid]], [1 if n["is_forward"] else 0 for n in piles[cid]], None)
+            for cid in ids]
+    if not pile or not any(p[3] for p in pile):
+        raise ValueError("update_models_on_both_strands: no training pile-up")     # assert!, model_tune.rs:135
+    params = ffi.Params()
+    params.forward = _hmm(ds["model_param"]["forward"])
+    params.reverse = _hmm(ds["model_param"]["reverse"])
+    params.band_frac = BAND_FRAC[ds["read_type"]]
+    f, r = api.fit_model(params, pack(pile), rounds=10, device=device)
+    for name, h in (("forward", f), ("reverse", r)):
+        d = {k: float(getattr(h, k)) for k in ("mat_mat", "mat_ins", "mat_del", "ins_mat", "ins_ins", "ins_del", "del_mat",
+                                               "del_ins", "del_del")}
+        d["mat_emit"] = [float(v) for v in h.mat_emit]
+        d["ins_emit"] = [float(v) for v in h.ins_emit]
+        ds["model_param"][name] = d
+
+
 def normalize_local_clustering(ds):
     """normalize.rs:6-51 over every node of the dataset: clusters relabelled by descending size, posteriors permuted."""
     L = ffi.lib()
@@ -189,7 +220,7 @@ def normalize_local_clustering(ds):
             n["posterior"] = post[i].tolist()
 
 
-def local_clustering_selected(ds, selection, gains=None, device=0, failed=None):
+def local_clustering_selected(ds, selection, gains=None, device=0, failed=None, refit=True):
     """mod.rs:56-83 on the parsed JSON object `ds` (modified in place).
 
     The reference panics when a chunk hits one of its asserts; here such a chunk (and a chunk of a shape this build does
@@ -198,8 +229,10 @@ def local_clustering_selected(ds, selection, gains=None, device=0, failed=None):
     raises like the reference, before touching `ds`."""
     validate(ds)
     update_coverage(ds)                                                       # mod.rs:57
+    if refit:
+        update_models_on_both_strands(ds, device=device)                      # mod.rs:58
     params = ffi.Params()
-    params.forward = _hmm(ds["model_param"]["forward"])                       # mod.rs:59 (no refit, see module doc)
+    params.forward = _hmm(ds["model_param"]["forward"])                       # mod.rs:59
     params.reverse = _hmm(ds["model_param"]["reverse"])
     params.gains = gains if gains is not None else api.estimate_gains(params.forward, params.reverse, device=device)
     params.haploid_coverage = coverage_of(ds)[1]
@@ -245,11 +278,11 @@ def local_clustering_selected(ds, selection, gains=None, device=0, failed=None):
     return ds
 
 
-def local_clustering(ds, gains=None, device=0, failed=None):
+def local_clustering(ds, gains=None, device=0, failed=None, refit=True):
     """mod.rs:23-26: every selected chunk."""
     validate(ds)
     return local_clustering_selected(ds, [c["id"] for c in ds["selected_chunks"]], gains=gains, device=device,
-                                     failed=failed)
+                                     failed=failed, refit=refit)
 
 
 def main(argv=None):
@@ -258,6 +291,8 @@ def main(argv=None):
     ap.add_argument("output", help="DataSet JSON ('-' = stdout)")
     ap.add_argument("--chunks", default="", help="comma-separated chunk ids (local_clustering_selected); default: all")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--no-refit", action="store_true",
+                    help="skip update_models_on_both_strands (mod.rs:58): cluster with model_param as found in the file")
     ap.add_argument("--keep-going", action="store_true",
                     help="a chunk that fails (where the reference would panic, or an unsupported shape) is left untouched "
                          "and listed on stderr instead of aborting the stage")
@@ -265,9 +300,10 @@ def main(argv=None):
     ds = json.load(sys.stdin if args.input == "-" else open(args.input))
     failed = [] if args.keep_going else None
     if args.chunks:
-        local_clustering_selected(ds, [int(x) for x in args.chunks.split(",")], device=args.device, failed=failed)
+        local_clustering_selected(ds, [int(x) for x in args.chunks.split(",")], device=args.device, failed=failed,
+                                  refit=not args.no_refit)
     else:
-        local_clustering(ds, device=args.device, failed=failed)
+        local_clustering(ds, device=args.device, failed=failed, refit=not args.no_refit)
     for cid, status in failed or []:
         sys.stderr.write(f"LC\tFAILED\t{cid}\t{status}\t{ffi.lib().jtk_lc_strerror(status).decode()}\n")
     api.trim_cache(args.device)

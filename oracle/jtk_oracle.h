@@ -157,6 +157,15 @@ void jo_generate_seq(jo_rng_t *rng, size_t len, uint8_t *out);
 size_t jo_phmm_gen(const jtk_hmm_t *hmm, const uint8_t *tmpl, size_t tl, jo_rng_t *rng, uint8_t *out,
                    size_t cap);
 
+/* ---------------- model_fit.c: model_tune.rs:96-156 (driver in tree; the Baum-Welch step is OWN SPEC, kiley absent) ---- */
+#define JTK_FIT_COUNTS 45 /* 9 transitions (row-major M,I,D x M,I,D) + mat_emit[16] + ins_emit[20] */
+double jo_phmm_counts(const jtk_hmm_t *hmm, const uint8_t *tmpl, size_t tl, const uint8_t *read, size_t rl,
+                      const uint8_t *ops, size_t n_ops, size_t radius, double *counts);
+void jo_fit_mstep(const jtk_hmm_t *old, const double *counts, jtk_hmm_t *out);
+int jo_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks, const uint8_t *tmpl_bases,
+                 const uint8_t *read_bases, const uint64_t *read_off, const uint8_t *ops, const uint64_t *ops_off,
+                 const uint8_t *strand, uint32_t rounds, jtk_hmm_t *fwd_out, jtk_hmm_t *rev_out);
+
 /* ---------------- local_clustering.c: mod.rs ------------------------------------------------------- */
 typedef struct jo_chunk_result {
     double score;

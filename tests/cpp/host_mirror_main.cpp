@@ -19,7 +19,7 @@ static std::string cigar_string(const jtk::Ops &ops) {  // Display for Ops, defi
 
 int main(int argc, char **argv) {
     if (argc < 6) {
-        fprintf(stderr, "usage: %s n_chunks tmpl_len reads_per_hap gains_file(18 doubles; '-' = estimate on the device) n_selected\n", argv[0]);
+        fprintf(stderr, "usage: %s n_chunks tmpl_len reads_per_hap gains_file(18 doubles; '-' = estimate on the device) n_selected [refit]\n", argv[0]);
         return 2;
     }
     const int n_chunks = atoi(argv[1]), tmpl_len = atoi(argv[2]), rph = atoi(argv[3]), n_selected = atoi(argv[5]);
@@ -84,6 +84,7 @@ int main(int argc, char **argv) {
     }
     jtk::LocalClusteringOptions opt;
     opt.gains = device_gains ? nullptr : &gains;
+    opt.refit_model = argc > 6 && atoi(argv[6]) != 0;  // update_models_on_both_strands (mod.rs:58)
     try {
         if (n_selected >= n_chunks) {
             jtk::local_clustering(ds, opt);

@@ -172,6 +172,10 @@ def lib():
     sig("jo_cluster_chunks", C.c_int, C.POINTER(Params), sz, p, PU8, PU8, C.POINTER(u64), PU8,
         C.POINTER(u64), PU8, C.c_int, C.POINTER(u32), PD, u32, p, PU8, C.POINTER(u64), u64, PU8,
         C.POINTER(u64), u64, C.c_int, PD)
+    sig("jo_phmm_counts", d, C.POINTER(Hmm), PU8, sz, PU8, sz, PU8, sz, sz, PD)
+    sig("jo_fit_mstep", None, C.POINTER(Hmm), PD, C.POINTER(Hmm))
+    sig("jo_fit_model", C.c_int, C.POINTER(Params), sz, p, PU8, PU8, C.POINTER(u64), PU8, C.POINTER(u64), PU8, u32,
+        C.POINTER(Hmm), C.POINTER(Hmm))
     sig("jo_polish_chunks", C.c_int, C.POINTER(Params), sz, p, PU8, PU8, C.POINTER(u64), PU8, C.POINTER(u64), PU8, u32, u32,
         u32, PU8, C.POINTER(u64), PU8, C.POINTER(u64), p, C.c_int)
     sig("jo_cluster_features", C.c_int, C.POINTER(Params), sz, p, PD, C.POINTER(u32), C.POINTER(u32), PD,
@@ -253,3 +257,12 @@ def polish_chunks(params, batch, radius=0, take_num=0, ignore_edge=0, n_threads=
                             ignore_edge, u8p(cons), u64p(cons_off), u8p(ops_out), u64p(ops_out_off), result.ctypes.data,
                             n_threads)
     return dict(rc=rc, result=result, cons=cons, cons_off=cons_off, ops_out=ops_out, ops_out_off=ops_out_off)
+
+
+def fit_model(params, batch, rounds=10):
+    """jo_fit_model: estimate_model_parameters_on_both_strands (model_tune.rs:119-152) on the training pile-ups of `batch`."""
+    f, r = Hmm(), Hmm()
+    rc = lib().jo_fit_model(C.byref(params), len(batch.chunks), batch.chunks.ctypes.data, u8p(batch.tmpl_bases),
+                            u8p(batch.read_bases), u64p(batch.read_off), u8p(batch.ops), u64p(batch.ops_off), u8p(batch.strand),
+                            rounds, C.byref(f), C.byref(r))
+    return rc, f, r

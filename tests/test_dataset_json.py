@@ -119,18 +119,20 @@ def test_untouched_fields_survive_the_json_round_trip(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_selected", [3, 2])
-def test_json_stage_matches_the_cpp_host_mirror(jtk_lib, tmp_path, n_selected):
+@pytest.mark.parametrize("n_selected,refit", [(3, False), (2, False), (3, True)])
+def test_json_stage_matches_the_cpp_host_mirror(jtk_lib, tmp_path, n_selected, refit):
     assert jtk_lib.jtk_lc_device_ok(0) == 1
     n_chunks, tmpl_len, rph = 3, 400, 8
     ds = synthetic_dataset(n_chunks, tmpl_len, rph)
     src, dst = tmp_path / "in.json", tmp_path / "out.json"
     src.write_text(json.dumps(ds))
     argv = [str(src), str(dst)] + (["--chunks", ",".join(str(c) for c in range(n_selected))] if n_selected < n_chunks else [])
+    argv += [] if refit else ["--no-refit"]           # refit: update_models_on_both_strands on the device (mod.rs:58)
     D.main(argv)                                      # gains: estimate_gain_default on the device (mod.rs:60)
     out = json.loads(dst.read_text())
     exe = HM.build_driver()
-    ref = subprocess.run([exe, str(n_chunks), str(tmpl_len), str(rph), "-", str(n_selected)], capture_output=True, text=True)
+    ref = subprocess.run([exe, str(n_chunks), str(tmpl_len), str(rph), "-", str(n_selected), "1" if refit else "0"],
+                         capture_output=True, text=True)
     assert ref.returncode == 0, ref.stderr
     chunks, nodes = {}, {}
     for line in ref.stdout.splitlines():
@@ -147,6 +149,11 @@ def test_json_stage_matches_the_cpp_host_mirror(jtk_lib, tmp_path, n_selected):
             cl, cig, ps = nodes[(r, node["chunk"])]
             assert (node["cluster"], node["cigar"]) == (cl, cig) and node["posterior"] == ps
     # everything the stage does not own is passed through
-    for key in ("input_file", "masked_kmers", "raw_reads", "hic_pairs", "hic_edges", "read_type", "model_param",
-                "error_rate", "processed_stages", "coverage"):
+    for key in ("input_file", "masked_kmers", "raw_reads", "hic_pairs", "hic_edges", "read_type", "error_rate",
+                "processed_stages", "coverage"):
         assert out[key] == ds[key]
+    # the stage overwrites model_param with the refitted model (model_tune.rs:20-25); without the refit it is passed through
+    assert (out["model_param"] == ds["model_param"]) == (not refit)
+    if refit:
+        f = out["model_param"]["forward"]
+        assert abs(f["mat_mat"] + f["mat_ins"] + f["mat_del"] - 1.0) < 1e-12 and len(f["ins_emit"]) == 20

@@ -269,3 +269,26 @@ def test_band_wider_than_the_fallback_kernel_is_reported(lib):
     p.band_frac = 0.26                                   # radius 130 > 127
     out = api.cluster_chunks(p, b, raise_on_chunk_failure=False)
     assert out["rc"] == -6 and (out["result"]["status"] == -3).all()
+
+
+# ---- the stage's model refit (model_tune.rs:96-156): polish + Baum-Welch rounds on the device
+
+@pytest.mark.parametrize("config,rounds", [("ont_noisy", 3), ("ont_diploid", 2)])
+def test_model_refit_matches_oracle(lib, config, rounds):
+    """jtk_lc_fit_model against oracle/model_fit.c: every parameter of both strands' models bit for bit, after rounds of
+    [polish with (band / 2, N, 0), one Baum-Welch step with the largest band]; two pile-ups of different length, so the
+    fit's radius differs from one pile-up's polishing radius"""
+    piles = []
+    for cid, L in [(300, 500), (301, 640)]:
+        cfg = dict(synth.CONFIGS[config])
+        cfg.update(tmpl_len=L, reads_per_hap=6)
+        piles.append(synth.make_pileup(cid, cfg))
+    b = jb.pack(piles)
+    p = jb.default_params(haploid_coverage=6.0, band_frac=0.03)
+    p.reverse.mat_mat, p.reverse.mat_del = 0.96, 0.02          # the two strands start from different models
+    rc, of, orv = O.fit_model(helpers.oracle_params(p), b, rounds=rounds)
+    assert rc == 0
+    df, dr = api.fit_model(p, b, rounds=rounds)
+    assert bytes(df) == bytes(of) and bytes(dr) == bytes(orv)
+    assert abs(df.mat_mat + df.mat_ins + df.mat_del - 1.0) < 1e-12
+    assert bytes(df) != bytes(p.forward)
