@@ -230,6 +230,38 @@ int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_l
                      const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t rounds,
                      jtk_hmm_t *forward_out, jtk_hmm_t *reverse_out, int device);
 
+/* ---- the first consumer of the stage's posteriors: cross-chunk correction ------------------------------------
+ * Replaces `AlignmentCorrection::correct_clustering_selected` (haplotyper/src/phmm_likelihood_correction.rs:32-97): per
+ * selected chunk with more than one cluster, a read-by-read similarity matrix from a 3-state affine-gap alignment of the
+ * neighbouring nodes' posteriors (`alignment` :475-490, `align_swg` :493-542, `sim` :545-561; on the device), then spectral
+ * clustering on the host (graph Laplacian :395-412, eigenvectors below 0.2 :415-473, 20 x misc::kmeans :295-302), the
+ * adjusted Rand index against the previous labels (:222-243), suppression of the lowest 5 % (:100-105) unless the chunk's
+ * local-clustering score protects it (:108-127).
+ * The data set reaches the call flattened: read r owns nodes node_off[r] .. node_off[r+1] (in read order), node e has
+ * post_len log-posteriors at posteriors[post_off].  chunks[] is DataSet.selected_chunks (cluster_num is updated in place).
+ * min_gain is `estimate_minimum_gain(&hmm) * PROTECT_FACTOR` (:118): a simulation through kiley that the caller runs.
+ * Output: cluster_out[e] = Node.cluster after the call, touched[e] = 1 where the reference rewrites the node; its posterior
+ * then is -10000 everywhere except 0 at the new cluster, with the chunk's NEW cluster_num entries (:88-93).
+ * Returns JTK_ERR_CHUNK_FAILED where the reference panics (a pile-up smaller than 4 x copy_num :348+:361, no eigenvalue
+ * below the threshold :455, posterior lengths that differ from cluster_num :547, ...); nothing is written then. */
+typedef struct jtk_cc_node {
+    uint64_t chunk;      /* Node.chunk                 (definitions/src/lib.rs:672-683) */
+    uint64_t cluster;    /* Node.cluster                */
+    uint32_t is_forward; /* Node.is_forward             */
+    uint32_t post_len;   /* Node.posterior.len()        */
+    uint64_t post_off;   /* into `posteriors`           */
+} jtk_cc_node_t;
+typedef struct jtk_cc_chunk {
+    uint64_t id;          /* Chunk.id                   (definitions/src/lib.rs:403-415) */
+    uint32_t cluster_num; /* Chunk.cluster_num (in / out) */
+    uint32_t copy_num;    /* Chunk.copy_num             */
+    double score;         /* Chunk.score                */
+} jtk_cc_chunk_t;
+int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id, const uint64_t *node_off, const jtk_cc_node_t *nodes,
+                              const double *posteriors, size_t n_chunks, jtk_cc_chunk_t *chunks, size_t n_selected,
+                              const uint64_t *selection, double haploid_coverage, double min_gain, uint64_t *cluster_out,
+                              uint8_t *touched, int device);
+
 /* Sort key of pileup_nodes (mod.rs:47-50): number of alignment columns that are not '|' in
  * Node::recover (definitions/src/lib.rs:773-813) for run-length cigar ops given per base. */
 int jtk_lc_pileup_sort_key(const uint8_t *tmpl, uint64_t tmpl_len, const uint8_t *read, uint64_t read_len,

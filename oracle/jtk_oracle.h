@@ -35,9 +35,11 @@ extern "C" {
 typedef struct jo_rng {
     uint64_t s[4];
     uint64_t draws; /* number of next_u64 calls so far (test aid) */
+    uint64_t kind;  /* 0 = Xoshiro256StarStar (the clustering stage), 1 = Xoroshiro128PlusPlus (correct_clustering) */
 } jo_rng_t;
 uint64_t jo_splitmix64_next(uint64_t *x);
 void jo_rng_seed_from_u64(jo_rng_t *rng, uint64_t seed);
+void jo_rng128pp_seed_from_u64(jo_rng_t *rng, uint64_t seed); /* Xoroshiro128PlusPlus::seed_from_u64 */
 uint64_t jo_rng_next_u64(jo_rng_t *rng);
 uint32_t jo_rng_next_u32(jo_rng_t *rng);
 uint64_t jo_gen_range_usize(jo_rng_t *rng, uint64_t n); /* rng.gen_range(0..n), n: usize  */
@@ -165,6 +167,14 @@ void jo_fit_mstep(const jtk_hmm_t *old, const double *counts, jtk_hmm_t *out);
 int jo_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks, const uint8_t *tmpl_bases,
                  const uint8_t *read_bases, const uint64_t *read_off, const uint8_t *ops, const uint64_t *ops_off,
                  const uint8_t *strand, uint32_t rounds, jtk_hmm_t *fwd_out, jtk_hmm_t *rev_out);
+
+/* ---------------- correction.c: phmm_likelihood_correction.rs:32-97 ------------------------------------------------ */
+/* ari_out[n_chunks] (optional): the adjusted Rand index of every corrected chunk; sims_first (optional): the similarity
+ * matrix of the first corrected chunk, members in correct_chunk's order (test aids) */
+int jo_correct_clustering(size_t n_reads, const uint64_t *read_id, const uint64_t *node_off, const jtk_cc_node_t *nodes,
+                          const double *posteriors, size_t n_chunks, jtk_cc_chunk_t *chunks, size_t n_selected,
+                          const uint64_t *selection, double haploid_coverage, double min_gain, uint64_t *cluster_out,
+                          uint8_t *touched, double *ari_out, double *sims_first);
 
 /* ---------------- local_clustering.c: mod.rs ------------------------------------------------------- */
 typedef struct jo_chunk_result {

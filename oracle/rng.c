@@ -25,6 +25,20 @@ void jo_rng_seed_from_u64(jo_rng_t *rng, uint64_t seed) {
     uint64_t x = seed;
     for (int i = 0; i < 4; i++) rng->s[i] = jo_splitmix64_next(&x);
     rng->draws = 0;
+    rng->kind = 0;
+}
+
+/* rand_xoshiro 0.6.0 Xoroshiro128PlusPlus (phmm_likelihood_correction.rs:295-296): seed_from_u64 fills the two state words
+ * from SplitMix64 like every generator of the crate; next_u64 = rotl(s0 + s1, 17) + s0, then s1 ^= s0,
+ * s0 = rotl(s0, 49) ^ s1 ^ (s1 << 21), s1 = rotl(s1, 28); next_u32 = the LOW half of next_u64 (recalled from the crate's
+ * source, which is not under /root/reference: unpinned). */
+void jo_rng128pp_seed_from_u64(jo_rng_t *rng, uint64_t seed) {
+    uint64_t x = seed;
+    rng->s[0] = jo_splitmix64_next(&x);
+    rng->s[1] = jo_splitmix64_next(&x);
+    rng->s[2] = rng->s[3] = 0;
+    rng->draws = 0;
+    rng->kind = 1;
 }
 
 static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
@@ -32,6 +46,16 @@ static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 -
 /* Xoshiro256StarStar::next_u64 */
 uint64_t jo_rng_next_u64(jo_rng_t *rng) {
     uint64_t *s = rng->s;
+    if (rng->kind == 1) {
+        const uint64_t s0 = s[0];
+        uint64_t s1 = s[1];
+        const uint64_t r = rotl64(s0 + s1, 17) + s0;
+        s1 ^= s0;
+        s[0] = rotl64(s0, 49) ^ s1 ^ (s1 << 21);
+        s[1] = rotl64(s1, 28);
+        rng->draws++;
+        return r;
+    }
     uint64_t result = rotl64(s[1] * 5, 7) * 9;
     uint64_t t = s[1] << 17;
     s[2] ^= s[0];
@@ -45,7 +69,10 @@ uint64_t jo_rng_next_u64(jo_rng_t *rng) {
 }
 
 /* Xoshiro256StarStar::next_u32: the upper half of next_u64 */
-uint32_t jo_rng_next_u32(jo_rng_t *rng) { return (uint32_t)(jo_rng_next_u64(rng) >> 32); }
+uint32_t jo_rng_next_u32(jo_rng_t *rng) {
+    if (rng->kind == 1) return (uint32_t)jo_rng_next_u64(rng);
+    return (uint32_t)(jo_rng_next_u64(rng) >> 32);
+}
 
 /* UniformInt<usize>::sample_single_inclusive(0, n-1) on a 64-bit target (rand 0.8.5
  * distributions/uniform.rs): zone = (range << lzcnt(range)) - 1; widening multiply rejection. */

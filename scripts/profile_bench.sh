@@ -1,16 +1,23 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): rocprofv3 kernel stats + HBM-traffic counters for the bench command.
-# Summaries land in gpurun_out/prof_*; copy what should be judged into profiles/.
+# Runs on the GPU box (via gpurun): rocprofv3 kernel stats + HBM-traffic counters for a bench command.
+# Summaries land in gpurun_out/prof_*; scripts/summarize_prof.py condenses them for profiles/.
+# usage: profile_bench.sh [tag] [bench args...]      (default: the default bench command, serial slices)
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
+TAG=${1:-r02}
+shift || true
+ARGS="${@:---steps 2 --warmup 1 --no-cpu-baseline --no-e2e}"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $REPO/bench.py --steps 16 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $CMD > $OUT/prof_stats.log 2>&1
+rm -rf $OUT/prof_stats_$TAG $OUT/prof_fetch_$TAG $OUT/prof_write_$TAG
+echo "python3 bench.py $ARGS" > $OUT/prof_cmd_$TAG.txt
+sha256sum $REPO/jtk_amd/_build/libjtk_lc.so | cut -c1-16 > $OUT/prof_libsha_$TAG.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_$TAG -- python3 $REPO/bench.py $ARGS > $OUT/prof_stats_$TAG.log 2>&1
 echo "stats rc=$?"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- $CMD > $OUT/prof_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch_$TAG -- python3 $REPO/bench.py $ARGS > $OUT/prof_fetch_$TAG.log 2>&1
 echo "fetch rc=$?"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- $CMD > $OUT/prof_write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$TAG -- python3 $REPO/bench.py $ARGS > $OUT/prof_write_$TAG.log 2>&1
 echo "write rc=$?"
-find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -name "*.csv" | head -20
+cd $REPO && python3 scripts/summarize_prof.py $OUT $TAG > $OUT/prof_summary_$TAG.txt 2>&1
+tail -5 $OUT/prof_summary_$TAG.txt

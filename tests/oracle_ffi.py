@@ -55,7 +55,7 @@ class FeatureChunk(C.Structure):
 
 
 class Rng(C.Structure):
-    _fields_ = [("s", C.c_uint64 * 4), ("draws", C.c_uint64)]
+    _fields_ = [("s", C.c_uint64 * 4), ("draws", C.c_uint64), ("kind", C.c_uint64)]
 
 
 class ClusterConfig(C.Structure):
