@@ -104,6 +104,25 @@ def fit_model(params, batch, rounds=10, device=0):
     return f, r
 
 
+def correct_clustering(read_id, node_off, nodes, posteriors, chunks, selection, haploid_coverage, min_gain, device=0):
+    """jtk_lc_correct_clustering: AlignmentCorrection::correct_clustering_selected (phmm_likelihood_correction.rs:32-97).
+    `nodes` (ffi.CC_NODE_DT) are the reads' nodes flattened by `node_off`; `chunks` (ffi.CC_CHUNK_DT) is updated in place
+    (cluster_num).  Returns (cluster, touched) per node."""
+    nodes = np.ascontiguousarray(nodes, dtype=ffi.CC_NODE_DT)
+    posteriors = np.ascontiguousarray(posteriors, dtype=np.float64)
+    read_id = np.ascontiguousarray(read_id, dtype=np.uint64)
+    node_off = np.ascontiguousarray(node_off, dtype=np.uint64)
+    selection = np.ascontiguousarray(selection, dtype=np.uint64)
+    if chunks.dtype != ffi.CC_CHUNK_DT or not chunks.flags.c_contiguous:
+        raise ValueError("chunks must be a contiguous array of ffi.CC_CHUNK_DT (it is updated in place)")
+    cluster = np.zeros(len(nodes), dtype=np.uint64)
+    touched = np.zeros(len(nodes), dtype=np.uint8)
+    check(ffi.lib().jtk_lc_correct_clustering(len(read_id), u64p(read_id), u64p(node_off), nodes.ctypes.data, f64p(posteriors),
+                                              len(chunks), chunks.ctypes.data, len(selection), u64p(selection),
+                                              float(haploid_coverage), float(min_gain), u64p(cluster), u8p(touched), device))
+    return cluster, touched
+
+
 def cluster_features(params, feature_chunks, variants, variant_type, post_stride, device=0,
                      raise_on_chunk_failure=True):
     """jtk_lc_cluster_features: cluster_filtered_variants + posterior on caller-supplied feature matrices."""

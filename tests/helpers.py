@@ -47,3 +47,50 @@ def random_feature_problem(rng, n, dim, k_true):
     x[rng.random((n, dim)) < 0.03] *= -1
     vt = np.stack([rng.integers(1, 4, dim), rng.integers(0, 3, dim)], axis=1).astype(np.uint32)
     return x, vt, lab
+
+
+def correction_problem(seed, n_chunks=6, n_reads=40, window=(3, 6), noise=1.2, flat=0.15, wrong=0.0, single=(), cluster_dt=None, node_dt=None):
+    """A small DataSet as phmm_likelihood_correction.rs sees it: two haplotypes over a chain of chunks (ids 0..n_chunks-1),
+    each read covering a window of consecutive chunks on either strand; every node carries ln-posteriors over its chunk's
+    clusters (two, or one for the chunks listed in `single`) and the arg-max of them as its cluster.  A fraction `flat` of
+    the nodes is uninformative (posterior near 0.5/0.5), which is what the correction exists to repair;
+    a fraction `wrong` is confidently mislabelled (these lower the adjusted Rand index of a chunk)."""
+    from jtk_amd import ffi
+    node_dt = node_dt or ffi.CC_NODE_DT
+    cluster_dt = cluster_dt or ffi.CC_CHUNK_DT
+    rng = np.random.default_rng(seed)
+    nodes, post, node_off, hap_of = [], [], [0], []
+    for r in range(n_reads):
+        hap = int(rng.integers(0, 2))
+        w = int(rng.integers(window[0], window[1] + 1))
+        w = min(w, n_chunks)
+        start = int(rng.integers(0, n_chunks - w + 1))
+        fwd = bool(rng.integers(0, 2))
+        ids = list(range(start, start + w))
+        if not fwd:
+            ids.reverse()
+        for cid in ids:
+            if cid in single:
+                p = np.array([0.0])
+                cl = 0
+            else:
+                z = rng.normal(noise * 3.0, noise) if rng.random() >= flat else rng.normal(0.0, 0.05)
+                logit = z if hap == 1 else -z
+                if wrong and rng.random() < wrong * (1 + cid % 3):  # confidently on the other haplotype, chunk dependent
+                    logit = -logit
+                p1 = 1.0 / (1.0 + np.exp(-logit))
+                p1 = min(max(p1, 1e-6), 1.0 - 1e-6)
+                p = np.log(np.array([1.0 - p1, p1]))
+                cl = int(np.argmax(p))
+            nodes.append((cid, cl, 1 if fwd else 0, len(p), len(post)))
+            post.extend(p.tolist())
+        node_off.append(len(nodes))
+        hap_of.append(hap)
+    nodes = np.array(nodes, dtype=node_dt)
+    chunks = np.zeros(n_chunks, dtype=cluster_dt)
+    chunks["id"] = np.arange(n_chunks)
+    chunks["cluster_num"] = [1 if c in single else 2 for c in range(n_chunks)]
+    chunks["copy_num"] = 2
+    chunks["score"] = rng.uniform(0.0, 30.0, n_chunks)
+    return dict(read_id=np.arange(n_reads, dtype=np.uint64) * 7 + 3, node_off=np.array(node_off, dtype=np.uint64), nodes=nodes,
+                posteriors=np.array(post, dtype=np.float64), chunks=chunks, hap=np.array(hap_of))

@@ -176,6 +176,9 @@ def lib():
     sig("jo_fit_mstep", None, C.POINTER(Hmm), PD, C.POINTER(Hmm))
     sig("jo_fit_model", C.c_int, C.POINTER(Params), sz, p, PU8, PU8, C.POINTER(u64), PU8, C.POINTER(u64), PU8, u32,
         C.POINTER(Hmm), C.POINTER(Hmm))
+    sig("jo_correct_clustering", C.c_int, sz, C.POINTER(u64), C.POINTER(u64), p, PD, sz, p, sz, C.POINTER(u64), d, d,
+        C.POINTER(u64), PU8, PD, PD)
+    sig("jo_rng128pp_seed_from_u64", None, C.POINTER(Rng), u64)
     sig("jo_polish_chunks", C.c_int, C.POINTER(Params), sz, p, PU8, PU8, C.POINTER(u64), PU8, C.POINTER(u64), PU8, u32, u32,
         u32, PU8, C.POINTER(u64), PU8, C.POINTER(u64), p, C.c_int)
     sig("jo_cluster_features", C.c_int, C.POINTER(Params), sz, p, PD, C.POINTER(u32), C.POINTER(u32), PD,
@@ -266,3 +269,21 @@ def fit_model(params, batch, rounds=10):
                             u8p(batch.read_bases), u64p(batch.read_off), u8p(batch.ops), u64p(batch.ops_off), u8p(batch.strand),
                             rounds, C.byref(f), C.byref(r))
     return rc, f, r
+
+
+def correct_clustering(read_id, node_off, nodes, posteriors, chunks, selection, haploid_coverage, min_gain, want_sims=0):
+    """jo_correct_clustering (phmm_likelihood_correction.rs:32-97).  `chunks` is updated in place.  Returns
+    (rc, cluster, touched, ari per chunk, similarity matrix of the first corrected chunk if want_sims = its read count)."""
+    nodes = np.ascontiguousarray(nodes)
+    posteriors = np.ascontiguousarray(posteriors, dtype=np.float64)
+    read_id = np.ascontiguousarray(read_id, dtype=np.uint64)
+    node_off = np.ascontiguousarray(node_off, dtype=np.uint64)
+    selection = np.ascontiguousarray(selection, dtype=np.uint64)
+    cluster = np.zeros(len(nodes), dtype=np.uint64)
+    touched = np.zeros(len(nodes), dtype=np.uint8)
+    ari = np.full(len(chunks), np.nan)
+    sims = np.zeros((want_sims, want_sims)) if want_sims else None
+    rc = lib().jo_correct_clustering(len(read_id), u64p(read_id), u64p(node_off), nodes.ctypes.data, f64p(posteriors), len(chunks),
+                                     chunks.ctypes.data, len(selection), u64p(selection), float(haploid_coverage), float(min_gain),
+                                     u64p(cluster), u8p(touched), f64p(ari), f64p(sims) if want_sims else None)
+    return rc, cluster, touched, ari, sims
