@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="override the dataset size (strong) / chunks per GPU (weak)")
     ap.add_argument("--streams", type=int, default=4,
                     help="slices of the rank's shard in flight, each a resident session on its own HIP stream and host thread")
+    ap.add_argument("--stagger-ms", type=float, default=0.0,
+                    help="slice i starts its first pass i x this many ms after slice 0 (inside the timed region): slices that "
+                         "start together stay in lock step (all in the pair-HMM passes, then all in their chains)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the one-shot (host buffers in, host buffers out) timing")
     args = ap.parse_args()
@@ -149,6 +152,9 @@ def main():
     elif rank == 0 and jbuild.is_stale():
         sys.stderr.write("bench.py: WARNING: a source is newer than libjtk_lc.so; timing the library as built "
                          "(run __graft_entry__.build() first)\n")
+    # the bench process owns its GPU: let the library keep the workspaces of a finished one-shot call for the next one
+    # (default 32 GB so that it cannot starve other users of the device in a shared process; a 2500-chunk call needs ~95 GB)
+    os.environ.setdefault("JTK_LC_POOL_GB", "160")
     sha = lib_sha16()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU (torch sees none)")
@@ -207,6 +213,8 @@ def main():
 
         def worker(i):
             try:
+                if not serial and args.stagger_ms > 0.0 and i > 0:
+                    time.sleep(i * args.stagger_ms / 1e3)
                 for s in range(n_steps):
                     sessions[i].run(skip_polish=False)   # returns when the device has finished this slice's pass
                     t = api.last_timing()                # thread-local: the pass this thread just ran
@@ -358,7 +366,7 @@ def main():
         warm = time.perf_counter() - t2
         tm = api.last_timing()
         line["e2e"] = dict(chunks_per_s=batch.n_chunks / warm, seconds=warm, first_call_seconds=cold,
-                           h2d_ms=tm["h2d_ms"], d2h_ms=tm["d2h_ms"], matches_resident=bool(np.array_equal(one["label"], out["label"])),
+                           h2d_ms=tm["h2d_ms"], d2h_ms=tm["d2h_ms"], pool_gb=float(os.environ["JTK_LC_POOL_GB"]), matches_resident=bool(np.array_equal(one["label"], out["label"])),
                            note="jtk_lc_cluster_chunks on this rank's shard from host buffers to host buffers; the first call "
                                 "also maps the device workspaces, the second reuses the pooled blocks")
     api.trim_cache(local_rank)

@@ -2327,7 +2327,10 @@ __device__ __forceinline__ double gains_expected(const jtk_gains_t *g, uint32_t 
 }
 
 // one workgroup of two waves per chunk: wave 0 runs the algorithm, wave 1 feeds it proposals
-__global__ __launch_bounds__(128) void mcmc_kernel(const ChunkMeta *chunks, ChunkState *state,
+#ifndef JTK_MCMC_WAVES
+#define JTK_MCMC_WAVES 1  // resident waves per SIMD the register budget is set for (2: 256 registers, the rest spills)
+#endif
+__global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(const ChunkMeta *chunks, ChunkState *state,
                                                   const jtk_lc_params_t *params, const double *feat_all,
                                                   const uint32_t *vtype_all, const uint64_t *vt_off_all,
                                                   uint32_t vt_stride_mode, uint32_t *label_all, double *post_all,
@@ -2583,7 +2586,8 @@ static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
 }
 static uint32_t clamp_k(uint32_t lds_k) { return lds_k < 2 ? 2 : (lds_k > JTK_MAX_COPY ? JTK_MAX_COPY : lds_k); }
 static bool mcmc_jump_in_lds(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
-    return mcmc_lds_core(lds_n, lds_d, lds_k) + JUMP_TAB_BYTES <= 80 * 1024;
+    static const bool never = getenv("JTK_MCMC_JUMP_GLOBAL") != nullptr;  // experiment: what the 16 KiB are worth to the other kernels
+    return !never && mcmc_lds_core(lds_n, lds_d, lds_k) + JUMP_TAB_BYTES <= 80 * 1024;
 }
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
     lds_k = clamp_k(lds_k);

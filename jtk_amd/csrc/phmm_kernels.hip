@@ -137,7 +137,13 @@ __global__ void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const 
 #endif
 #define RW 72   // entries per ring slot: 64 lanes + 4 wrapped copies in front + 2 behind (rounded up)
 
-__global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_reads, const ReadMeta *reads,
+// Register budget: 152 per wave instead of the 168 that three waves per SIMD allow.  The chain kernel's waves hold 360
+// registers each; a SIMD that hosts one has 152 left, and with this cap a pair-HMM wave of another batch still fits beside
+// it (bench.py overlaps batches).  On gfx90a+ the attribute counts the unified file in halves, hence 76.
+#ifndef JTK_PHMM_NUM_VGPR
+#define JTK_PHMM_NUM_VGPR 76
+#endif
+__global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(JTK_PHMM_NUM_VGPR))) void phmm_kernel(uint32_t n_reads, const ReadMeta *reads,
                                                   const ChunkMeta *chunks, const ChunkState *state,
                                                   DevBufs bufs, const uint8_t *ey_all, const uint64_t *delta_all,
                                                   const HmmDev *hmm2, double *scratch_all,
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
                 mx = fd > mx ? fd : mx;
                 mx = wave_max(mx);
                 if (mx > 0.0) {
-                    const int e = jtk_ilogb_pos(mx);
+                    const int e = __builtin_amdgcn_readfirstlane(jtk_ilogb_pos(mx));  // the same in every lane: keep it scalar
                     const double sc = pow2i(-e);
                     fm *= sc;
                     fi *= sc;
@@ -333,6 +339,7 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
 #pragma unroll
         for (int q = 0; q < JTK_PHMM_PF; q++) pq[q] = load_pair((T - 5) - (((T - 5) - q) & (JTK_PHMM_PF - 1)));
         int delta_next = 0;  // c[t+1] - c[t]
+        int EFcur = __builtin_amdgcn_readfirstlane(s_EF[T >> 6]);  // forward exponent of the block the sweep is in (scalar)
         const double2 *ring_me = ring + lane + 4;  // source row i+k: entry ring_me[k] of its slot
 
         // One backward step.  The sweep is unrolled by 4 (t & 3 == 3 - U inside a group), which makes the queue
@@ -348,7 +355,9 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
                 return half[(lo2 >> 2) & 1] + (lo2 & 3) * RW;
             };
             if (U == 0 && (t & 63) == 63 && t < T) {  // the sweep enters the block below
-                const double f = fast_pow2(s_EF[(t + 1) >> 6] - s_EF[t >> 6]);
+                const int EFabove = EFcur;
+                EFcur = __builtin_amdgcn_readfirstlane(s_EF[t >> 6]);
+                const double f = fast_pow2(EFabove - EFcur);
 #pragma unroll
                 for (int sl = 0; sl < 8; sl++) {
                     double2 v = ring_me[sl * RW];
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
                 mx = vd > mx ? vd : mx;
                 mx = wave_max(mx);
                 if (mx > 0.0) {
-                    const int e = jtk_ilogb_pos(mx);
+                    const int e = __builtin_amdgcn_readfirstlane(jtk_ilogb_pos(mx));
                     const double sc = pow2i(-e);
                     vm *= sc;
                     vi *= sc;
@@ -410,8 +419,7 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) void phmm_kernel(uint32_t n_rea
             const double hM = *reinterpret_cast<const double *>(s_eM + xs + y8) * vm;
             const double hI = *reinterpret_cast<const double *>(s_eI + ey8) * vi;
             // (2) common exponent of this step
-            const int EFt = s_EF[t >> 6];
-            const int G = EFt + EB;
+            const int G = EFcur + EB;
             if (t < T && G != Gprev) {
                 const double sc = pow2i(Gprev - G);
 #pragma unroll

@@ -11,7 +11,8 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "_build", "libjtk_lc.so")
+# JTK_LC_LIB: an experiment build of the library (scripts/*probe*.sh); the product never sets it
+LIB_PATH = os.environ.get("JTK_LC_LIB") or os.path.join(PKG_DIR, "_build", "libjtk_lc.so")
 SYNTH_LIB_PATH = os.path.join(PKG_DIR, "_build", "libjtk_synth.so")
 
 NUM_ROW = 14

@@ -52,6 +52,11 @@ assert o["rc"] == 0
 x = np.ascontiguousarray(np.random.default_rng(1).normal(size=(9, 4)))
 asn = np.zeros(9, dtype=np.uintp); gain = np.zeros((9, 3))
 O.lib().jo_cluster_filtered_variants_exact(O.f64p(x), 9, 4, 3, O.szp(asn), O.f64p(gain))
+# the cross-chunk correction (oracle/correction.c)
+prob = helpers.correction_problem(3, n_chunks=5, n_reads=30, wrong=0.05)
+rc, *_ = O.correct_clustering(prob["read_id"], prob["node_off"], prob["nodes"], prob["posteriors"], prob["chunks"].copy(),
+                              np.arange(5, dtype=np.uint64), 20.0, 1.0, 0)
+assert rc == 0
 print("ok")
 '''
     assert "ok" in run_child(code, {})
