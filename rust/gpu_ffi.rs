@@ -34,6 +34,16 @@ pub struct JtkLcResult {
     pub score: f64, pub cluster_num: u32, pub status: i32, pub polish_rounds: u32, pub n_variants: u32,
 }
 
+// the flattened DataSet view of jtk_lc_correct_clustering (phmm_likelihood_correction.rs:32-97)
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct JtkCcNode {
+    pub chunk: u64, pub cluster: u64, pub is_forward: u32, pub post_len: u32, pub post_off: u64,
+}
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct JtkCcChunk {
+    pub id: u64, pub cluster_num: u32, pub copy_num: u32, pub score: f64,
+}
+
 extern "C" {
     pub fn jtk_lc_cluster_chunks(
         params: *const JtkLcParams, n_chunks: usize, chunks: *const JtkLcChunk,
@@ -44,6 +54,24 @@ extern "C" {
         ops_out: *mut u8, ops_out_off: *mut u64, ops_cap: u64, device: c_int) -> c_int;
     pub fn jtk_lc_estimate_gains(forward: *const JtkHmm, reverse: *const JtkHmm, seed: u64, seq_len: u32, band: u32,
                                  homop_len: u32, out: *mut JtkGains, device: c_int) -> c_int;   // likelihood_gains.rs:162-192
+    // model_tune.rs:119-152 on the training pile-ups the host selected (model_tune.rs:99-118)
+    pub fn jtk_lc_fit_model(
+        params: *const JtkLcParams, n_chunks: usize, chunks: *const JtkLcChunk,
+        tmpl_bases: *const u8, read_bases: *const u8, read_off: *const u64,
+        ops: *const u8, ops_off: *const u64, strand: *const u8, rounds: u32,
+        forward_out: *mut JtkHmm, reverse_out: *mut JtkHmm, device: c_int) -> c_int;
+    // kiley polish_until_converge_antidiagonal on a batch of windows (consensus/mod.rs:476-483)
+    pub fn jtk_lc_polish_chunks(
+        params: *const JtkLcParams, n_chunks: usize, chunks: *const JtkLcChunk,
+        tmpl_bases: *const u8, read_bases: *const u8, read_off: *const u64,
+        ops: *const u8, ops_off: *const u64, strand: *const u8, radius: u32, take_num: u32, ignore_edge: u32,
+        cons_out: *mut u8, cons_off: *mut u64, cons_cap: u64,
+        ops_out: *mut u8, ops_out_off: *mut u64, ops_cap: u64, result: *mut JtkLcResult, device: c_int) -> c_int;
+    // AlignmentCorrection::correct_clustering_selected (phmm_likelihood_correction.rs:32-97)
+    pub fn jtk_lc_correct_clustering(
+        n_reads: usize, read_id: *const u64, node_off: *const u64, nodes: *const JtkCcNode, posteriors: *const f64,
+        n_chunks: usize, chunks: *mut JtkCcChunk, n_selected: usize, selection: *const u64,
+        haploid_coverage: f64, min_gain: f64, cluster_out: *mut u64, touched: *mut u8, device: c_int) -> c_int;
     pub fn jtk_lc_trim_cache(device: c_int) -> c_int;          // hand pooled device workspaces back to the driver
     pub fn jtk_lc_strerror(status: c_int) -> *const c_char;
     pub fn jtk_lc_last_error() -> *const c_char;

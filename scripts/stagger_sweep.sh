@@ -2,7 +2,7 @@
 # GPU box: the default bench workload with different slice counts / start offsets (one line each)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
-for cfg in "4 0" "4 200" "4 300" "4 400" "6 200" "8 150" "3 400" "2 600"; do
+for cfg in ${@:-"4 0" "3 0" "5 0" "6 0" "8 0" "10 0"}; do
   set -- $cfg
   python bench.py --streams $1 --stagger-ms $2 --no-cpu-baseline --no-e2e --steps 6 2>/dev/null | python -c "
 import sys, json

@@ -49,9 +49,10 @@ def test_rust_ffi_matches_the_header():
         assert name in cf, name
         assert (len([a for a in args.split(",") if a.strip()]) if args else 0) == cf[name], name
         seen += 1
-    assert seen >= 4 and "jtk_lc_cluster_chunks" in ext
+    assert seen >= 7 and "jtk_lc_cluster_chunks" in ext
     for c_name, r_name in [("jtk_hmm", "JtkHmm"), ("jtk_gain_profile", "JtkGainProfile"), ("jtk_gains", "JtkGains"),
-                           ("jtk_lc_params", "JtkLcParams"), ("jtk_lc_chunk", "JtkLcChunk"), ("jtk_lc_result", "JtkLcResult")]:
+                           ("jtk_lc_params", "JtkLcParams"), ("jtk_lc_chunk", "JtkLcChunk"), ("jtk_lc_result", "JtkLcResult"),
+                           ("jtk_cc_node", "JtkCcNode"), ("jtk_cc_chunk", "JtkCcChunk")]:
         assert rust_struct_fields(rust, r_name) == c_struct_fields(header, c_name), c_name
 
 
