@@ -129,6 +129,17 @@ int jtk_lc_cluster_chunks(const jtk_lc_params_t *params, size_t n_chunks, const 
                           uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out,
                           uint64_t *ops_out_off, uint64_t ops_cap, int device);
 
+/* The same call over several GPUs of one node from one host process (SURVEY 8b's `device_mask`, as a list): chunks are
+ * dealt to `devices` in contiguous, read-balanced shares, each share runs as on a single device (sliced, overlapped), the
+ * outputs are written in place as above.  Chunks are independent (one RNG stream per chunk id), so results do not depend on
+ * the device list; the path has no exchange step and no collective runs.  A device may be listed more than once. */
+int jtk_lc_cluster_chunks_multi(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                                const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                                const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
+                                uint32_t *label, double *log_post, uint32_t post_stride, jtk_lc_result_t *result,
+                                uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out,
+                                uint64_t *ops_out_off, uint64_t ops_cap, const int *devices, size_t n_devices);
+
 /* Same, but the template is an already polished consensus and ops are already re-threaded: skips
  * polish_until_converge_antidiagonal.  This is `pseudo_mcmc::clustering` (pseudo_mcmc.rs:77-107) batched;
  * a Rust host that keeps real kiley polishing calls this one and inherits exactness downstream.

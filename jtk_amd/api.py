@@ -23,15 +23,21 @@ def _outputs(batch):
                 ops_out_off=ops_out_off)
 
 
-def cluster_chunks(params, batch, device=0, raise_on_chunk_failure=True):
-    """jtk_lc_cluster_chunks: polish + variant search + clustering for every chunk of `batch`."""
+def cluster_chunks(params, batch, device=0, raise_on_chunk_failure=True, devices=None):
+    """jtk_lc_cluster_chunks: polish + variant search + clustering for every chunk of `batch`;
+    devices=[...]: jtk_lc_cluster_chunks_multi over that list of GPUs."""
     L = ffi.lib()
     o = _outputs(batch)
-    rc = L.jtk_lc_cluster_chunks(C.byref(params), batch.n_chunks, batch.chunks.ctypes.data, u8p(batch.tmpl_bases),
-                                 u8p(batch.read_bases), u64p(batch.read_off), u8p(batch.ops), u64p(batch.ops_off),
-                                 u8p(batch.strand), u32p(o["label"]), f64p(o["log_post"]), batch.post_stride,
-                                 o["result"].ctypes.data, u8p(o["cons"]), u64p(o["cons_off"]), len(o["cons"]),
-                                 u8p(o["ops_out"]), u64p(o["ops_out_off"]), len(o["ops_out"]), device)
+    args = (C.byref(params), batch.n_chunks, batch.chunks.ctypes.data, u8p(batch.tmpl_bases),
+            u8p(batch.read_bases), u64p(batch.read_off), u8p(batch.ops), u64p(batch.ops_off),
+            u8p(batch.strand), u32p(o["label"]), f64p(o["log_post"]), batch.post_stride,
+            o["result"].ctypes.data, u8p(o["cons"]), u64p(o["cons_off"]), len(o["cons"]),
+            u8p(o["ops_out"]), u64p(o["ops_out_off"]), len(o["ops_out"]))
+    if devices is None:
+        rc = L.jtk_lc_cluster_chunks(*args, device)
+    else:
+        dev = (C.c_int * len(devices))(*devices)
+        rc = L.jtk_lc_cluster_chunks_multi(*args, dev, len(devices))
     if rc != 0 and (raise_on_chunk_failure or rc != -6):
         check(rc)
     o["rc"] = rc

@@ -61,6 +61,22 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def source_sha16():
+    """sha256[:16] over the sources the device library is built from (names + contents, sorted): what a profile under
+    profiles/ is tied to -- unlike the .so's own hash it does not depend on where or when hipcc ran."""
+    import hashlib
+    files = [os.path.join(CSRC, f) for f in SOURCES]
+    files += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    files += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h")]
+    h = hashlib.sha256()
+    for f in sorted(set(files)):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS[:7]).encode())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     """True when a source is newer than the library built from it (bench.py refuses to time a stale build)."""
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]

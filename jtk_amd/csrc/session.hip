@@ -1094,13 +1094,19 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
                     const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off, const uint8_t *ops,
                     const uint64_t *ops_off, const uint8_t *strand, int skip_polish, uint32_t *label, double *log_post,
                     uint32_t post_stride, jtk_lc_result_t *result, uint8_t *cons_out, uint64_t *cons_off,
-                    uint64_t cons_cap, uint8_t *ops_out, uint64_t *ops_out_off, uint64_t ops_cap, int device) {
-    size_t n_slices = std::min<size_t>(3, n_chunks / 500);  // 2500 chunks: 2.48 s unsliced, 2.21 / 2.12 s in 2 / 3 slices
-    if (const char *e = getenv("JTK_LC_SLICES")) n_slices = (size_t)atoi(e);
+                    uint64_t cons_cap, uint8_t *ops_out, uint64_t *ops_out_off, uint64_t ops_cap, const int *devices,
+                    size_t n_devices) {
+    // several devices: the same slicing, consecutive slices dealt to consecutive devices (a device's slices overlap
+    // each other as on one GPU; devices share nothing)
+    if (!devices || n_devices == 0) return fail(JTK_ERR_INVALID_ARG, "no device given");
+    size_t per_dev = std::min<size_t>(3, n_chunks / n_devices / 500);  // 2500 chunks: 2.48 s unsliced, 2.21 / 2.12 s in 2 / 3 slices
+    if (const char *e = getenv("JTK_LC_SLICES")) per_dev = (size_t)atoi(e);
+    if (per_dev < 1) per_dev = 1;
+    size_t n_slices = per_dev * n_devices;
     if (n_slices > n_chunks) n_slices = n_chunks;
     if (n_slices < 2 || !params || !chunks || !read_off || !ops_off || !label || !log_post || !result)
         return run_slice(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, skip_polish, label,
-                         log_post, post_stride, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap, device);
+                         log_post, post_stride, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap, devices[0]);
     g_last_error.clear();
     uint64_t n_reads = 0;
     for (size_t c = 0; c < n_chunks; c++) {
@@ -1151,6 +1157,7 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
             S.ops.resize(ops_need);
             S.ops_off.resize(r1 - r0 + 1);
         }
+        const int device = devices[std::min(sl / per_dev, n_devices - 1)];
         threads.emplace_back([=, &S]() {
             S.rc = run_slice(params, c1 - c0, S.chunks.data(), tmpl_bases, read_bases, read_off + r0, ops, ops_off + r0,
                              strand + r0, skip_polish, label + r0, log_post + r0 * post_stride, post_stride, result + c0,
@@ -1208,7 +1215,22 @@ int jtk_lc_cluster_chunks(const jtk_lc_params_t *params, size_t n_chunks, const 
                           uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out, uint64_t *ops_out_off,
                           uint64_t ops_cap, int device) {
     return run_once(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, 0, label,
-                    log_post, post_stride, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap, device);
+                    log_post, post_stride, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap, &device, 1);
+}
+
+// The same stage call over several GPUs of one node from ONE host process: contiguous, read-balanced shares of the
+// chunks per device, each share sliced and overlapped as on a single device, results written in place.  The path has no
+// exchange step, so there is no collective: this is SURVEY 8(b)'s `device_mask` as an explicit list.
+int jtk_lc_cluster_chunks_multi(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+                                const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
+                                const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t *label,
+                                double *log_post, uint32_t post_stride, jtk_lc_result_t *result, uint8_t *cons_out,
+                                uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out, uint64_t *ops_out_off,
+                                uint64_t ops_cap, const int *devices, size_t n_devices) {
+    g_last_error.clear();
+    return run_once(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, 0, label,
+                    log_post, post_stride, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap, devices,
+                    n_devices);
 }
 
 int jtk_lc_cluster_polished(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
@@ -1216,7 +1238,7 @@ int jtk_lc_cluster_polished(const jtk_lc_params_t *params, size_t n_chunks, cons
                             const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t *label,
                             double *log_post, uint32_t post_stride, jtk_lc_result_t *result, int device) {
     return run_once(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, 1, label,
-                    log_post, post_stride, result, nullptr, nullptr, 0, nullptr, nullptr, 0, device);
+                    log_post, post_stride, result, nullptr, nullptr, 0, nullptr, nullptr, 0, &device, 1);
 }
 
 // kiley polish_until_converge_antidiagonal(template, seqs, ops, strands, HMMPolishConfig::new(radius, take_num, ignore_edge))

@@ -75,7 +75,7 @@ CC_CHUNK_DT = np.dtype([("id", "<u8"), ("cluster_num", "<u4"), ("copy_num", "<u4
 
 # every symbol declared in include/jtk_lc.h (tests check the library exports them)
 EXPORTED_SYMBOLS = (
-    "jtk_lc_cluster_chunks", "jtk_lc_cluster_polished", "jtk_lc_polish_chunks", "jtk_lc_modification_table",
+    "jtk_lc_cluster_chunks", "jtk_lc_cluster_chunks_multi", "jtk_lc_cluster_polished", "jtk_lc_polish_chunks", "jtk_lc_modification_table",
     "jtk_lc_cluster_features", "jtk_lc_estimate_gains", "jtk_lc_fit_model", "jtk_lc_correct_clustering", "jtk_lc_trim_cache", "jtk_lc_pileup_sort_key", "jtk_lc_normalize_pileup", "jtk_lc_strerror",
     "jtk_lc_last_error", "jtk_lc_version", "jtk_lc_device_ok", "jtk_lc_last_timing",
     "jtk_lc_session_create", "jtk_lc_session_run", "jtk_lc_session_fetch", "jtk_lc_session_destroy",
@@ -124,6 +124,8 @@ def lib():
 
     sig("jtk_lc_cluster_chunks", i32, PP, sz, vp, PU8, PU8, PU64, PU8, PU64, PU8, PU32, PD, u32, vp, PU8,
         PU64, u64, PU8, PU64, u64, i32)
+    sig("jtk_lc_cluster_chunks_multi", i32, PP, sz, vp, PU8, PU8, PU64, PU8, PU64, PU8, PU32, PD, u32, vp, PU8,
+        PU64, u64, PU8, PU64, u64, C.POINTER(C.c_int), sz)
     sig("jtk_lc_cluster_polished", i32, PP, sz, vp, PU8, PU8, PU64, PU8, PU64, PU8, PU32, PD, u32, vp, i32)
     sig("jtk_lc_polish_chunks", i32, PP, sz, vp, PU8, PU8, PU64, PU8, PU64, PU8, u32, u32, u32, PU8, PU64, u64, PU8, PU64,
         u64, vp, i32)

@@ -52,6 +52,14 @@ extern "C" {
         label: *mut u32, log_post: *mut f64, post_stride: u32, result: *mut JtkLcResult,
         cons_out: *mut u8, cons_off: *mut u64, cons_cap: u64,
         ops_out: *mut u8, ops_out_off: *mut u64, ops_cap: u64, device: c_int) -> c_int;
+    // the same over several GPUs of one node (contiguous, read-balanced shares; no collective)
+    pub fn jtk_lc_cluster_chunks_multi(
+        params: *const JtkLcParams, n_chunks: usize, chunks: *const JtkLcChunk,
+        tmpl_bases: *const u8, read_bases: *const u8, read_off: *const u64,
+        ops: *const u8, ops_off: *const u64, strand: *const u8,
+        label: *mut u32, log_post: *mut f64, post_stride: u32, result: *mut JtkLcResult,
+        cons_out: *mut u8, cons_off: *mut u64, cons_cap: u64,
+        ops_out: *mut u8, ops_out_off: *mut u64, ops_cap: u64, devices: *const c_int, n_devices: usize) -> c_int;
     pub fn jtk_lc_estimate_gains(forward: *const JtkHmm, reverse: *const JtkHmm, seed: u64, seq_len: u32, band: u32,
                                  homop_len: u32, out: *mut JtkGains, device: c_int) -> c_int;   // likelihood_gains.rs:162-192
     // model_tune.rs:119-152 on the training pile-ups the host selected (model_tune.rs:99-118)

@@ -7,8 +7,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from jtk_amd import build as jbuild  # noqa: E402
 
 FAMILY = {"mcmc": ["mcmc_kernel"], "phmm": ["phmm_kernel", "phmm_wide_kernel", "finalize_kernel"],
           "polish": ["sum_tables_kernel", "select_edits_kernel", "rethread_kernel", "commit_kernel", "band_prep_kernel"],
@@ -27,7 +31,7 @@ def main(root, tag):
     m = re.search(r"--workload (\S+)", cmd)
     if m:
         workload = m.group(1)
-    out = [f"== rocprofv3 --kernel-trace --stats -- {cmd} ==", f"(library sha256[:16] {sha}; workload {workload})",
+    out = [f"== rocprofv3 --kernel-trace --stats -- {cmd} ==", f"(library sha256[:16] {sha}; kernel sources {jbuild.source_sha16()}; workload {workload})",
            f"{'kernel':28s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>12s} {'pct':>7s}"]
     pmc = {}
     for f in glob.glob(f"{root}/prof_stats_{tag}/**/*_kernel_stats.csv", recursive=True):
@@ -51,7 +55,7 @@ def main(root, tag):
             pmc[k]["launches_in_profile"] = n
     print("\n".join(out))
     json.dump({"command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- {cmd}",
-               "workload": workload, "lib_sha16": sha,
+               "workload": workload, "lib_sha16": sha, "src_sha16": jbuild.source_sha16(),
                "note": "KiB per launch; FETCH_SIZE on gfx950 reports half of the bytes of wide coalesced reads "
                        "(MI355X_MICROARCH.md HBM): hbm_bytes = (2*FETCH + WRITE)*1024",
                "kernel_family": FAMILY, "kernels": pmc}, open(f"{root}/prof_traffic_{tag}.json", "w"), indent=1)

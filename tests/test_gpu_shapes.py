@@ -292,3 +292,22 @@ def test_model_refit_matches_oracle(lib, config, rounds):
     assert bytes(df) == bytes(of) and bytes(dr) == bytes(orv)
     assert abs(df.mat_mat + df.mat_ins + df.mat_del - 1.0) < 1e-12
     assert bytes(df) != bytes(p.forward)
+
+
+def test_multi_device_call_matches_single_device(lib):
+    """jtk_lc_cluster_chunks_multi: shares of the chunks per listed device, results in place.  One GPU here, listed twice and
+    three times: the partition, the per-share slicing and the stitching of the variable-length outputs are what is tested."""
+    b, cfg, p = helpers.small_batch(n_chunks=7, tmpl_len=300, reads_per_hap=6)
+    one = api.cluster_chunks(p, b)
+    for devices in ([0, 0], [0, 0, 0], [0]):
+        many = api.cluster_chunks(p, b, devices=devices)
+        for k in ("label", "log_post", "result", "cons_off", "ops_out_off"):
+            assert np.array_equal(one[k], many[k]), (devices, k)
+        assert np.array_equal(one["cons"][:int(one["cons_off"][-1])], many["cons"][:int(many["cons_off"][-1])])
+        assert np.array_equal(one["ops_out"][:int(one["ops_out_off"][-1])], many["ops_out"][:int(many["ops_out_off"][-1])])
+    with pytest.raises(ffi.JtkError) as e:
+        api.cluster_chunks(p, b, devices=[])
+    assert e.value.status == -1
+    with pytest.raises(ffi.JtkError) as e:
+        api.cluster_chunks(p, b, devices=[0, 97])
+    assert e.value.status == -2
