@@ -435,16 +435,21 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(
                 return entry(x)[k];
 #endif
             };
+            // vm enters the accumulator of this cell's read base only: one masked copy per base, shared by the sub and
+            // the ins entries (fma(x, 0, acc) == acc exactly, so masking vm instead of the pair changes no bit)
+            double vmq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) vmq[q] = y8 == 8 * q ? vm : 0.0;
             {  // sub (entry i-1): toM(i-1, j-1), toD(i-1, j)
                 const double2 a = pair(-1, -1);
 #pragma unroll
-                for (int q = 0; q < 4; q++) acc[q] = fma(y8 == 8 * q ? a.x : 0.0, vm, acc[q]);
+                for (int q = 0; q < 4; q++) acc[q] = fma(a.x, vmq[q], acc[q]);
                 acc[4] = fma(a.y, vd, acc[4]);
             }
             {  // ins (entry i): toM(i, j-1), toD(i, j);   copy 1 (entry i-1): the same pair against hatM
                 const double2 a = pair(0, 0);
 #pragma unroll
-                for (int q = 0; q < 4; q++) acc[5 + q] = fma(y8 == 8 * q ? a.x : 0.0, vm, acc[5 + q]);
+                for (int q = 0; q < 4; q++) acc[5 + q] = fma(a.x, vmq[q], acc[5 + q]);
                 acc[9] = fma(a.y, vd, acc[9]);
                 acc[10] = fma(a.y, vd, fma(a.x, hM, acc[10]));
             }
