@@ -2336,9 +2336,12 @@ __global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(const ChunkMe
                                                   uint32_t vt_stride_mode, uint32_t *label_all, double *post_all,
                                                   uint32_t post_stride, double *lg_all, const uint64_t *lg_off,
                                                   uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, uint32_t jump_in_lds,
-                                                  uint32_t flags, const uint64_t *rng_resume) {
+                                                  uint32_t flags, const uint64_t *rng_resume, const uint32_t *order) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t ci = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // workgroups are dispatched in blockIdx order: `order` lists the chunks with the longest chains first (their
+    // length is 20 x 2000 x n proposals per candidate k), so that on ragged batches the kernel does not end on a
+    // long chain that started late
+    const uint32_t ci = order ? order[blockIdx.x] : blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     ChunkState *st = &state[ci];
     if (st->status != 0) return;
     const ChunkMeta cm = chunks[ci];
@@ -2677,7 +2680,8 @@ int mcmc_upload_jump_table(hipStream_t s) {
 int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
                 const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
                 uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
-                const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, const uint64_t *rng_resume) {
+                const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, const uint64_t *rng_resume,
+                const uint32_t *order) {
     if (n_chunks == 0) return 0;
     lds_k = clamp_k(lds_k);
     const size_t lds = mcmc_lds_bytes(lds_n, lds_d, lds_k);
@@ -2685,6 +2689,6 @@ int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, Chunk
     static const uint32_t flags = getenv("JTK_MCMC_LEGACY") ? 1u : 0u;  // differential testing only
     mcmc_kernel<<<n_chunks, 128, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
                                           post_stride, lg, lg_off, lds_n, lds_d, lds_k,
-                                          mcmc_jump_in_lds(lds_n, lds_d, lds_k) ? 1u : 0u, flags, rng_resume);
+                                          mcmc_jump_in_lds(lds_n, lds_d, lds_k) ? 1u : 0u, flags, rng_resume, order);
     return 0;
 }

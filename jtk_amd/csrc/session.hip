@@ -40,7 +40,8 @@ size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k);
 int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
                 const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
                 uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
-                const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, const uint64_t *rng_resume);
+                const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, const uint64_t *rng_resume,
+                const uint32_t *order);
 
 namespace {
 
@@ -180,7 +181,7 @@ struct jtk_lc_session {
     DevPtr d_params, d_hmm2, d_chunks, d_reads, d_state, d_tmpl0, d_tmpl1, d_ops0, d_ops1, d_opslen0, d_opslen1,
         d_ey, d_delta, d_scratch, d_raw, d_rawG, d_lk, d_table, d_total, d_edits, d_newlen, d_counter, d_nactive,
         d_homop, d_homop_off, d_aux, d_aux_off, d_cand, d_list, d_sel, d_feat, d_vtype, d_pos, d_label, d_post,
-        d_lg, d_lg_off, d_vt_off, d_tmpl_init, d_ops_init, d_opslen_init;
+        d_lg, d_lg_off, d_vt_off, d_tmpl_init, d_ops_init, d_opslen_init, d_order;
     size_t tmpl_bytes = 0, ops_bytes = 0;
     DevBufs bufs;
     std::vector<KernelTimer> timers;
@@ -453,6 +454,15 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
     if ((rc = dev_upload(s, s->d_params, pv))) return rc;
     if ((rc = dev_upload(s, s->d_hmm2, hv))) return rc;
     if ((rc = dev_upload(s, s->d_chunks, s->h_chunks))) return rc;
+    {  // dispatch order of the chain kernel: longest chains (reads x candidate cluster counts) first, ties by position
+        std::vector<uint32_t> order(s->h_chunks.size());
+        for (uint32_t c = 0; c < order.size(); c++) order[c] = c;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            const ChunkMeta &x = s->h_chunks[a], &y = s->h_chunks[b];
+            return (uint64_t)x.n_reads * std::min<uint32_t>(x.copy_num, 4) > (uint64_t)y.n_reads * std::min<uint32_t>(y.copy_num, 4);
+        });
+        if ((rc = dev_upload(s, s->d_order, order))) return rc;
+    }
     if ((rc = dev_upload(s, s->d_reads, s->h_reads))) return rc;
     if ((rc = dev_alloc<ChunkState>(s->d_state, n_chunks))) return rc;
     if ((rc = dev_upload(s, s->d_tmpl_init, h_tmpl))) return rc;
@@ -632,7 +642,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                 // a chunk picks at most ROUND * max(copy_num, 2) columns (pseudo_mcmc.rs:421,527,532): size the
                 // LDS work area for the batch, so that two chunks share a CU whenever they can
                 std::min<uint32_t>(JTK_MAX_DIM, 3u * std::max<uint32_t>(s->max_copy, 2u)), s->max_copy,
-                s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr);
+                s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr, s->d_order.as<uint32_t>());
     tstop(s);
     if (mcmc_rc != 0) {
         (void)hipStreamSynchronize(st);
@@ -1572,7 +1582,7 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
     if (launch_mcmc(s->stream, (uint32_t)n_chunks, d_chunks.as<ChunkMeta>(), d_state.as<ChunkState>(),
                     d_params.as<jtk_lc_params_t>(), d_var.as<double>(), d_vt.as<uint32_t>(), d_vtoff.as<uint64_t>(), 1,
                     d_label.as<uint32_t>(), d_post.as<double>(), post_stride, d_lg.as<double>(), d_lgoff.as<uint64_t>(),
-                    max_n, max_d, max_k, nullptr) != 0)
+                    max_n, max_d, max_k, nullptr, nullptr) != 0)
         return fail(JTK_ERR_INTERNAL, "the chain kernel could not be launched (jump table upload failed)");
     HIP_TRY(hipEventRecord(ev1, s->stream));
     HIP_TRY(hipMemcpyAsync(sts.data(), d_state.p, sts.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, s->stream));
