@@ -19,7 +19,9 @@
 #define JTK_MAX_COPY 7           // one clustering() call sees copy_num < 8 (UPPER_COPY_NUM, mod.rs:85); larger chunks
                                  // go through clustering_recursive's split, which session.hip drives
 #define JTK_MAX_DIM (3 * JTK_MAX_COPY)  // ROUND * max(copy_num, 2) picked columns (pseudo_mcmc.rs:421,527,532)
-#define JTK_MAX_PILEUP 511       // reads per pile-up in the chain kernel (register tables to 255, LDS tables beyond)
+#define JTK_MAX_PILEUP 1023      // reads per pile-up in the chain kernel: 10-bit read indices in its proposal records and hop
+                                 // words (register tables to 255 reads, LDS tables beyond); the LDS work area (n x D
+                                 // doubles + tables) has to fit 160 KiB as well: session.hip sizes it per launch
 #define JTK_POLISH_MIN_GAIN 0.1
 #define JTK_POLISH_MAX_ROUNDS 20
 

@@ -165,12 +165,17 @@ struct ChunkExtra {
 
 }  // namespace
 
+struct ChainClass {
+    uint32_t first = 0, count = 0, lds_n = 0, lds_d = 0, lds_k = 0;
+};
+
 struct jtk_lc_session {
     int device = 0;
     hipStream_t stream = nullptr;
     jtk_lc_params_t params;
     uint32_t n_chunks = 0, n_reads = 0, post_stride = 1;
     uint32_t max_tmpl = 0, max_read = 0, max_n = 0, max_copy = 0, n_waves = 0;
+    ChainClass chain_class[2];  // the chain kernel's launches (by LDS need), as ranges of d_order
     uint64_t scratch_stride = 0;
     bool features_only = false;
     std::vector<ChunkMeta> h_chunks;
@@ -454,13 +459,63 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
     if ((rc = dev_upload(s, s->d_params, pv))) return rc;
     if ((rc = dev_upload(s, s->d_hmm2, hv))) return rc;
     if ((rc = dev_upload(s, s->d_chunks, s->h_chunks))) return rc;
-    {  // dispatch order of the chain kernel: longest chains (reads x candidate cluster counts) first, ties by position
-        std::vector<uint32_t> order(s->h_chunks.size());
-        for (uint32_t c = 0; c < order.size(); c++) order[c] = c;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-            const ChunkMeta &x = s->h_chunks[a], &y = s->h_chunks[b];
-            return (uint64_t)x.n_reads * std::min<uint32_t>(x.copy_num, 4) > (uint64_t)y.n_reads * std::min<uint32_t>(y.copy_num, 4);
-        });
+    {  // The chain kernel's launches.  Its LDS work area is sized per launch (reads x columns of features + tables), and
+       // two workgroups share a CU only below 80 KiB each: chunks whose own need stays below that form class 0 (all of a
+       // diploid / low-copy batch), the others class 1 (several hundred reads, or many columns).  Within a class the
+       // longest chains (reads x candidate cluster counts) are dispatched first.  A class-1 combination that does not fit
+       // a CU's 160 KiB loses its largest members (reported as JTK_ERR_UNSUPPORTED, like a pile-up beyond JTK_MAX_PILEUP).
+        auto dims_of = [&](const ChunkMeta &cm, uint32_t *n, uint32_t *d, uint32_t *k) {
+            *n = cm.n_reads;
+            *k = std::min<uint32_t>(std::max<uint32_t>(cm.copy_num, 2u), JTK_MAX_COPY);
+            // a chunk picks at most ROUND * max(copy_num, 2) columns (pseudo_mcmc.rs:421,527,532)
+            *d = std::min<uint32_t>(JTK_MAX_DIM, 3u * std::max<uint32_t>(cm.copy_num, 2u));
+        };
+        std::vector<uint32_t> cls[2];
+        for (uint32_t c = 0; c < s->h_chunks.size(); c++) {
+            uint32_t n, d, k;
+            dims_of(s->h_chunks[c], &n, &d, &k);
+            if (n > JTK_MAX_PILEUP || s->h_chunks[c].copy_num > JTK_MAX_COPY) {
+                if (s->h_state0[c].status == 0) s->h_state0[c].status = JTK_ERR_UNSUPPORTED;
+                continue;
+            }
+            cls[mcmc_lds_bytes(n, d, k) <= 80 * 1024 ? 0 : 1].push_back(c);
+        }
+        std::vector<uint32_t> order;
+        for (int q = 0; q < 2; q++) {
+            auto &v = cls[q];
+            auto need = [&](uint32_t c) {
+                uint32_t n, d, k;
+                dims_of(s->h_chunks[c], &n, &d, &k);
+                return mcmc_lds_bytes(n, d, k);
+            };
+            ChainClass &cc = s->chain_class[q];
+            for (;;) {
+                cc = ChainClass{};
+                for (uint32_t c : v) {
+                    uint32_t n, d, k;
+                    dims_of(s->h_chunks[c], &n, &d, &k);
+                    cc.lds_n = std::max(cc.lds_n, n);
+                    cc.lds_d = std::max(cc.lds_d, d);
+                    cc.lds_k = std::max(cc.lds_k, k);
+                }
+                if (v.empty() || mcmc_lds_bytes(cc.lds_n, cc.lds_d, cc.lds_k) <= 160 * 1024) break;
+                auto worst = std::max_element(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return need(a) < need(b); });
+                if (q == 0) {
+                    cls[1].push_back(*worst);  // class 0's maxima can combine beyond one member's need: hand it over
+                } else if (s->h_state0[*worst].status == 0) {
+                    s->h_state0[*worst].status = JTK_ERR_UNSUPPORTED;
+                }
+                v.erase(worst);
+            }
+            std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) {
+                const ChunkMeta &x = s->h_chunks[a], &y = s->h_chunks[b];
+                return (uint64_t)x.n_reads * std::min<uint32_t>(x.copy_num, 4) > (uint64_t)y.n_reads * std::min<uint32_t>(y.copy_num, 4);
+            });
+            cc.first = (uint32_t)order.size();
+            cc.count = (uint32_t)v.size();
+            order.insert(order.end(), v.begin(), v.end());
+        }
+        if (order.empty()) order.push_back(0);
         if ((rc = dev_upload(s, s->d_order, order))) return rc;
     }
     if ((rc = dev_upload(s, s->d_reads, s->h_reads))) return rc;
@@ -636,13 +691,14 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                   s->max_tmpl);
     tstop(s);
     tstart(s, JTK_K_MCMC);
-    const int mcmc_rc = launch_mcmc(st, s->n_chunks, chunks, state, s->d_params.as<jtk_lc_params_t>(), s->d_feat.as<double>(),
-                s->d_vtype.as<uint32_t>(), nullptr, 0, s->d_label.as<uint32_t>(), s->d_post.as<double>(),
-                s->post_stride, s->d_lg.as<double>(), s->d_lg_off.as<uint64_t>(), s->max_n,
-                // a chunk picks at most ROUND * max(copy_num, 2) columns (pseudo_mcmc.rs:421,527,532): size the
-                // LDS work area for the batch, so that two chunks share a CU whenever they can
-                std::min<uint32_t>(JTK_MAX_DIM, 3u * std::max<uint32_t>(s->max_copy, 2u)), s->max_copy,
-                s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr, s->d_order.as<uint32_t>());
+    int mcmc_rc = 0;
+    for (const ChainClass &cc : s->chain_class) {
+        if (cc.count == 0 || mcmc_rc != 0) continue;
+        mcmc_rc = launch_mcmc(st, cc.count, chunks, state, s->d_params.as<jtk_lc_params_t>(), s->d_feat.as<double>(),
+                              s->d_vtype.as<uint32_t>(), nullptr, 0, s->d_label.as<uint32_t>(), s->d_post.as<double>(),
+                              s->post_stride, s->d_lg.as<double>(), s->d_lg_off.as<uint64_t>(), cc.lds_n, cc.lds_d, cc.lds_k,
+                              s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr, s->d_order.as<uint32_t>() + cc.first);
+    }
     tstop(s);
     if (mcmc_rc != 0) {
         (void)hipStreamSynchronize(st);
@@ -1549,7 +1605,7 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
         cms[c].local_coverage = fc.local_coverage;
         sts[c].dim = fc.dim;
         sts[c].k = 1;
-        if (fc.dim > JTK_MAX_DIM || fc.copy_num > JTK_MAX_COPY) sts[c].status = JTK_ERR_UNSUPPORTED;
+        if (fc.dim > JTK_MAX_DIM || fc.copy_num > JTK_MAX_COPY || fc.n_reads > JTK_MAX_PILEUP) sts[c].status = JTK_ERR_UNSUPPORTED;
         else if (fc.copy_num > post_stride)  // a posterior row holds up to copy_num entries
             return fail(JTK_ERR_INVALID_ARG, "post_stride smaller than a chunk's copy_num");
         vt_off[c] = fc.vt_off;
@@ -1558,8 +1614,8 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
         n_reads += fc.n_reads;
         if (fc.var_off + (uint64_t)fc.n_reads * fc.dim > n_var) n_var = fc.var_off + (uint64_t)fc.n_reads * fc.dim;
         if (fc.vt_off + fc.dim > n_vt) n_vt = fc.vt_off + fc.dim;
-        if (fc.n_reads > max_n) max_n = fc.n_reads;
-        if (fc.dim > max_d) max_d = fc.dim;
+        if (sts[c].status == 0 && fc.n_reads > max_n) max_n = fc.n_reads;
+        if (sts[c].status == 0 && fc.dim > max_d) max_d = fc.dim;
     }
     std::vector<jtk_lc_params_t> pv(1, *params);
     std::vector<double> varv(variants, variants + n_var);

@@ -324,9 +324,10 @@ def test_chain_variants_match_oracle(lib):
 
 def test_large_pileups_match_oracle(lib):
     """more than 255 reads (7 copies x 40 reads, or the first pass of a copy_num >= 8 chunk): the generic chain with its
-    per-read and per-size tables in LDS instead of registers; 256 and 511 are the edges of that mode"""
+    per-read and per-size tables in LDS instead of registers; 256 and 1023 (10-bit read indices) are the edges of that
+    mode, 540 reads is a 9-copy pile-up at 60x"""
     p = jb.default_params(haploid_coverage=40.0)
-    specs = [(256, 4, 2, 2), (300, 6, 3, 3), (511, 3, 2, 2), (255, 4, 3, 3)]   # ~40 s: the generic chain is slow
+    specs = [(256, 4, 2, 2), (300, 6, 3, 3), (511, 3, 2, 2), (255, 4, 3, 3), (540, 6, 4, 4), (1023, 3, 2, 2)]
     dev, ora, truth = run_features_both(p, specs, seed=19)
     assert np.array_equal(dev["result"]["status"], np.zeros(len(specs), np.int32))
     assert np.array_equal(dev["label"], ora["label"])
@@ -334,9 +335,9 @@ def test_large_pileups_match_oracle(lib):
     assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(ora["log_post"]))
     assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(ora["result"]["score"]))
     # one more read than the kernel takes is reported, not mis-clustered
-    x, vt, _ = random_feature_problem(np.random.default_rng(3), 512, 3, 2, 0, 2)
+    x, vt, _ = random_feature_problem(np.random.default_rng(3), 1024, 3, 2, 0, 2)
     ch = np.zeros(1, dtype=ffi.FEATURE_CHUNK_DT)
-    ch[0] = (5, 2, 512, 3, 0, 0, 0, 0, 256.0)
+    ch[0] = (5, 2, 1024, 3, 0, 0, 0, 0, 512.0)
     out = api.cluster_features(p, ch, x.ravel(), vt.ravel().astype(np.uint32), 2, raise_on_chunk_failure=False)
     assert out["rc"] == -6 and out["result"]["status"][0] == -3
 

@@ -311,3 +311,22 @@ def test_multi_device_call_matches_single_device(lib):
     with pytest.raises(ffi.JtkError) as e:
         api.cluster_chunks(p, b, devices=[0, 97])
     assert e.value.status == -2
+
+
+def test_pileup_beyond_511_reads_matches_oracle(lib):
+    """a 9-copy pile-up at 60x (540 reads) next to a diploid one: the big chunk's first pass (K = 4 on 540 reads) runs in the
+    chain kernel's second launch class (LDS work area above 80 KiB), the diploid chunk in the first; both bit-exact"""
+    cfg_big = dict(synth.CONFIGS["ont_4copy"], tmpl_len=260, reads_per_hap=60, n_haps=9, copy_num=9, divergence=2.5e-2)
+    cfg_small = dict(synth.CONFIGS["ont_diploid"], tmpl_len=260, reads_per_hap=12)
+    b = jb.pack([synth.make_pileup(4200, cfg_small), synth.make_pileup(4100, cfg_big, min_variants=3)])
+    p = jb.default_params(haploid_coverage=60.0, band_frac=cfg_big["band_frac"])
+    assert int(b.chunks["n_reads"].max()) == 540
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, n_threads=2)
+    assert ora["rc"] == 0
+    dev = api.cluster_chunks(p, b)
+    assert np.array_equal(dev["result"]["status"], np.zeros(2, np.int32))
+    assert np.array_equal(dev["label"], ora["label"])
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert np.abs(dev["log_post"] - ora["log_post"]).max() < 1e-4
+    n = int(dev["cons_off"][-1])
+    assert np.array_equal(dev["cons_off"], ora["cons_off"]) and bytes(dev["cons"][:n]) == bytes(ora["cons"][:n])
