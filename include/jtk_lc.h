@@ -227,6 +227,15 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks,
 int jtk_lc_estimate_gains(const jtk_hmm_t *forward, const jtk_hmm_t *reverse, uint64_t seed, uint32_t seq_len,
                           uint32_t band, uint32_t homop_len, jtk_gains_t *out, int device);
 
+/* `estimate_minimum_gain(&hmm)` (likelihood_gains.rs:6-39), the scale of correct_clustering's protection rule
+ * (phmm_likelihood_correction.rs:118: min_gain = estimate_minimum_gain(&hmm) * PROTECT_FACTOR).  sample_num templates of
+ * `len` random bases, each with one base deleted (kiley introduce_errors(.., 0, 1, 0)); per template the median over seq_num
+ * simulated reads of lk(read | template) - lk(read | template minus the base) with the banded bootstrap likelihood; the
+ * third smallest median, at least 1.  The reference's constants: seed 23908, 1000, 500, 100, band 25.  Sampling on the
+ * host, alignments and likelihoods on the device (the machinery of jtk_lc_estimate_gains; own specification of kiley). */
+int jtk_lc_estimate_minimum_gain(const jtk_hmm_t *forward, const jtk_hmm_t *reverse, uint64_t seed, uint32_t sample_num,
+                                 uint32_t seq_num, uint32_t len, uint32_t band, double *out, int device);
+
 /* ---- stage preamble: model refit ----------------------------------------------------------------------
  * Replaces `estimate_model_parameters_on_both_strands` (haplotyper/src/model_tune.rs:119-152; entered through
  * `update_models_on_both_strands`, local_clustering/mod.rs:58) on the training pile-ups the host has selected

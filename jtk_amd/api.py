@@ -100,6 +100,14 @@ def estimate_gains(hmm_forward, hmm_reverse, seed=309423, seq_len=100, band=10, 
     return out
 
 
+def estimate_minimum_gain(hmm_forward, hmm_reverse, seed=23908, sample_num=1000, seq_num=500, seq_len=100, band=25, device=0):
+    """jtk_lc_estimate_minimum_gain; the defaults are the reference's constants (likelihood_gains.rs:7-11)."""
+    out = C.c_double(0.0)
+    check(ffi.lib().jtk_lc_estimate_minimum_gain(C.byref(hmm_forward), C.byref(hmm_reverse), seed, sample_num, seq_num, seq_len,
+                                                 band, C.byref(out), device))
+    return out.value
+
+
 def fit_model(params, batch, rounds=10, device=0):
     """jtk_lc_fit_model: the model refit of the stage preamble (model_tune.rs:119-152) on the training pile-ups `batch`;
     returns (forward, reverse)."""

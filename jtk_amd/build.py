@@ -61,15 +61,18 @@ def build(force=False, verbose=False):
     return OUT
 
 
+PROFILED_SOURCES = ["phmm_kernels.hip", "phmm_wide.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip",
+                    "session.hip", "device_common.h"]
+
+
 def source_sha16():
-    """sha256[:16] over the sources the device library is built from (names + contents, sorted): what a profile under
-    profiles/ is tied to -- unlike the .so's own hash it does not depend on where or when hipcc ran."""
+    """sha256[:16] over the sources that determine the profiled kernels and their launches (names + contents + flags): what
+    a profile under profiles/ is tied to -- unlike the .so's own hash it does not depend on where or when hipcc ran, nor
+    on entry points added beside the path."""
     import hashlib
-    files = [os.path.join(CSRC, f) for f in SOURCES]
-    files += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    files += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h")]
+    files = [os.path.join(CSRC, f) for f in PROFILED_SOURCES] + [os.path.join(ROOT, "include", "jtk_math.h")]
     h = hashlib.sha256()
-    for f in sorted(set(files)):
+    for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())

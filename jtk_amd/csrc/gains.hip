@@ -328,9 +328,128 @@ int gain_of(const jtk_lc_params_t &params, uint64_t seed, uint32_t seq_len, uint
     return 0;
 }
 
+// kiley gen_seq::introduce_errors(seq, rng, 0, 1, 0) (likelihood_gains.rs:18), own specification (oracle/likelihood_gains.c
+// introduce_one_deletion): shuffle [Match x (len - 1), Del] with SliceRandom::shuffle, drop the base at the Del's place
+void introduce_one_deletion(Xoshiro &rng, const std::string &seq, std::string &out) {
+    const size_t len = seq.size();
+    size_t del_pos = len - 1;
+    for (size_t i = len - 1; i >= 1; i--) {
+        const size_t j = rng.gen_index((uint32_t)(i + 1));
+        if (del_pos == i)
+            del_pos = j;
+        else if (del_pos == j)
+            del_pos = i;
+    }
+    out = seq;
+    out.erase(del_pos, 1);
+}
+
+// estimate_minimum_gain's samples [s0, s1): medians[s] = median over reads of lk(read | hap1) - lk(read | hap2)
+int minimum_gain_batch(const jtk_lc_params_t &params, uint64_t seed, size_t s0, size_t s1, uint32_t seq_num, uint32_t len,
+                       uint32_t band, int device, double *medians) {
+    const size_t ns = s1 - s0, cap = 3 * (size_t)len + 16;
+    std::vector<std::string> tmpls(2 * ns), reads(ns * seq_num);
+    uint32_t max_len = len;
+    for (size_t i = 0; i < ns; i++) {
+        Xoshiro rng(seed + (uint64_t)(s0 + i));  // likelihood_gains.rs:16
+        generate_seq(rng, len, tmpls[2 * i]);
+        introduce_one_deletion(rng, tmpls[2 * i], tmpls[2 * i + 1]);
+        for (uint32_t t = 0; t < seq_num; t++) {
+            const jtk_hmm_t &h = (t % 2 == 0) ? params.forward : params.reverse;  // :22-25
+            phmm_gen(h, tmpls[2 * i], rng, cap, reads[i * seq_num + t]);
+            max_len = std::max<uint32_t>(max_len, (uint32_t)reads[i * seq_num + t].size());
+        }
+    }
+    if (max_len > EDIT_MAX_LEN) {
+        jtk_internal_set_error("estimate_minimum_gain: simulated sequence longer than 250 bases");
+        return JTK_ERR_UNSUPPORTED;
+    }
+    const size_t n_chunks = 2 * ns, n_reads = n_chunks * seq_num;
+    std::vector<jtk_lc_chunk_t> chunks(n_chunks);
+    std::vector<uint8_t> tb, rb, strand(n_reads);
+    std::vector<uint64_t> roff(1, 0);
+    std::vector<PairMeta> pairs(n_reads);
+    for (size_t c = 0; c < n_chunks; c++) {
+        memset(&chunks[c], 0, sizeof chunks[c]);
+        chunks[c].chunk_id = c;
+        chunks[c].copy_num = 2;
+        chunks[c].n_reads = seq_num;
+        chunks[c].tmpl_off = tb.size();
+        chunks[c].tmpl_len = tmpls[c].size();
+        chunks[c].read_first = c * seq_num;
+        tb.insert(tb.end(), tmpls[c].begin(), tmpls[c].end());
+        for (uint32_t t = 0; t < seq_num; t++) {
+            const std::string &r = reads[(c / 2) * seq_num + t];
+            PairMeta &pm = pairs[c * seq_num + t];
+            pm.tmpl_off = (uint32_t)chunks[c].tmpl_off;
+            pm.tmpl_len = (uint32_t)tmpls[c].size();
+            pm.read_off = (uint32_t)rb.size();
+            pm.read_len = (uint32_t)r.size();
+            rb.insert(rb.end(), r.begin(), r.end());
+            roff.push_back(rb.size());
+            strand[c * seq_num + t] = (t % 2 == 0) ? 1 : 0;
+        }
+    }
+    std::vector<uint8_t> ops_strided;
+    std::vector<uint32_t> ops_len;
+    int rc = device_edit_ops(pairs, tb, rb, max_len, ops_strided, ops_len);
+    if (rc) return rc;
+    std::vector<uint8_t> ops;
+    std::vector<uint64_t> ooff(1, 0);
+    for (size_t g = 0; g < n_reads; g++) {
+        ops.insert(ops.end(), ops_strided.begin() + g * EDIT_OPS_STRIDE, ops_strided.begin() + g * EDIT_OPS_STRIDE + ops_len[g]);
+        ooff.push_back(ops.size());
+    }
+    std::vector<double> lk(n_reads);
+    rc = jtk_internal_likelihoods(&params, n_chunks, chunks.data(), tb.data(), rb.data(), roff.data(), ops.data(), ooff.data(),
+                                  strand.data(), band, device, lk.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < ns; i++) {
+        std::vector<double> d(seq_num);
+        for (uint32_t t = 0; t < seq_num; t++) d[t] = lk[(2 * i) * seq_num + t] - lk[(2 * i + 1) * seq_num + t];
+        medians[i] = nth(d, seq_num / 2);
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+// estimate_minimum_gain (likelihood_gains.rs:6-39): what correct_clustering's protection rule is scaled by
+// (phmm_likelihood_correction.rs:118).  The reference's constants are (23908, 1000, 500, 100, 25).
+int jtk_lc_estimate_minimum_gain(const jtk_hmm_t *forward, const jtk_hmm_t *reverse, uint64_t seed, uint32_t sample_num,
+                                 uint32_t seq_num, uint32_t len, uint32_t band, double *out, int device) {
+    jtk_internal_set_error("");
+    if (!forward || !reverse || !out || sample_num < 3 || seq_num == 0 || len < 2 || len > 200 || band == 0 ||
+        band > JTK_MAX_RADIUS) {
+        jtk_internal_set_error("jtk_lc_estimate_minimum_gain: bad argument (sample_num >= 3, 2 <= len <= 200, 1 <= band <= 30)");
+        return JTK_ERR_INVALID_ARG;
+    }
+    if (!jtk_lc_device_ok(device)) {
+        jtk_internal_set_error("no gfx950 device (jtk_lc has no CPU fallback)");
+        return JTK_ERR_NO_DEVICE;
+    }
+    HIP_OK(hipSetDevice(device));
+    jtk_lc_params_t params;
+    memset(&params, 0, sizeof params);
+    params.forward = *forward;
+    params.reverse = *reverse;
+    params.gains.max_homopolymer_len = 1;  // unused by the likelihood batches
+    params.haploid_coverage = 1.0;
+    params.band_frac = 0.0;
+    std::vector<double> medians(sample_num);
+    // batches of ~100,000 reads keep the likelihood session's workspaces at a few GB
+    const size_t per = std::max<size_t>(1, 50000 / seq_num);
+    for (size_t s0 = 0; s0 < sample_num; s0 += per) {
+        const size_t s1 = std::min<size_t>(sample_num, s0 + per);
+        const int rc = minimum_gain_batch(params, seed, s0, s1, seq_num, len, band, device, medians.data() + s0);
+        if (rc) return rc;
+    }
+    std::sort(medians.begin(), medians.end());
+    *out = std::max(medians[2], 1.0);
+    return 0;
+}
 
 int jtk_lc_estimate_gains(const jtk_hmm_t *forward, const jtk_hmm_t *reverse, uint64_t seed, uint32_t seq_len,
                           uint32_t band, uint32_t homop_len, jtk_gains_t *out, int device) {

@@ -285,8 +285,61 @@ def local_clustering(ds, gains=None, device=0, failed=None, refit=True):
                                      failed=failed, refit=refit)
 
 
+def correct_clustering_selected(ds, selection, device=0, min_gain=None):
+    """AlignmentCorrection::correct_clustering_selected (phmm_likelihood_correction.rs:32-97) on the parsed JSON object `ds`
+    (modified in place): jtk_lc_correct_clustering on the flattened nodes, then the write-back of :80-96.  min_gain defaults
+    to estimate_minimum_gain(model) x PROTECT_FACTOR (:118) computed on the device."""
+    tag, cov = coverage_of(ds)
+    if cov is None:
+        raise ValueError("correct_clustering: coverage is NotAvailable (the reference unwraps it, :154)")
+    if min_gain is None:
+        min_gain = api.estimate_minimum_gain(_hmm(ds["model_param"]["forward"]), _hmm(ds["model_param"]["reverse"]),
+                                             device=device) * 1.0
+    n_nodes = sum(len(r["nodes"]) for r in ds["encoded_reads"])
+    nodes = np.zeros(n_nodes, dtype=ffi.CC_NODE_DT)
+    node_off = np.zeros(len(ds["encoded_reads"]) + 1, dtype=np.uint64)
+    read_id = np.zeros(len(ds["encoded_reads"]), dtype=np.uint64)
+    post = []
+    e = 0
+    for r, read in enumerate(ds["encoded_reads"]):
+        read_id[r] = read["id"]
+        for node in read["nodes"]:
+            nodes[e] = (node["chunk"], node["cluster"], 1 if node["is_forward"] else 0, len(node["posterior"]), len(post))
+            post.extend(float(x) for x in node["posterior"])
+            e += 1
+        node_off[r + 1] = e
+    chunks = np.zeros(len(ds["selected_chunks"]), dtype=ffi.CC_CHUNK_DT)
+    for i, c in enumerate(ds["selected_chunks"]):
+        chunks[i] = (c["id"], c["cluster_num"], c["copy_num"], c["score"])
+    cluster, touched = api.correct_clustering(read_id, node_off, nodes, np.array(post, dtype=np.float64), chunks,
+                                              sorted(int(x) for x in selection), cov, min_gain, device=device)
+    cluster_num = {}
+    for i, c in enumerate(ds["selected_chunks"]):
+        c["cluster_num"] = int(chunks["cluster_num"][i])
+        cluster_num[c["id"]] = c["cluster_num"]
+    e = 0
+    for read in ds["encoded_reads"]:
+        for node in read["nodes"]:
+            if touched[e]:                                           # :85-93
+                node["cluster"] = int(cluster[e])
+                node["posterior"] = [-10000.0] * cluster_num[node["chunk"]]
+                node["posterior"][node["cluster"]] = 0.0
+            e += 1
+
+
+def correct_clustering(ds, device=0, min_gain=None):
+    """AlignmentCorrection::correct_clustering (phmm_likelihood_correction.rs:14-30): chunks no read visits are dropped,
+    every chunk with more than one cluster is corrected."""
+    present = {n["chunk"] for r in ds["encoded_reads"] for n in r["nodes"]}
+    ds["selected_chunks"] = [c for c in ds["selected_chunks"] if c["id"] in present]
+    correct_clustering_selected(ds, [c["id"] for c in ds["selected_chunks"] if 1 < c["cluster_num"]], device=device,
+                                min_gain=min_gain)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--stage", default="local_clustering", choices=("local_clustering", "correct_clustering"),
+                    help="which JTK stage to run on the file (jtk local_clustering / jtk correct_clustering)")
     ap.add_argument("input", help="DataSet JSON ('-' = stdin)")
     ap.add_argument("output", help="DataSet JSON ('-' = stdout)")
     ap.add_argument("--chunks", default="", help="comma-separated chunk ids (local_clustering_selected); default: all")
@@ -299,7 +352,13 @@ def main(argv=None):
     args = ap.parse_args(argv)
     ds = json.load(sys.stdin if args.input == "-" else open(args.input))
     failed = [] if args.keep_going else None
-    if args.chunks:
+    if args.stage == "correct_clustering":
+        validate(ds)
+        if args.chunks:
+            correct_clustering_selected(ds, [int(x) for x in args.chunks.split(",")], device=args.device)
+        else:
+            correct_clustering(ds, device=args.device)
+    elif args.chunks:
         local_clustering_selected(ds, [int(x) for x in args.chunks.split(",")], device=args.device, failed=failed,
                                   refit=not args.no_refit)
     else:

@@ -76,7 +76,7 @@ CC_CHUNK_DT = np.dtype([("id", "<u8"), ("cluster_num", "<u4"), ("copy_num", "<u4
 # every symbol declared in include/jtk_lc.h (tests check the library exports them)
 EXPORTED_SYMBOLS = (
     "jtk_lc_cluster_chunks", "jtk_lc_cluster_chunks_multi", "jtk_lc_cluster_polished", "jtk_lc_polish_chunks", "jtk_lc_modification_table",
-    "jtk_lc_cluster_features", "jtk_lc_estimate_gains", "jtk_lc_fit_model", "jtk_lc_correct_clustering", "jtk_lc_trim_cache", "jtk_lc_pileup_sort_key", "jtk_lc_normalize_pileup", "jtk_lc_strerror",
+    "jtk_lc_cluster_features", "jtk_lc_estimate_gains", "jtk_lc_estimate_minimum_gain", "jtk_lc_fit_model", "jtk_lc_correct_clustering", "jtk_lc_trim_cache", "jtk_lc_pileup_sort_key", "jtk_lc_normalize_pileup", "jtk_lc_strerror",
     "jtk_lc_last_error", "jtk_lc_version", "jtk_lc_device_ok", "jtk_lc_last_timing",
     "jtk_lc_session_create", "jtk_lc_session_run", "jtk_lc_session_fetch", "jtk_lc_session_destroy",
 )
@@ -131,6 +131,7 @@ def lib():
         u64, vp, i32)
     sig("jtk_lc_modification_table", i32, PP, PU8, u64, u32, PU8, PU64, PU8, PU64, PU8, PD, PD, i32)
     sig("jtk_lc_estimate_gains", i32, C.POINTER(Hmm), C.POINTER(Hmm), u64, u32, u32, u32, C.POINTER(Gains), i32)
+    sig("jtk_lc_estimate_minimum_gain", i32, C.POINTER(Hmm), C.POINTER(Hmm), u64, u32, u32, u32, u32, PD, i32)
     sig("jtk_lc_fit_model", i32, PP, sz, vp, PU8, PU8, PU64, PU8, PU64, PU8, u32, C.POINTER(Hmm), C.POINTER(Hmm), i32)
     sig("jtk_lc_correct_clustering", i32, sz, PU64, PU64, vp, PD, sz, vp, sz, PU64, C.c_double, C.c_double, PU64, PU8, i32)
     sig("jtk_lc_trim_cache", i32, i32)

@@ -71,6 +71,9 @@ void jo_pvalues(double prob, size_t n, double *out);
 void jo_estimate_gain(const jtk_hmm_t *fwd, const jtk_hmm_t *rev, uint64_t seed, size_t seq_len,
                       size_t band, size_t homop_len, jtk_gains_t *out);
 void jo_estimate_gain_default(const jtk_hmm_t *fwd, const jtk_hmm_t *rev, jtk_gains_t *out); /* :190 */
+/* likelihood_gains.rs:6-39 (reference constants: seed 23908, 1000 samples, 500 reads, length 100, band 25) */
+double jo_estimate_minimum_gain(const jtk_hmm_t *fwd, const jtk_hmm_t *rev, uint64_t seed, size_t sample_num, size_t seq_num,
+                                size_t len, size_t band, int n_threads);
 
 /* ---------------- pseudo_mcmc.c --------------------------------------------------------------------- */
 typedef struct jo_cluster_config { /* pseudo_mcmc.rs:17-25 */

@@ -180,3 +180,59 @@ void jo_estimate_gain(const jtk_hmm_t *fwd, const jtk_hmm_t *rev, uint64_t seed,
 void jo_estimate_gain_default(const jtk_hmm_t *fwd, const jtk_hmm_t *rev, jtk_gains_t *out) {
     jo_estimate_gain(fwd, rev, 309423, 100, 10, 3, out);
 }
+
+/* kiley gen_seq::introduce_errors(seq, rng, 0, 1, 0) (likelihood_gains.rs:18): kiley is not under /root/reference; OWN
+ * SPECIFICATION after the crate's published source as recalled: the operations [Match x (len - 1), Del x 1] are shuffled
+ * with rand 0.8.5 SliceRandom::shuffle (for i in (1..len).rev(): swap(i, gen_index(i + 1))) and applied in order, so the
+ * base at the Del's final position is dropped.  Parity with kiley unpinned. */
+static size_t introduce_one_deletion(jo_rng_t *rng, const uint8_t *seq, size_t len, uint8_t *out) {
+    size_t del_pos = len - 1;
+    for (size_t i = len - 1; i >= 1; i--) {
+        const size_t j = (size_t)jo_gen_index(rng, i + 1);
+        if (del_pos == i)
+            del_pos = j;
+        else if (del_pos == j)
+            del_pos = i;
+    }
+    size_t p = 0;
+    for (size_t i = 0; i < len; i++)
+        if (i != del_pos) out[p++] = seq[i];
+    return p;
+}
+
+/* estimate_minimum_gain (likelihood_gains.rs:6-39; the reference's constants: seed 23908, 1000 samples x 500 reads of a
+ * 100-base template, band 25, floor 1.0): per sample the median over reads of lk(read | hap1) - lk(read | hap1 minus one
+ * base), reads drawn from hap1; the third smallest of the samples' medians, at least 1. */
+double jo_estimate_minimum_gain(const jtk_hmm_t *fwd, const jtk_hmm_t *rev, uint64_t seed, size_t sample_num, size_t seq_num,
+                                size_t len, size_t band, int n_threads) {
+    if (sample_num < 3 || seq_num == 0 || len < 2) return 0.0 / 0.0; /* medians[2] / lks[SEQ_NUM / 2] out of bounds */
+    double *medians = (double *)malloc(sample_num * sizeof(double));
+    (void)n_threads;
+#pragma omp parallel for schedule(dynamic) num_threads(n_threads > 0 ? n_threads : 1)
+    for (long s = 0; s < (long)sample_num; s++) {
+        jo_rng_t rng;
+        jo_rng_seed_from_u64(&rng, seed + (uint64_t)s);
+        uint8_t *hap1 = (uint8_t *)malloc(len), *hap2 = (uint8_t *)malloc(len);
+        const size_t rcap = 3 * len + 16;
+        uint8_t *read = (uint8_t *)malloc(rcap);
+        double *lks = (double *)malloc(seq_num * sizeof(double));
+        jo_generate_seq(&rng, len, hap1);
+        const size_t l2 = introduce_one_deletion(&rng, hap1, len, hap2);
+        for (size_t t = 0; t < seq_num; t++) {
+            const jtk_hmm_t *h = (t % 2 == 0) ? fwd : rev;
+            const size_t rl = jo_phmm_gen(h, hap1, len, &rng, read, rcap);
+            const double lk_base = jo_phmm_likelihood_bootstrap(h, hap1, len, read, rl, band);
+            const double lk_diff = jo_phmm_likelihood_bootstrap(h, hap2, l2, read, rl, band);
+            lks[t] = lk_base - lk_diff;
+        }
+        medians[s] = nth(lks, seq_num, seq_num / 2);
+        free(hap1);
+        free(hap2);
+        free(read);
+        free(lks);
+    }
+    qsort(medians, sample_num, sizeof(double), cmp_f64);
+    const double m = medians[2];
+    free(medians);
+    return m > 1.0 ? m : 1.0; /* .max(MIN_REQ) */
+}

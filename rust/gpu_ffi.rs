@@ -62,6 +62,8 @@ extern "C" {
         ops_out: *mut u8, ops_out_off: *mut u64, ops_cap: u64, devices: *const c_int, n_devices: usize) -> c_int;
     pub fn jtk_lc_estimate_gains(forward: *const JtkHmm, reverse: *const JtkHmm, seed: u64, seq_len: u32, band: u32,
                                  homop_len: u32, out: *mut JtkGains, device: c_int) -> c_int;   // likelihood_gains.rs:162-192
+    pub fn jtk_lc_estimate_minimum_gain(forward: *const JtkHmm, reverse: *const JtkHmm, seed: u64, sample_num: u32,
+                                        seq_num: u32, len: u32, band: u32, out: *mut f64, device: c_int) -> c_int;  // likelihood_gains.rs:6-39
     // model_tune.rs:119-152 on the training pile-ups the host selected (model_tune.rs:99-118)
     pub fn jtk_lc_fit_model(
         params: *const JtkLcParams, n_chunks: usize, chunks: *const JtkLcChunk,

@@ -176,6 +176,7 @@ def lib():
     sig("jo_fit_mstep", None, C.POINTER(Hmm), PD, C.POINTER(Hmm))
     sig("jo_fit_model", C.c_int, C.POINTER(Params), sz, p, PU8, PU8, C.POINTER(u64), PU8, C.POINTER(u64), PU8, u32,
         C.POINTER(Hmm), C.POINTER(Hmm))
+    sig("jo_estimate_minimum_gain", d, C.POINTER(Hmm), C.POINTER(Hmm), u64, sz, sz, sz, sz, C.c_int)
     sig("jo_correct_clustering", C.c_int, sz, C.POINTER(u64), C.POINTER(u64), p, PD, sz, p, sz, C.POINTER(u64), d, d,
         C.POINTER(u64), PU8, PD, PD)
     sig("jo_rng128pp_seed_from_u64", None, C.POINTER(Rng), u64)

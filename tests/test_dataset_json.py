@@ -157,3 +157,50 @@ def test_json_stage_matches_the_cpp_host_mirror(jtk_lib, tmp_path, n_selected, r
     if refit:
         f = out["model_param"]["forward"]
         assert abs(f["mat_mat"] + f["mat_ins"] + f["mat_del"] - 1.0) < 1e-12 and len(f["ins_emit"]) == 20
+
+
+@pytest.mark.gpu
+def test_json_correct_clustering_stage_matches_the_oracle(jtk_lib, tmp_path):
+    """`python -m jtk_amd.dataset --stage correct_clustering`: local clustering first (so that nodes carry real posteriors),
+    then AlignmentCorrection::correct_clustering (phmm_likelihood_correction.rs:14-97) on the file; the node labels,
+    posteriors and cluster_num it writes equal what oracle/correction.c computes from the same DataSet."""
+    import oracle_ffi as O
+    from jtk_amd import api, ffi
+    ds = synthetic_dataset(5, 220, 8)
+    D.local_clustering(ds, refit=False)
+    before = copy.deepcopy(ds)
+    min_gain = api.estimate_minimum_gain(D._hmm(ds["model_param"]["forward"]), D._hmm(ds["model_param"]["reverse"]))
+    assert min_gain >= 1.0
+    src, dst = tmp_path / "in.json", tmp_path / "out.json"
+    src.write_text(json.dumps(before))
+    assert D.main(["--stage", "correct_clustering", str(src), str(dst)]) == 0
+    after = json.loads(dst.read_text())
+    # the same through the oracle
+    nodes, post, node_off, read_id = [], [], [0], []
+    for read in before["encoded_reads"]:
+        read_id.append(read["id"])
+        for n in read["nodes"]:
+            nodes.append((n["chunk"], n["cluster"], 1 if n["is_forward"] else 0, len(n["posterior"]), len(post)))
+            post.extend(n["posterior"])
+        node_off.append(len(nodes))
+    nodes = np.array(nodes, dtype=ffi.CC_NODE_DT)
+    chunks = np.zeros(len(before["selected_chunks"]), dtype=ffi.CC_CHUNK_DT)
+    for i, c in enumerate(before["selected_chunks"]):
+        chunks[i] = (c["id"], c["cluster_num"], c["copy_num"], c["score"])
+    sel = [c["id"] for c in before["selected_chunks"] if c["cluster_num"] > 1]
+    _, cov = D.coverage_of(before)
+    rc, cluster, touched, _, _ = O.correct_clustering(read_id, node_off, nodes, post, chunks, sel, cov, min_gain)
+    assert rc == 0
+    e = 0
+    k_of = {int(c["id"]): int(c["cluster_num"]) for c in chunks}
+    assert {c["id"]: c["cluster_num"] for c in after["selected_chunks"]} == k_of
+    for rb, ra in zip(before["encoded_reads"], after["encoded_reads"]):
+        for nb, na in zip(rb["nodes"], ra["nodes"]):
+            if touched[e]:
+                want = [-10000.0] * k_of[nb["chunk"]]
+                want[int(cluster[e])] = 0.0
+                assert na["cluster"] == int(cluster[e]) and na["posterior"] == want
+            else:
+                assert na["cluster"] == nb["cluster"] and na["posterior"] == nb["posterior"]
+            e += 1
+    assert touched.any()

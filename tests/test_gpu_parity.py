@@ -90,6 +90,22 @@ def test_estimate_gains_matches_oracle(lib, seed, seq_len, band, homop_len):
             assert d.gain > 0.0 and 1e-9 <= d.prob <= 1.0
 
 
+@pytest.mark.parametrize("seed,sample_num,seq_num,seq_len,band", [(23908, 40, 60, 100, 25), (5, 7, 21, 64, 12)])
+def test_estimate_minimum_gain_matches_oracle(lib, seed, sample_num, seq_num, seq_len, band):
+    """estimate_minimum_gain (likelihood_gains.rs:6-39), the scale of correct_clustering's protection rule: the reference's
+    seed / length / band on a reduced number of samples and reads, and an odd shape; identical bits"""
+    import ctypes as C
+    p = jb.default_params(haploid_coverage=30.0)
+    p.reverse.mat_mat -= 0.01
+    p.reverse.mat_ins += 0.01
+    dev = api.estimate_minimum_gain(p.forward, p.reverse, seed, sample_num, seq_num, seq_len, band)
+    po = helpers.oracle_params(p)
+    ora = O.lib().jo_estimate_minimum_gain(C.byref(po.forward), C.byref(po.reverse), seed, sample_num, seq_num, seq_len, band, 8)
+    assert dev == ora and dev >= 1.0
+    with pytest.raises(ffi.JtkError):
+        api.estimate_minimum_gain(p.forward, p.reverse, seed, 2, seq_num, seq_len, band)
+
+
 def random_feature_problem(rng, n, dim, k_true, cid=0, copy_num=2):
     return helpers.random_feature_problem(rng, n, dim, k_true)
 

@@ -111,3 +111,16 @@ def test_reference_panics_are_reported():
     prob["posteriors"][1] = 0.5
     rc, *_ = run(prob)
     assert rc == -6
+
+
+def test_estimate_minimum_gain_properties():
+    """likelihood_gains.rs:6-39: deterministic in its seed, floored at 1, and for the default ONT-like model a deleted base
+    costs a read a few nats (the third smallest of the per-template medians)"""
+    from jtk_amd import batch as jb
+    from helpers import oracle_params
+    p = oracle_params(jb.default_params(haploid_coverage=30.0))
+    f = lambda seed, n=12: O.lib().jo_estimate_minimum_gain(C.byref(p.forward), C.byref(p.reverse), seed, n, 40, 100, 25, 8)
+    a, b = f(23908), f(23908)
+    assert a == b and a >= 1.0
+    assert 1.0 <= a < 20.0
+    assert np.isnan(O.lib().jo_estimate_minimum_gain(C.byref(p.forward), C.byref(p.reverse), 1, 2, 40, 100, 25, 1))
