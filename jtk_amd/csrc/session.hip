@@ -1151,7 +1151,7 @@ static int run_slice(const jtk_lc_params_t *params, size_t n_chunks, const jtk_l
     return rc;
 }
 
-// The one-shot entry points on a large batch: up to three slices of the batch run as independent sessions on their own streams
+// The one-shot entry points on a large batch: up to four slices of the batch run as independent sessions on their own streams
 // and host threads, so that one slice's pair-HMM passes fill the CUs another slice's chain kernel leaves idle during
 // its tail (the overlap bench.py gets from four resident batches, §6 of DESIGN.md).  Chunks are independent (the RNG
 // is seeded per chunk), so the results do not depend on the slicing.  A slice keeps >= 500 chunks: below that the
@@ -1165,7 +1165,7 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
     // several devices: the same slicing, consecutive slices dealt to consecutive devices (a device's slices overlap
     // each other as on one GPU; devices share nothing)
     if (!devices || n_devices == 0) return fail(JTK_ERR_INVALID_ARG, "no device given");
-    size_t per_dev = std::min<size_t>(3, n_chunks / n_devices / 500);  // 2500 chunks: 2.48 s unsliced, 2.21 / 2.12 s in 2 / 3 slices
+    size_t per_dev = std::min<size_t>(4, n_chunks / n_devices / 500);  // 2500 chunks: 2.08 / 1.80 / 2.08 / 2.17 s in 3 / 4 / 5 / 6 slices
     if (const char *e = getenv("JTK_LC_SLICES")) per_dev = (size_t)atoi(e);
     if (per_dev < 1) per_dev = 1;
     size_t n_slices = per_dev * n_devices;
