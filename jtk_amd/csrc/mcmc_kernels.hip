@@ -2198,10 +2198,15 @@ __device__ __forceinline__ double mcmc_chain_dispatch(const Lds &m, uint32_t n, 
         if (D <= 4) return mcmc_chain_k2<4, true, 2>(km, n, D, cov, &rng, lane);
         return mcmc_chain_k2<8, false, 2>(km, n, D, cov, &rng, lane);
     }
-    if (m.flags & 1u) {  // JTK_MCMC_LEGACY: the one-proposal-per-iteration chain, kept for differential testing
+#ifdef JTK_MCMC_WITH_LEGACY
+    // The one-proposal-per-iteration chain, kept for differential testing (build with -DJTK_MCMC_WITH_LEGACY, run with
+    // JTK_MCMC_LEGACY=1).  Not in the product build: its twelve inlined instantiations alone raise the kernel from 248 to
+    // 354 registers, i.e. from two chain waves per SIMD to one.
+    if (m.flags & 1u) {
         if (n <= 63) return mcmc_chain<K, true>(m, n, D, cov, rng, lane);
         return mcmc_chain<K, false>(m, n, D, cov, rng, lane);
     }
+#endif
     rng_set_parse_mode(rng, (uint32_t)K, lane);
     return mcmc_chain_tab<K>(m, n, D, cov, &rng, lane);
 }
@@ -2288,8 +2293,9 @@ __device__ __forceinline__ bool mcmc_clustering(const Lds &m, uint32_t n, uint32
     return true;
 }
 
+// out of line: one candidate cluster count per call keeps the kernel body (k-means, model selection, posteriors) small
 template <int K>
-__device__ __forceinline__ bool run_k(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score, uint32_t lane) {
+__device__ __attribute__((noinline)) bool run_k(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score, uint32_t lane) {
     return mcmc_clustering<K>(m, n, D, cov, rng, score, lane);
 }
 
@@ -2327,8 +2333,12 @@ __device__ __forceinline__ double gains_expected(const jtk_gains_t *g, uint32_t 
 }
 
 // one workgroup of two waves per chunk: wave 0 runs the algorithm, wave 1 feeds it proposals
+// Register budget: two waves per SIMD (<= 256 registers; the kernel needs 248).  A chain workgroup is two latency-bound waves
+// that leave their SIMDs idle most of the time: at 360 registers (the legacy chain inlined) a chain wave had its SIMD to itself
+// and 625 workgroups shut every other kernel out of the machine; at 248 two of them share a SIMD, or one sits beside a
+// pair-HMM wave of another batch (152 registers) -- bench.py overlaps batches: 1,680 -> 1,820 chunks/s.
 #ifndef JTK_MCMC_WAVES
-#define JTK_MCMC_WAVES 1  // resident waves per SIMD the register budget is set for (2: 256 registers, the rest spills)
+#define JTK_MCMC_WAVES 2
 #endif
 __global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(const ChunkMeta *chunks, ChunkState *state,
                                                   const jtk_lc_params_t *params, const double *feat_all,
@@ -2576,8 +2586,7 @@ __global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(const ChunkMe
 
 }  // namespace
 
-// LDS work area of one chunk.  Two workgroups share a CU as long as each stays under 80 KiB: the producer's jump
-// table (16 KiB) is staged in LDS only when that still holds, larger pile-ups read it from global memory.
+// LDS work area of one chunk (the producer's 16 KiB jump table comes from global memory unless JTK_MCMC_JUMP_LDS is set).
 static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
     const size_t npad = (lds_n + 63u) & ~63u;
@@ -2589,8 +2598,11 @@ static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
 }
 static uint32_t clamp_k(uint32_t lds_k) { return lds_k < 2 ? 2 : (lds_k > JTK_MAX_COPY ? JTK_MAX_COPY : lds_k); }
 static bool mcmc_jump_in_lds(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
-    static const bool never = getenv("JTK_MCMC_JUMP_GLOBAL") != nullptr;  // experiment: what the 16 KiB are worth to the other kernels
-    return !never && mcmc_lds_core(lds_n, lds_d, lds_k) + JUMP_TAB_BYTES <= 80 * 1024;
+    // The producer's 16 KiB jump table is read from global memory (L2-resident: every workgroup reads the same table) unless
+    // JTK_MCMC_JUMP_LDS asks for a per-workgroup copy: the copy makes the serial chain no faster (the producer has slack) and
+    // costs the kernels that overlap with it 16 KiB of LDS per chunk: 1,823 -> 1,893 chunks/s without it.
+    static const bool in_lds = getenv("JTK_MCMC_JUMP_LDS") != nullptr;
+    return in_lds && mcmc_lds_core(lds_n, lds_d, lds_k) + JUMP_TAB_BYTES <= 80 * 1024;
 }
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
     lds_k = clamp_k(lds_k);

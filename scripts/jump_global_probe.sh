@@ -8,6 +8,6 @@ for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); print('$1', round(d['value'], 1), 'chunks/s', round(d['ms_per_step'], 1), 'ms/step', {k: round(v) for k, v in d['roofline']['serial_pass']['kernel_ms'].items()})
 "; }
-python bench.py --no-cpu-baseline --no-e2e --steps 6 2>/dev/null | show lds
-JTK_MCMC_JUMP_GLOBAL=1 python bench.py --no-cpu-baseline --no-e2e --steps 6 2>/dev/null | show global
-JTK_MCMC_JUMP_GLOBAL=1 python bench.py --no-cpu-baseline --no-e2e --steps 6 --streams 6 2>/dev/null | show global6
+JTK_MCMC_JUMP_LDS=1 python bench.py --no-cpu-baseline --no-e2e --steps 6 2>/dev/null | show lds
+python bench.py --no-cpu-baseline --no-e2e --steps 6 2>/dev/null | show global
+python bench.py --no-cpu-baseline --no-e2e --steps 6 --streams 6 2>/dev/null | show global6

@@ -17,6 +17,8 @@ with api.Session(p, b) as s:
 print("MCMCMS", t["kernel_ms"]["mcmc"], "k", r["result"]["cluster_num"].tolist(), "D", r["result"]["n_variants"].tolist())
 PY
 python3 /tmp/tabrun.py 8 2>&1 | grep MCMCMS
+# the legacy chain is not in the product build: build it in (one register-hungry wave per SIMD), run, rebuild
+JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_WITH_LEGACY -DJTK_MCMC_WAVES=1" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
 JTK_MCMC_LEGACY=1 python3 /tmp/tabrun.py 8 2>&1 | grep MCMCMS
 JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_STATS" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
 python3 /tmp/tabrun.py 2 > gpurun_out/tabstat_raw.txt 2>&1
