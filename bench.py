@@ -132,6 +132,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the one-shot (host buffers in, host buffers out) timing")
     args = ap.parse_args()
+    # the bench process owns its GPU: let the library keep the workspaces of a finished one-shot call for the next one
+    # (default 32 GB so that it cannot starve other users of the device in a shared process; a 2500-chunk call needs ~95 GB)
+    os.environ.setdefault("JTK_LC_POOL_GB", "160")
+    # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue run in order: a
+    # slice's 300 ms chain kernel would hold up another slice's pair-HMM launches.  One queue per slice (+ torch's streams).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, args.streams + 2)))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,9 +160,6 @@ def main():
     elif rank == 0 and jbuild.is_stale():
         sys.stderr.write("bench.py: WARNING: a source is newer than libjtk_lc.so; timing the library as built "
                          "(run __graft_entry__.build() first)\n")
-    # the bench process owns its GPU: let the library keep the workspaces of a finished one-shot call for the next one
-    # (default 32 GB so that it cannot starve other users of the device in a shared process; a 2500-chunk call needs ~95 GB)
-    os.environ.setdefault("JTK_LC_POOL_GB", "160")
     sha = lib_sha16()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU (torch sees none)")
