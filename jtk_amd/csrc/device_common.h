@@ -9,6 +9,7 @@
 #define JTK_WAVE 64
 #define JTK_MAX_RADIUS 30        // 2r+1 <= 61 lanes: 3 spare lanes make the lane ring unambiguous (phmm_kernel)
 #define JTK_WIDE_MAX_RADIUS 127  // wider bands (CLR / None reads, long ONT chunks) take phmm_wide_kernel
+#define JTK_PAIR_MAX_RADIUS 14   // 2r+1 <= 29 cells + 3 spare lanes fit a 32-lane half: phmm_pair_kernel runs two reads per wave
 #define JTK_SCALE_BLOCK 64       // one power-of-two exponent per 64 anti-diagonals (oracle/phmm.c)
 #define JTK_ACC_N 16             // accumulators per template row (see phmm_kernels.hip)
 #define JTK_LOG_ZERO (-1.0e300)
@@ -99,7 +100,14 @@ void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const C
                  const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta,
                  const HmmDev *hmm2, double *scratch, uint64_t scratch_stride, uint32_t n_waves,
                  uint32_t *work_counter, double *raw, int *rawG, double *lk, uint32_t max_tmpl,
-                 uint32_t max_read, int only_active);
+                 uint32_t max_read, int only_active, uint32_t skip_le_radius = 0);
+// phmm_pair.hip: the same sweep for band radius <= JTK_PAIR_MAX_RADIUS, two reads of a chunk per wave.  items[q] = index of
+// the first read of the pair, bit 31 set when the item is a single read; phmm_kernel is then told to skip those chunks.
+size_t phmm_pair_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
+void launch_phmm_pair(hipStream_t s, uint32_t n_items, const uint32_t *items, const ReadMeta *reads, const ChunkMeta *chunks,
+                      const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
+                      double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *raw, int *rawG,
+                      double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active);
 void launch_finalize(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                      const ChunkState *state, const HmmDev *hmm2, const double *raw, const int *rawG,
                      const double *lk, double *table, uint32_t max_tmpl, int only_active);

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(
                                                   const HmmDev *hmm2, double *scratch_all,
                                                   uint64_t scratch_stride, uint32_t *work_counter, double *raw_all,
                                                   int *rawG_all, double *lk_all, uint32_t lds_tmpl,
-                                                  uint32_t lds_read, int only_active) {
+                                                  uint32_t lds_read, int only_active, uint32_t skip_le_radius) {
     extern __shared__ __align__(16) unsigned char smem[];
     // LDS carve: ring [8][RW] double2 | eM[16] | eI[20] | delta words | block exponents | template codes | read codes
     // A ring slot holds the 64 lanes at entries 4..67 plus copies of lanes 60..63 in front and of lanes 0..1 behind,
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(
         if (only_active && !st.active) continue;
         if (cm.take_num && item - cm.read_first >= cm.take_num) continue;  // this read does not vote (its ops are still re-threaded)
         if (cm.radius > JTK_MAX_RADIUS) continue;                          // phmm_wide_kernel's read
+        if (cm.radius <= skip_le_radius) continue;                         // phmm_pair_kernel's read
         const int L = (int)st.tmpl_len, n = (int)rm.read_len, T = L + n, r = (int)cm.radius;
         const HmmDev *h = hmm2 + (rm.strand ? 0 : 1);
         const uint64_t *delta = delta_all + rm.delta_off;
@@ -601,13 +602,13 @@ void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const C
                  const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta,
                  const HmmDev *hmm2, double *scratch, uint64_t scratch_stride, uint32_t n_waves,
                  uint32_t *work_counter, double *raw, int *rawG, double *lk, uint32_t max_tmpl,
-                 uint32_t max_read, int only_active) {
+                 uint32_t max_read, int only_active, uint32_t skip_le_radius) {
     if (n_reads == 0) return;
     hipMemsetAsync(work_counter, 0, sizeof(uint32_t), s);
     const size_t lds = phmm_lds_bytes(max_tmpl, max_read);
     phmm_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch,
                                          scratch_stride, work_counter, raw, rawG, lk, max_tmpl, max_read,
-                                         only_active);
+                                         only_active, skip_le_radius);
 }
 
 void launch_finalize(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,

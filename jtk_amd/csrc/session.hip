@@ -176,6 +176,8 @@ struct jtk_lc_session {
     uint32_t n_chunks = 0, n_reads = 0, post_stride = 1;
     uint32_t max_tmpl = 0, max_read = 0, max_n = 0, max_copy = 0, n_waves = 0;
     ChainClass chain_class[2];  // the chain kernel's launches (by LDS need), as ranges of d_order
+    uint32_t n_pair_items = 0, n_pair_waves = 0;  // phmm_pair_kernel: chunks with band radius <= JTK_PAIR_MAX_RADIUS
+    DevPtr d_pair_items;
     uint64_t scratch_stride = 0;
     bool features_only = false;
     std::vector<ChunkMeta> h_chunks;
@@ -578,6 +580,33 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         s->scratch_stride = (uint64_t)(s->max_tmpl + s->max_read + 8) * 64 * 2;  // doubles
         if ((rc = dev_alloc<double>(s->d_scratch, s->scratch_stride * s->n_waves))) return rc;
     }
+    {  // narrow bands: two reads of a chunk per wave (phmm_pair.hip); JTK_PHMM_PAIR=0 keeps them on phmm_kernel
+        static const bool pair_on = []() {
+            const char *e = getenv("JTK_PHMM_PAIR");
+            return !(e && e[0] == '0');
+        }();
+        std::vector<uint32_t> items;
+        if (pair_on)
+            for (size_t c = 0; c < n_chunks; c++) {
+                const ChunkMeta &cm = s->h_chunks[c];
+                if (cm.radius > JTK_PAIR_MAX_RADIUS || s->h_state0[c].status != 0) continue;
+                const uint32_t voters = cm.take_num ? std::min(cm.take_num, cm.n_reads) : cm.n_reads;
+                for (uint32_t r = 0; r + 1 < voters; r += 2) items.push_back(cm.read_first + r);
+                if (voters & 1u) items.push_back((cm.read_first + voters - 1) | 0x80000000u);
+            }
+        s->n_pair_items = (uint32_t)items.size();
+        if (s->n_pair_items) {
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, device));
+            const size_t pl = phmm_pair_lds_bytes(s->max_tmpl, s->max_read);
+            if (pl > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "template + reads too long for the LDS staging of phmm_pair_kernel");
+            uint32_t per_cu = (uint32_t)((160u * 1024u) / pl);
+            if (per_cu > 8) per_cu = 8;  // two waves per SIMD by registers
+            s->n_pair_waves = std::min<uint32_t>(std::min<uint32_t>(s->n_pair_items, (uint32_t)prop.multiProcessorCount * per_cu),
+                                                 s->n_waves);  // shares phmm_kernel's scratch stripes (launched after it)
+            if ((rc = dev_upload(s, s->d_pair_items, items))) return rc;
+        }
+    }
     if (s->n_wide_reads) {
         const size_t wl = phmm_wide_lds_bytes(s->max_tmpl, s->max_read);
         if (wl > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "template + read too long for the LDS staging of phmm_wide_kernel");
@@ -661,7 +690,12 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
         launch_phmm(st, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(),
                     hmm2, s->d_scratch.as<double>(), s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(),
                     s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read,
-                    only_active);
+                    only_active, s->n_pair_items ? JTK_PAIR_MAX_RADIUS : 0);
+        if (s->n_pair_items)
+            launch_phmm_pair(st, s->n_pair_items, s->d_pair_items.as<uint32_t>(), reads, chunks, state, s->bufs,
+                             s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), hmm2, s->d_scratch.as<double>(), s->scratch_stride,
+                             s->n_pair_waves, s->d_counter.as<uint32_t>(), s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                             s->d_lk.as<double>(), s->max_tmpl, s->max_read, only_active);
         if (s->n_wide_reads)
             launch_phmm_wide(st, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(),
                              hmm2, s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves,
