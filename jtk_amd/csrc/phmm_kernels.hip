@@ -315,10 +315,11 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(
 #endif
         };
         // ring: P_{T+2} (nothing) .. P_{T-4}; queue: pq[s & (PF-1)] = P_s for the next PF below
+        // the wrapped copies without exec-mask branches: lanes 0..1 / 60..63 write their copy, the others their own entry again
+        const int wrap_off = lane < 2 ? 64 : (lane >= 60 ? -64 : 0);
         auto ring_put_at = [&](double2 *e, double2 v) __attribute__((always_inline)) {  // e: the lane's entry of a slot
             e[0] = v;
-            if (lane < 2) e[64] = v;
-            if (lane >= 60) e[-64] = v;
+            e[wrap_off] = v;
         };
         auto ring_put = [&](int slot, double2 v) __attribute__((always_inline)) { ring_put_at(ring + slot * RW + lane + 4, v); };
         // Ring entries are kept in the scale of the block of the step that reads them: a pair enters multiplied by the

@@ -247,10 +247,10 @@ __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, cons
         }
         auto load_pair = [&](int ss) -> double2 { return ss >= 0 ? scratch[(uint64_t)ss * 64 + lane] : make_double2(0.0, 0.0); };
         double2 *ring_me = ring + hb * PR_RW + l32 + 4;  // this lane's entry of slot 0
+        const int wrap_off = l32 < 2 ? 32 : (l32 >= 28 ? -32 : 0);  // the wrapped copy, or the lane's own entry again
         auto ring_put_at = [&](double2 *e, double2 v) __attribute__((always_inline)) {
             e[0] = v;
-            if (l32 < 2) e[32] = v;
-            if (l32 >= 28) e[-32] = v;
+            e[wrap_off] = v;
         };
         auto ring_put = [&](int slot, double2 v) __attribute__((always_inline)) { ring_put_at(ring_me + slot * PR_SLOT, v); };
         auto rel = [&](int d, int blk) -> double {  // 2^(EF[block of diagonal d] - EF[blk]) of this half
