@@ -11,6 +11,7 @@
 #define JTK_WIDE_MAX_RADIUS 127  // wider bands (CLR / None reads, long ONT chunks) take phmm_wide_kernel
 #define JTK_PAIR_MAX_RADIUS 14   // 2r+1 <= 29 cells + 3 spare lanes fit a 32-lane half: phmm_pair_kernel runs two reads per wave
 #define JTK_SCALE_BLOCK 64       // one power-of-two exponent per 64 anti-diagonals (oracle/phmm.c)
+#define JTK_SCRATCH_GUARD 16     // zero rows in front of a wave's forward stripe (phmm_kernel reads pairs of diagonals >= -13)
 #define JTK_ACC_N 16             // accumulators per template row (see phmm_kernels.hip)
 #define JTK_LOG_ZERO (-1.0e300)
 #define JTK_LN2 0.6931471805599453094

@@ -137,11 +137,11 @@ __global__ void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const 
 #endif
 #define RW 72   // entries per ring slot: 64 lanes + 4 wrapped copies in front + 2 behind (rounded up)
 
-// Register budget: 152 per wave instead of the 168 that three waves per SIMD allow.  The chain kernel's waves hold 360
-// registers each; a SIMD that hosts one has 152 left, and with this cap a pair-HMM wave of another batch still fits beside
-// it (bench.py overlaps batches).  On gfx90a+ the attribute counts the unified file in halves, hence 76.
+// Register budget: the 168 that three waves per SIMD allow (the attribute counts the unified file of gfx90a+ in halves,
+// hence 84).  A chain wave holds 248 registers, so a SIMD that hosts one still takes a pair-HMM wave of another batch
+// beside it (bench.py overlaps batches); while the chain kernel needed 360 this kernel was capped at 152 for that.
 #ifndef JTK_PHMM_NUM_VGPR
-#define JTK_PHMM_NUM_VGPR 76
+#define JTK_PHMM_NUM_VGPR 84
 #endif
 __global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(JTK_PHMM_NUM_VGPR))) void phmm_kernel(uint32_t n_reads, const ReadMeta *reads,
                                                   const ChunkMeta *chunks, const ChunkState *state,
@@ -163,7 +163,10 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(
     uint8_t *s_xs = reinterpret_cast<uint8_t *>(s_EF + n_blk);  // s_xs[PAD + i - 1] = 32 * code(x[i-1]): row of eM in bytes
     uint8_t *s_ey = s_xs + ((lds_tmpl + 2 * PAD + 15) & ~15u);    // s_ey[PAD + j] = 8 * ey[j]: entry of eI in bytes
     const int lane = threadIdx.x;
-    double2 *scratch = reinterpret_cast<double2 *>(scratch_all + (uint64_t)blockIdx.x * scratch_stride);
+    // the stripe starts with JTK_SCRATCH_GUARD rows of zeros: "the pair of a diagonal below 0" is then an ordinary load
+    double2 *scratch = reinterpret_cast<double2 *>(scratch_all + (uint64_t)blockIdx.x * scratch_stride) + JTK_SCRATCH_GUARD * 64;
+#pragma unroll
+    for (int g = 1; g <= JTK_SCRATCH_GUARD; g++) scratch[-g * 64 + lane] = make_double2(0.0, 0.0);
 
     for (;;) {
         uint32_t item = 0;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(
 #ifdef JTK_PHMM_EXPERIMENT_NOLOAD
             return make_double2(1e-3 * ss, 0.5);
 #else
-            return ss >= 0 ? scratch[(uint64_t)ss * 64 + lane] : make_double2(0.0, 0.0);
+            return scratch[(int64_t)ss * 64 + lane];  // ss >= -JTK_SCRATCH_GUARD
 #endif
         };
         // ring: P_{T+2} (nothing) .. P_{T-4}; queue: pq[s & (PF-1)] = P_s for the next PF below
@@ -337,9 +340,15 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(
             v.y *= rel(ss, T >> 6);
             ring_put(ss & 7, v);
         }
-        double2 pq[JTK_PHMM_PF];
+        // The pairs of a group of four diagonals are loaded as one batch a whole group ahead (pqY) and handed over at the
+        // group's end (pq = pqY): the flush's conditional stores make the compiler wait for EVERY outstanding load
+        // (s_waitcnt vmcnt(0)) wherever a loaded register is used; with one load per step each load had a single step to
+        // arrive -- a batch issued after the group's first use has four.  pq[idx] holds the pair P_s of the current group
+        // with s == idx (mod 4).
+        auto s_of = [&](int tb, int idx) -> int { return tb - 5 - ((2 - idx) & 3); };  // the s in {tb-8 .. tb-5} with s == idx (mod 4)
+        double2 pq[JTK_PHMM_PF], pqY[JTK_PHMM_PF];
 #pragma unroll
-        for (int q = 0; q < JTK_PHMM_PF; q++) pq[q] = load_pair((T - 5) - (((T - 5) - q) & (JTK_PHMM_PF - 1)));
+        for (int q = 0; q < JTK_PHMM_PF; q++) pq[q] = load_pair(s_of(T | 3, q));
         int delta_next = 0;  // c[t+1] - c[t]
         int EFcur = __builtin_amdgcn_readfirstlane(s_EF[T >> 6]);  // forward exponent of the block the sweep is in (scalar)
         const double2 *ring_me = ring + lane + 4;  // source row i+k: entry ring_me[k] of its slot
@@ -391,7 +400,6 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(
                 }
                 ring_put_at(entry(-5), v);
             }
-            pq[pq_idx] = load_pair(t - 5 - JTK_PHMM_PF);
             // (1) backward values of this diagonal
             double vm, vi, vd;
             if (t == T) {
@@ -492,10 +500,16 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(
         if (t <= T) step(t, std::integral_constant<int, (u)>{}, std::integral_constant<int, (2 - (u)) & 3>{}); \
     }
             GROUP_STEP(0)
+            // the next group's pairs, issued right after this group's first use of a loaded pair: that use is where the
+            // compiler waits for everything outstanding, so these loads are not waited for until the next group
+#pragma unroll
+            for (int q = 0; q < JTK_PHMM_PF; q++) pqY[q] = load_pair(s_of(tb, q) - 4);
             GROUP_STEP(1)
             GROUP_STEP(2)
             GROUP_STEP(3)
 #undef GROUP_STEP
+#pragma unroll
+            for (int q = 0; q < JTK_PHMM_PF; q++) pq[q] = pqY[q];
         }
         // rows still in the band after t == 0
         {

@@ -81,7 +81,10 @@ __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, cons
     const uint32_t xs_bytes = (lds_tmpl + 2 * PR_PAD + 15) & ~15u, ey_bytes = (lds_read + 1 + 2 * PR_PAD + 15) & ~15u;
     uint8_t *s_ey = s_xs + xs_bytes;  // [2][ey_bytes]
     const int lane = threadIdx.x, hb = lane >> 5, l32 = lane & 31;
-    double2 *scratch = reinterpret_cast<double2 *>(scratch_all + (uint64_t)blockIdx.x * scratch_stride);
+    // the stripe starts with JTK_SCRATCH_GUARD rows of zeros: "the pair of a diagonal below 0" is then an ordinary load
+    double2 *scratch = reinterpret_cast<double2 *>(scratch_all + (uint64_t)blockIdx.x * scratch_stride) + JTK_SCRATCH_GUARD * 64;
+#pragma unroll
+    for (int g = 1; g <= JTK_SCRATCH_GUARD; g++) scratch[-g * 64 + lane] = make_double2(0.0, 0.0);
     // this half's views
     const unsigned char *t_eM = s_tab + hb * 36 * 8, *t_eI = t_eM + 16 * 8;
     uint64_t *h_delta = s_delta + hb * n_blk;
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, cons
             if (tt >= 1) cc -= dbit(tt);
             c5 = cc;
         }
-        auto load_pair = [&](int ss) -> double2 { return ss >= 0 ? scratch[(uint64_t)ss * 64 + lane] : make_double2(0.0, 0.0); };
+        auto load_pair = [&](int ss) -> double2 { return scratch[(int64_t)ss * 64 + lane]; };  // ss >= -JTK_SCRATCH_GUARD
         double2 *ring_me = ring + hb * PR_RW + l32 + 4;  // this lane's entry of slot 0
         const int wrap_off = l32 < 2 ? 32 : (l32 >= 28 ? -32 : 0);  // the wrapped copy, or the lane's own entry again
         auto ring_put_at = [&](double2 *e, double2 v) __attribute__((always_inline)) {
@@ -264,9 +267,11 @@ __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, cons
             v.y *= rel(ss, Tmax >> 6);
             ring_put(ss & 7, v);
         }
-        double2 pq[PR_PF];
+        // one batch of loads per group of four diagonals, a group ahead (see phmm_kernel)
+        auto s_of = [&](int tb, int idx) -> int { return tb - 5 - ((2 - idx) & 3); };
+        double2 pq[PR_PF], pqY[PR_PF];
 #pragma unroll
-        for (int qq = 0; qq < PR_PF; qq++) pq[qq] = load_pair((Tmax - 5) - (((Tmax - 5) - qq) & (PR_PF - 1)));
+        for (int qq = 0; qq < PR_PF; qq++) pq[qq] = load_pair(s_of(Tmax | 3, qq));
         int delta_next = 0;
         int EFcur = h_EF[Tmax >> 6];
         double2 *half[2] = {ring_me, ring_me + 4 * PR_SLOT};
@@ -310,7 +315,6 @@ __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, cons
                 }
                 ring_put_at(entry(-5), v);
             }
-            pq[pq_idx] = load_pair(t - 5 - PR_PF);
             double vm, vi, vd;
             {
                 const double xm = rot32_from_next(hM_2), xd = rot32_from_next(bD_1), xi = hI_1;
@@ -402,10 +406,14 @@ __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, cons
         if (t <= Tmax) step(t, std::integral_constant<int, (u)>{}, std::integral_constant<int, (2 - (u)) & 3>{}); \
     }
             PR_GROUP_STEP(0)
+#pragma unroll
+            for (int qq = 0; qq < PR_PF; qq++) pqY[qq] = load_pair(s_of(tb, qq) - 4);
             PR_GROUP_STEP(1)
             PR_GROUP_STEP(2)
             PR_GROUP_STEP(3)
 #undef PR_GROUP_STEP
+#pragma unroll
+            for (int qq = 0; qq < PR_PF; qq++) pq[qq] = pqY[qq];
         }
         {
             const int lo = c - r, off = (l32 - lo) & 31, i = lo + off;

@@ -577,7 +577,7 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         const uint32_t want = (uint32_t)prop.multiProcessorCount * per_cu;
         s->n_waves = n_reads < want ? (uint32_t)n_reads : want;
         if (s->n_waves == 0) s->n_waves = 1;
-        s->scratch_stride = (uint64_t)(s->max_tmpl + s->max_read + 8) * 64 * 2;  // doubles
+        s->scratch_stride = (uint64_t)(s->max_tmpl + s->max_read + 8 + JTK_SCRATCH_GUARD) * 64 * 2;  // doubles
         if ((rc = dev_alloc<double>(s->d_scratch, s->scratch_stride * s->n_waves))) return rc;
     }
     {  // narrow bands: two reads of a chunk per wave (phmm_pair.hip); JTK_PHMM_PAIR=0 keeps them on phmm_kernel
