@@ -30,8 +30,9 @@ void jo_rng_seed_from_u64(jo_rng_t *rng, uint64_t seed) {
 
 /* rand_xoshiro 0.6.0 Xoroshiro128PlusPlus (phmm_likelihood_correction.rs:295-296): seed_from_u64 fills the two state words
  * from SplitMix64 like every generator of the crate; next_u64 = rotl(s0 + s1, 17) + s0, then s1 ^= s0,
- * s0 = rotl(s0, 49) ^ s1 ^ (s1 << 21), s1 = rotl(s1, 28); next_u32 = the LOW half of next_u64 (recalled from the crate's
- * source, which is not under /root/reference: unpinned). */
+ * s0 = rotl(s0, 49) ^ s1 ^ (s1 << 21), s1 = rotl(s1, 28) -- pinned by the reference implementation's known-answer vector for
+ * state (1, 2) (tests/test_oracle_correction.py); next_u32 = the LOW half of next_u64 (recalled from the crate's source,
+ * which is not under /root/reference: that choice is unpinned). */
 void jo_rng128pp_seed_from_u64(jo_rng_t *rng, uint64_t seed) {
     uint64_t x = seed;
     rng->s[0] = jo_splitmix64_next(&x);
