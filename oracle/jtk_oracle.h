@@ -218,6 +218,10 @@ int jo_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl, ui
 double jo_exp(double x);
 double jo_log(double x);
 
+/* test hooks (correction.c): include/jtk_eigen.h and misc.rs adjusted_rand_index :22-46 as the correction uses them */
+void jo_symmetric_eigen(double *a, size_t n, double *v);
+double jo_adjusted_rand_index(const size_t *label, const size_t *pred, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,450 @@
+"""The pinning kit's Python half.  rust/dump_golden.rs (run by a jtk maintainer inside ban-m/jtk with the real crates) turns
+tests/golden/reference/inputs.json into tests/golden/reference/reference_golden.json; `oracle_dump` produces the SAME
+structure from this repository's CPU oracle and `device_dump` the device's share of it through the C ABI; `compare` lists
+where two dumps differ.  tests/test_reference_golden.py drives them.  Every f64 travels as its bit pattern."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+import oracle_ffi as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(HERE, "golden", "reference")
+INPUTS = os.path.join(REF_DIR, "inputs.json")
+GOLDEN = os.path.join(REF_DIR, "reference_golden.json")
+OPS = "=XID"
+DRAWS = 1000
+DIFF = "SDI"  # Display of likelihood_gains::DiffType, in jtk_diff_type order
+
+
+def bits(x):
+    return int(np.float64(x).view(np.uint64))
+
+
+def bits_vec(xs):
+    return [int(v) for v in np.ascontiguousarray(xs, dtype=np.float64).view(np.uint64).ravel()]
+
+
+def unbits(xs):
+    return np.array(xs, dtype=np.uint64).view(np.float64)
+
+
+def load_inputs():
+    return json.load(open(INPUTS))
+
+
+def to_hmm(d):
+    h = O.Hmm()
+    for k in ("mat_mat", "mat_ins", "mat_del", "ins_mat", "ins_ins", "ins_del", "del_mat", "del_ins", "del_del"):
+        setattr(h, k, d[k])
+    for i in range(16):
+        h.mat_emit[i] = d["mat_emit"][i]
+    for i in range(20):
+        h.ins_emit[i] = d["ins_emit"][i]
+    return h
+
+
+def hmm_json(h):
+    return dict(trans=bits_vec([getattr(h, k) for k in ("mat_mat", "mat_ins", "mat_del", "ins_mat", "ins_ins", "ins_del", "del_mat",
+                                                         "del_ins", "del_del")]),
+                mat_emit=bits_vec(list(h.mat_emit)), ins_emit=bits_vec(list(h.ins_emit)))
+
+
+def gains_display(g):
+    """impl Display for Gains (likelihood_gains.rs:63-76): three lines of tab-joined "{gain:.0},{prob:.2}" """
+    rows = []
+    for arr in (g.subst, g.deletions, g.insertions):
+        rows.append("\t".join("%.0f,%.2f" % (arr[i].gain, arr[i].prob) for i in range(g.max_homopolymer_len)))
+    return "\n".join(rows)
+
+
+def gains_from_dump(section):
+    """The Gains a dump ran with: the nine exact `expected` gains + the probabilities recovered from the Display string (a
+    probability is a count of 50 simulations / 50, floored at 1e-9: likelihood_gains.rs:302-314, so {:.2} loses nothing)."""
+    g = O.Gains()
+    g.max_homopolymer_len = 3
+    arrs = (g.subst, g.deletions, g.insertions)
+    for e in section["gains_expected"]:
+        arrs[e["type"]][e["homop"] - 1].gain = float(unbits([e["gain"]])[0])
+    for t, line in enumerate(section["gains_display"].split("\n")):
+        for h, item in enumerate(line.split("\t")):
+            p = round(float(item.split(",")[1]) * 50) / 50
+            arrs[t][h].prob = max(p, 1e-9)
+    return g
+
+
+def _rng(seed, kind=0):
+    r = O.Rng()
+    (O.lib().jo_rng128pp_seed_from_u64 if kind else O.lib().jo_rng_seed_from_u64)(C.byref(r), seed)
+    return r
+
+
+def dump_rng(inp):
+    L = O.lib()
+    out = []
+    for seed in inp["seeds"]:
+        r = _rng(seed)
+        next_u64 = [L.jo_rng_next_u64(C.byref(r)) for _ in range(16)]
+        r = _rng(seed)
+        next_u32 = [L.jo_rng_next_u32(C.byref(r)) for _ in range(16)]
+        gen_range, gen_bool, choose, slice_choose, weighted = [], [], [], [], []
+        for n in inp["ranges"]:
+            r = _rng(seed)
+            xs = [L.jo_gen_range_usize(C.byref(r), n) for _ in range(DRAWS)]
+            gen_range.append(dict(n=n, draws=xs, next=L.jo_rng_next_u64(C.byref(r))))
+        for p in inp["bools"]:
+            r = _rng(seed)
+            xs = [L.jo_gen_bool(C.byref(r), p) for _ in range(DRAWS)]
+            gen_bool.append(dict(p=bits(p), draws=xs, next=L.jo_rng_next_u64(C.byref(r))))
+        for k in inp["choose_k"]:
+            r = _rng(seed)
+            xs = [L.jo_choose_other(C.byref(r), k, t % k) for t in range(DRAWS)]
+            choose.append(dict(k=k, draws=xs, next=L.jo_rng_next_u64(C.byref(r))))
+        for n in inp["slice_len"]:
+            r = _rng(seed)
+            xs = [L.jo_gen_index(C.byref(r), n) for _ in range(DRAWS)]  # SliceRandom::choose = self[gen_index(rng, len)]
+            slice_choose.append(dict(n=n, draws=xs, next=L.jo_rng_next_u64(C.byref(r))))
+        for wb in inp["weights"]:
+            w = unbits(wb).copy()
+            r = _rng(seed)
+            xs = [L.jo_choose_weighted(C.byref(r), O.f64p(w), len(w)) for _ in range(DRAWS)]
+            weighted.append(dict(weights=bits_vec(w), draws=xs, next=L.jo_rng_next_u64(C.byref(r))))
+        r = _rng(seed, 1)
+        x_u64 = [L.jo_rng_next_u64(C.byref(r)) for _ in range(16)]
+        r = _rng(seed, 1)
+        x_u32 = [L.jo_rng_next_u32(C.byref(r)) for _ in range(16)]
+        r = _rng(seed, 1)
+        x_rng = [L.jo_gen_range_usize(C.byref(r), 7) for _ in range(DRAWS)]
+        out.append(dict(seed=seed, next_u64=next_u64, next_u32=next_u32, gen_range=gen_range, gen_bool=gen_bool, choose_other=choose,
+                        slice_choose=slice_choose, choose_weighted=weighted, xoroshiro128pp_next_u64=x_u64,
+                        xoroshiro128pp_next_u32=x_u32, xoroshiro128pp_gen_range7=x_rng))
+    return out
+
+
+def _sig_cfv():
+    L = O.lib()
+    L.jo_cluster_filtered_variants.restype = C.c_int
+    L.jo_cluster_filtered_variants.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t),
+                                               C.POINTER(C.c_int), C.POINTER(O.ClusterConfig), C.POINTER(O.Rng),
+                                               C.POINTER(C.c_size_t), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                               C.POINTER(C.c_size_t)]
+    return L
+
+
+def feature_matrix(pr):
+    n = len(pr["variants"])
+    dim = len(pr["variant_type"])
+    x = np.zeros((n, dim))
+    for i, row in enumerate(pr["variants"]):
+        x[i] = unbits(row)
+    return x
+
+
+def dump_features(inp, fwd, rev, gains=None):
+    L = _sig_cfv()
+    if gains is None:
+        gains = O.Gains()
+        L.jo_estimate_gain_default(C.byref(fwd), C.byref(rev), C.byref(gains))
+    expected = [dict(type=t, homop=h, gain=bits(L.jo_gains_expected(C.byref(gains), h, t))) for t in range(3) for h in (1, 2, 3)]
+    pvalues = []
+    for total in (12, 24, 60, 160):
+        for t, arr in enumerate((gains.subst, gains.deletions, gains.insertions)):
+            for h in (1, 2, 3):
+                pv = np.zeros(total + 1)
+                L.jo_pvalues(arr[h - 1].prob, total, O.f64p(pv))
+                pvalues.append(dict(total=total, type=t, homop=h, pvalue=bits_vec(pv)))
+    problems = []
+    for pr in inp:
+        x = feature_matrix(pr)
+        n, dim = x.shape
+        copy_num = pr["copy_num"]
+        km = []
+        if n and dim:
+            for k in range(2, min(max(copy_num, 2), n) + 1):
+                r = _rng(pr["chunk_id"] * 3490)
+                asn, dist = np.zeros(n, dtype=np.uintp), C.c_double()
+                rc = L.jo_kmeans(O.f64p(x), n, dim, k, C.byref(r), C.byref(dist), O.szp(asn))
+                assert rc == 0
+                km.append(dict(k=k, dist=bits(dist.value), assignments=asn.tolist(), next=L.jo_rng_next_u64(C.byref(r))))
+        cfg = O.ClusterConfig(pr["band"], C.pointer(gains), pr["coverage"], copy_num, pr["local_coverage"])
+        vth = np.array([v[0] for v in pr["variant_type"]], dtype=np.uintp)
+        vtt = np.array([v[1] for v in pr["variant_type"]], dtype=np.int32)
+        r = _rng(pr["chunk_id"] * 3490)
+        asn = np.zeros(n, dtype=np.uintp)
+        lg = np.zeros((n, max(copy_num, 1)))
+        score, k_out = C.c_double(), C.c_size_t()
+        rc = L.jo_cluster_filtered_variants(O.f64p(x), n, dim, O.szp(vth), vtt.ctypes.data_as(C.POINTER(C.c_int)), C.byref(cfg),
+                                            C.byref(r), O.szp(asn), O.f64p(lg), C.byref(score), C.byref(k_out))
+        assert rc == 0, pr["name"]
+        k = k_out.value
+        lk_gains = [bits_vec(lg.reshape(-1)[i * k:(i + 1) * k]) for i in range(n)]  # n x k, packed
+        problems.append(dict(name=pr["name"], chunk_id=pr["chunk_id"], kmeans=km, assignments=asn.tolist(), lk_gains=lk_gains,
+                             score=bits(score.value), k=k, next=L.jo_rng_next_u64(C.byref(r))))
+    return dict(gains_expected=expected, gains_display=gains_display(gains), pvalues=pvalues, problems=problems)
+
+
+def batch_of(pileups):
+    """inputs.json pile-ups -> the flat C-ABI batch (jtk_amd.batch.Batch)"""
+    from jtk_amd import batch as jb
+    chunks = np.zeros(len(pileups), dtype=O.CHUNK_DT)
+    tmpl, reads, ops, read_off, ops_off, strand = [], [], [], [0], [0], []
+    for i, pu in enumerate(pileups):
+        t = pu["template"].encode()
+        chunks[i] = (pu["chunk_id"], pu["copy_num"], len(pu["reads"]), sum(len(x) for x in tmpl), len(t), len(strand))
+        tmpl.append(t)
+        for rd, op, s in zip(pu["reads"], pu["ops"], pu["strands"]):
+            reads.append(rd.encode())
+            read_off.append(read_off[-1] + len(rd))
+            ops.append(bytes(OPS.index(c) for c in op))
+            ops_off.append(ops_off[-1] + len(op))
+            strand.append(s)
+    u8 = lambda parts: np.frombuffer(b"".join(parts), dtype=np.uint8).copy()  # noqa: E731
+    return jb.Batch(chunks=chunks, tmpl_bases=u8(tmpl), read_bases=u8(reads), read_off=np.array(read_off, dtype=np.uint64),
+                    ops=u8(ops), ops_off=np.array(ops_off, dtype=np.uint64), strand=np.array(strand, dtype=np.uint8))
+
+
+def params_of(inputs, gains, coverage, band_frac=0.03):
+    p = O.Params()
+    p.forward, p.reverse = to_hmm(inputs["hmm"]["forward"]), to_hmm(inputs["hmm"]["reverse"])
+    p.gains = gains
+    p.haploid_coverage = coverage
+    p.band_frac = band_frac
+    return p
+
+
+def _pileup_results(inp, out, pol, b, tables):
+    res = []
+    stride = out["log_post"].shape[1]
+    for i, pu in enumerate(inp):
+        r0, n = int(b.chunks[i]["read_first"]), len(pu["reads"])
+        k = int(out["result"]["cluster_num"][i])
+        c0, c1 = int(out["cons_off"][i]), int(out["cons_off"][i + 1])
+        ops = ["".join(OPS[o] for o in out["ops_out"][int(out["ops_out_off"][r]):int(out["ops_out_off"][r + 1])])
+               for r in range(r0, r0 + n)]
+        res.append(dict(chunk_id=pu["chunk_id"], radius=pu["band_width"] // 2, reads=tables[i],
+                        consensus=bytes(out["cons"][c0:c1]).decode(), ops=ops,
+                        assignments=out["label"][r0:r0 + n].tolist(),
+                        posterior=[bits_vec(out["log_post"][r, :k]) for r in range(r0, r0 + n)],
+                        score=bits(out["result"]["score"][i]), k=k, n_variants=int(out["result"]["n_variants"][i])))
+        assert stride >= k
+    return res
+
+
+def dump_pileups(inputs, gains=None):
+    """the oracle's share of section "pileups" (per-read tables on the unpolished template, the stage result, one fit step)"""
+    L = O.lib()
+    inp = inputs["pileups"]
+    fwd, rev = to_hmm(inputs["hmm"]["forward"]), to_hmm(inputs["hmm"]["reverse"])
+    if gains is None:
+        gains = O.Gains()
+        L.jo_estimate_gain_default(C.byref(fwd), C.byref(rev), C.byref(gains))
+    b = batch_of(inp)
+    p = params_of(inputs, gains, inp[0]["coverage"])
+    tables = []
+    for pu in inp:
+        t = O.seq(pu["template"])
+        per = []
+        for rd, op, s in zip(pu["reads"], pu["ops"], pu["strands"]):
+            h = fwd if s else rev
+            y, o = O.seq(rd), np.array([OPS.index(c) for c in op], dtype=np.uint8)
+            tab, lk = O.modification_table(h, t, y, o, pu["band_width"] // 2)
+            boot = L.jo_phmm_likelihood_bootstrap(C.byref(h), O.u8p(t), len(t), O.u8p(y), len(y), pu["band_width"] // 2)
+            per.append(dict(lk=bits(lk), table=bits_vec(tab), bootstrap_lk=bits(boot)))
+        tables.append(per)
+    out = O.cluster_chunks(p, b, skip_polish=False)
+    assert out["rc"] == 0
+    rc, f1, r1 = O.fit_model(p, b, rounds=1)
+    assert rc == 0
+    return dict(gains_display=gains_display(gains), pileups=_pileup_results(inp, out, None, b, tables),
+                fit_one_step=dict(forward=hmm_json(f1), reverse=hmm_json(r1)))
+
+
+def dump_eigen(inp):
+    import test_independent_checks as tic
+    out = []
+    for m in inp:
+        a = np.array([unbits(row) for row in m])
+        vals, vecs = tic.jo_eigen(a)
+        order = np.argsort(np.abs(vals), kind="stable")
+        out.append(dict(eigenvalues=bits_vec(vals[order]), eigenvectors=[bits_vec(vecs[:, j]) for j in order]))
+    return out
+
+
+def oracle_dump(inputs):
+    fwd, rev = to_hmm(inputs["hmm"]["forward"]), to_hmm(inputs["hmm"]["reverse"])
+    return dict(format=1, crates="jtk_amd CPU oracle (oracle/*.c)", rng=dump_rng(inputs["rng"]),
+                features=dump_features(inputs["features"], fwd, rev), pileups=dump_pileups(inputs), eigen=dump_eigen(inputs["eigen"]))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# comparison
+# ------------------------------------------------------------------------------------------------------------------
+def same_partition(a, b):
+    import helpers
+    return helpers.same_partition(a, b)
+
+
+def max_abs(a_bits, b_bits):
+    a, b = unbits(a_bits), unbits(b_bits)
+    if a.shape != b.shape:
+        return float("inf")
+    both_small = (a < -1e290) & (b < -1e290)  # "impossible edit" markers: any pair of hugely negative values agrees
+    d = np.abs(a - b)
+    d[both_small] = 0.0
+    d[np.isnan(a) & np.isnan(b)] = 0.0
+    return float(d.max()) if d.size else 0.0
+
+
+def compare_rng(gold, mine):
+    bad = []
+    for g, m in zip(gold, mine):
+        s = g["seed"]
+        for key in ("next_u64", "next_u32", "xoroshiro128pp_next_u64", "xoroshiro128pp_next_u32", "xoroshiro128pp_gen_range7"):
+            if g[key] != m[key]:
+                bad.append(f"rng seed {s}: {key} differs")
+        for key, tag in (("gen_range", "n"), ("gen_bool", "p"), ("choose_other", "k"), ("slice_choose", "n"),
+                         ("choose_weighted", "weights")):
+            for ge, me in zip(g[key], m[key]):
+                if ge["draws"] != me["draws"] or ge["next"] != me["next"]:
+                    first = next((i for i, (x, y) in enumerate(zip(ge["draws"], me["draws"])) if x != y), None)
+                    bad.append(f"rng seed {s}: {key}({tag}={ge[tag] if tag != 'weights' else len(ge[tag])}) differs from draw {first}"
+                               f" (stream position after {DRAWS} draws {'equal' if ge['next'] == me['next'] else 'differs'})")
+    return bad
+
+
+def compare_features(gold, mine, tol=1e-4):
+    """labels exact up to a permutation of names, k equal, scores / gains within tol (north_star's tolerance)"""
+    bad = []
+    for ge, me in zip(gold["pvalues"], mine["pvalues"]):
+        d = max_abs(ge["pvalue"], me["pvalue"])
+        if d > 1e-12:
+            bad.append(f"pvalues total={ge['total']} type={ge['type']} homop={ge['homop']}: max |diff| {d:.3g}")
+    for g, m in zip(gold["problems"], mine["problems"]):
+        name = g["name"]
+        for gk, mk in zip(g["kmeans"], m["kmeans"]):
+            if gk["assignments"] != mk["assignments"] or gk["next"] != mk["next"]:
+                bad.append(f"{name}: kmeans(k={gk['k']}) assignments / stream position differ")
+            elif max_abs([gk["dist"]], [mk["dist"]]) > 1e-9:
+                bad.append(f"{name}: kmeans(k={gk['k']}) residual differs")
+        if g["k"] != m["k"]:
+            bad.append(f"{name}: k {g['k']} vs {m['k']}")
+            continue
+        if not same_partition(g["assignments"], m["assignments"]):
+            bad.append(f"{name}: assignments differ")
+        if g["next"] != m["next"]:
+            bad.append(f"{name}: generator position after the call differs")
+        if max_abs([g["score"]], [m["score"]]) > tol:
+            bad.append(f"{name}: score differs by {max_abs([g['score']], [m['score']]):.3g}")
+        if g["assignments"] == m["assignments"]:
+            d = max(max_abs(a, b) for a, b in zip(g["lk_gains"], m["lk_gains"])) if g["lk_gains"] else 0.0
+            if d > tol:
+                bad.append(f"{name}: lk_gains differ by {d:.3g}")
+    return bad
+
+
+def compare_pileups(gold, mine, tol=1e-4, table_tol=1e-6, what=("tables", "stage", "fit")):
+    bad = []
+    for g, m in zip(gold["pileups"], mine["pileups"]):
+        cid = g["chunk_id"]
+        if "tables" in what:
+            for r, (gr, mr) in enumerate(zip(g["reads"], m["reads"])):
+                if max_abs([gr["lk"]], [mr["lk"]]) > tol:
+                    bad.append(f"chunk {cid} read {r}: lk differs by {max_abs([gr['lk']], [mr['lk']]):.3g}")
+                if "bootstrap_lk" in mr and max_abs([gr["bootstrap_lk"]], [mr["bootstrap_lk"]]) > tol:
+                    bad.append(f"chunk {cid} read {r}: bootstrap lk differs")
+                if len(gr["table"]) != len(mr["table"]):
+                    bad.append(f"chunk {cid} read {r}: table has {len(gr['table'])} entries, expected {len(mr['table'])}")
+                elif max_abs(gr["table"], mr["table"]) > table_tol:
+                    bad.append(f"chunk {cid} read {r}: table differs by {max_abs(gr['table'], mr['table']):.3g}")
+        if "stage" in what:
+            if g["consensus"] != m["consensus"]:
+                bad.append(f"chunk {cid}: polished consensus differs")
+            elif g["ops"] != m["ops"]:
+                bad.append(f"chunk {cid}: re-threaded ops differ")
+            if g["k"] != m["k"]:
+                bad.append(f"chunk {cid}: k {g['k']} vs {m['k']}")
+            elif not same_partition(g["assignments"], m["assignments"]):
+                bad.append(f"chunk {cid}: assignments differ")
+            elif g["assignments"] == m["assignments"]:
+                d = max(max_abs(a, b) for a, b in zip(g["posterior"], m["posterior"]))
+                if d > tol:
+                    bad.append(f"chunk {cid}: posteriors differ by {d:.3g}")
+            if max_abs([g["score"]], [m["score"]]) > tol:
+                bad.append(f"chunk {cid}: score differs")
+    if "fit" in what and "fit_one_step" in mine:
+        for strand in ("forward", "reverse"):
+            for key in ("trans", "mat_emit", "ins_emit"):
+                d = max_abs(gold["fit_one_step"][strand][key], mine["fit_one_step"][strand][key])
+                if d > 1e-9:
+                    bad.append(f"fit_one_step {strand}.{key} differs by {d:.3g}")
+    return bad
+
+
+def compare_eigen(gold, mine):
+    """eigenvalues to 1e-10; eigenvectors up to sign where the eigenvalue is isolated, as projectors where it is not"""
+    bad = []
+    if gold is None:
+        return bad
+    for i, (g, m) in enumerate(zip(gold, mine)):
+        gv, mv = unbits(g["eigenvalues"]), unbits(m["eigenvalues"])
+        if np.abs(np.sort(gv) - np.sort(mv)).max() > 1e-10:
+            bad.append(f"eigen {i}: eigenvalues differ by {np.abs(np.sort(gv) - np.sort(mv)).max():.3g}")
+            continue
+        G = np.array([unbits(v) for v in g["eigenvectors"]]).T[:, np.argsort(gv, kind="stable")]
+        M = np.array([unbits(v) for v in m["eigenvectors"]]).T[:, np.argsort(mv, kind="stable")]
+        w = np.sort(gv)
+        start = 0
+        for j in range(1, len(w) + 1):
+            if j == len(w) or w[j] - w[j - 1] > 1e-8:
+                pg, pm = G[:, start:j] @ G[:, start:j].T, M[:, start:j] @ M[:, start:j].T
+                if np.abs(pg - pm).max() > 1e-7:
+                    bad.append(f"eigen {i}: eigenspace of eigenvalues {start}..{j - 1} differs by {np.abs(pg - pm).max():.3g}")
+                start = j
+    return bad
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the device's share (C ABI): features through jtk_lc_cluster_features, pile-ups through jtk_lc_modification_table and
+# jtk_lc_cluster_chunks, the fit through jtk_lc_fit_model
+# ------------------------------------------------------------------------------------------------------------------
+def device_dump(inputs, gains_features, gains_pileups):
+    from jtk_amd import api, ffi
+    import helpers  # noqa: F401
+    out = {}
+    # features: post-tail outputs (labels after the arg-max re-assignment, log-posteriors)
+    feats = inputs["features"]
+    chunks = np.zeros(len(feats), dtype=ffi.FEATURE_CHUNK_DT)
+    var, vts = [], []
+    voff = vtoff = rfirst = 0
+    for i, pr in enumerate(feats):
+        x = feature_matrix(pr)
+        n, dim = x.shape
+        chunks[i] = (pr["chunk_id"], pr["copy_num"], n, dim, 0, voff, vtoff, rfirst, pr["local_coverage"])
+        var.append(x.ravel())
+        vts.append(np.array(pr["variant_type"], dtype=np.uint32).reshape(-1))
+        voff += n * dim
+        vtoff += dim
+        rfirst += n
+    p = ffi.Params.from_buffer_copy(bytes(params_of(inputs, gains_features, feats[0]["coverage"])))
+    stride = max(pr["copy_num"] for pr in feats)
+    dev = api.cluster_features(p, chunks, np.concatenate(var), np.concatenate(vts).astype(np.uint32), stride)
+    out["features"] = dict(label=dev["label"], log_post=dev["log_post"], k=dev["result"]["cluster_num"], score=dev["result"]["score"],
+                           first=chunks["read_first"], n=chunks["n_reads"])
+    # pile-ups
+    inp = inputs["pileups"]
+    b = batch_of(inp)
+    p = ffi.Params.from_buffer_copy(bytes(params_of(inputs, gains_pileups, inp[0]["coverage"])))
+    tables = []
+    for i, pu in enumerate(inp):
+        sub = b.subset([i])
+        reads = [sub.read(r) for r in range(sub.n_reads)]
+        ops = [sub.read_ops(r) for r in range(sub.n_reads)]
+        tab, lk = api.modification_table(p, sub.template(0), reads, ops, sub.strand)
+        tables.append([dict(lk=bits(lk[r]), table=bits_vec(tab[r])) for r in range(sub.n_reads)])
+    res = api.cluster_chunks(p, b)
+    f1, r1 = api.fit_model(p, b, rounds=1)
+    out["pileups"] = dict(pileups=_pileup_results(inp, res, None, b, tables),
+                          fit_one_step=dict(forward=hmm_json(f1), reverse=hmm_json(r1)))
+    return out

@@ -1,0 +1,156 @@
+"""Checks of the CPU oracle against INDEPENDENT implementations (scipy / numpy / scikit-learn), for the pieces whose
+mathematics is standard: these need no Rust toolchain and narrow what `parity unpinned` can hide.  They pin VALUES to
+closed forms; the bit-level behaviour of the crates the reference uses is what tests/test_reference_golden.py is for."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.special
+import scipy.stats
+
+import oracle_ffi as O
+
+
+def test_pvalues_match_the_binomial_upper_tail(oracle):
+    """likelihood_gains.rs:115-129 `pvalues`: i -> P(i <= X | n, prob)"""
+    L = O.lib()
+    for n in (12, 24, 60, 160):
+        for prob in (1e-9, 0.02, 0.1, 0.3, 0.66):
+            out = np.zeros(n + 1)
+            L.jo_pvalues(prob, n, O.f64p(out))
+            ref = scipy.stats.binom.sf(np.arange(n + 1) - 1, n, prob)
+            ok = ref > 1e-280  # below that the log-space recurrence and scipy underflow differently
+            assert np.allclose(out[ok], ref[ok], rtol=1e-9), (n, prob)
+            assert np.all(out[~ok] < 1e-270)
+            assert out[0] == pytest.approx(1.0, abs=1e-12)
+
+
+def test_poisson_lk_matches_logpmf(oracle):
+    """pseudo_mcmc.rs:636-638 poisson_lk and :641-645 max_poisson_lk"""
+    L = O.lib()
+    for lam in (0.5, 12.0, 30.0, 41.5):
+        for x in (0, 1, 7, 30, 61, 160):
+            assert L.jo_poisson_lk(x, lam) == pytest.approx(scipy.stats.poisson.logpmf(x, lam), rel=1e-11, abs=1e-11)
+            best = max(scipy.stats.poisson.logpmf(x, c * lam) for c in range(1, 5))
+            assert L.jo_max_poisson_lk(x, lam, 1, 4) == pytest.approx(best, rel=1e-11, abs=1e-11)
+
+
+def test_logsumexp_matches_scipy(oracle):
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 7, 40):
+        xs = rng.normal(-30, 25, n)
+        assert O.lib().jo_logsumexp(O.f64p(xs), n) == pytest.approx(scipy.special.logsumexp(xs), rel=1e-13)
+
+
+def test_exp_log_are_within_one_ulp_of_libm(oracle):
+    """include/jtk_math.h (fdlibm) against the platform libm numpy uses"""
+    rng = np.random.default_rng(11)
+    L = O.lib()
+    xs = np.concatenate([rng.uniform(-700, 700, 2000), rng.normal(0, 1e-3, 500), [0.0, -0.0, 1.0, -1.0]])
+    for x in xs:
+        got, ref = L.jo_exp(float(x)), float(np.exp(x))
+        assert abs(got - ref) <= np.spacing(ref), x
+    for x in np.concatenate([np.exp(rng.uniform(-700, 700, 2000)), [1.0, 2.0, 0.5, 1e-300, 1e300]]):
+        got, ref = L.jo_log(float(x)), float(np.log(x))
+        assert abs(got - ref) <= np.spacing(abs(ref)) if ref != 0 else got == 0.0, x
+
+
+def laplacian(rng, n, split, cross=0.6):
+    w = np.full((n, n), 1e-16)
+    for a, b in ((0, split), (split, n)):
+        blk = rng.uniform(0.55, 0.99, (b - a, b - a))
+        w[a:b, a:b] = (blk + blk.T) / 2
+    if cross:
+        w[0, n - 1] = w[n - 1, 0] = cross
+    sq = np.sqrt(1.0 / w.sum(axis=1))
+    lap = -w * sq[:, None] * sq[None, :]
+    np.fill_diagonal(lap, 1.0)
+    return lap
+
+
+def jo_eigen(a):
+    n = len(a)
+    work, v = np.array(a, dtype=np.float64, order="C"), np.zeros((n, n))
+    O.lib().jo_symmetric_eigen.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double)]
+    O.lib().jo_symmetric_eigen.restype = None
+    O.lib().jo_symmetric_eigen(O.f64p(work), n, O.f64p(v))
+    return np.diag(work).copy(), v
+
+
+def test_jacobi_eigen_matches_numpy_eigh(oracle):
+    """include/jtk_eigen.h stands in for nalgebra's symmetric_eigen (phmm_likelihood_correction.rs:419): eigenvalues and the
+    spanned subspaces must be those of LAPACK (eigenvectors themselves are defined up to sign / rotation in a degenerate
+    eigenspace, so the comparison is of projectors onto the clusters of close eigenvalues)"""
+    rng = np.random.default_rng(7)
+    mats = [laplacian(rng, 12, 6), laplacian(rng, 30, 11), laplacian(rng, 40, 20, cross=0.0)]
+    m = rng.normal(size=(25, 25))
+    mats.append((m + m.T) / 2)
+    for a in mats:
+        n = len(a)
+        vals, vecs = jo_eigen(a)
+        assert np.allclose(vecs.T @ vecs, np.eye(n), atol=1e-12)                 # orthonormal columns
+        assert np.allclose(a @ vecs, vecs * vals[None, :], atol=1e-11)           # A v_i = lambda_i v_i
+        w, q = np.linalg.eigh(a)
+        order = np.argsort(vals)
+        assert np.allclose(vals[order], w, atol=1e-11)
+        # projectors onto groups of eigenvalues closer than 1e-8 (the 1e-16 links make the small ones near-degenerate)
+        groups, start = [], 0
+        for i in range(1, n + 1):
+            if i == n or w[i] - w[i - 1] > 1e-8:
+                groups.append((start, i))
+                start = i
+        for lo, hi in groups:
+            p_np = q[:, lo:hi] @ q[:, lo:hi].T
+            mine = vecs[:, order[lo:hi]]
+            assert np.allclose(mine @ mine.T, p_np, atol=1e-7), (lo, hi)
+
+
+def test_spectral_labels_do_not_depend_on_the_eigenvector_signs(oracle):
+    """what the correction does with the eigenvectors (features = v * D^-1/2, column-normalised, distance-based k-means):
+    flipping the sign of any eigenvector permutes nothing -- k-means on sign-flipped columns gives the same partition for the
+    same generator state, because every distance is unchanged"""
+    rng = np.random.default_rng(3)
+    a = laplacian(rng, 30, 11)
+    vals, vecs = jo_eigen(a)
+    order = np.argsort(np.abs(vals))
+    feats = vecs[:, order[:2]].copy()
+    feats /= np.sqrt((feats ** 2).sum(axis=0))
+    L = O.lib()
+    outs = []
+    for signs in ((1, 1), (-1, 1), (1, -1), (-1, -1)):
+        f = np.ascontiguousarray(feats * np.array(signs)[None, :])
+        r = O.Rng()
+        L.jo_rng_seed_from_u64(C.byref(r), 77)
+        asn, dist = np.zeros(30, dtype=np.uintp), C.c_double()
+        assert L.jo_kmeans(O.f64p(f), 30, 2, 2, C.byref(r), C.byref(dist), O.szp(asn)) == 0
+        outs.append(asn.copy())
+    import helpers
+    # k-means++ seeding draws the same indices (distances are sign-invariant), so even the label NAMES agree
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    assert helpers.same_partition(outs[0], [0] * 11 + [1] * 19)
+
+
+def test_adjusted_rand_index_matches_sklearn(oracle):
+    """misc.rs:22-46 in integer arithmetic against the closed form"""
+    from sklearn.metrics import adjusted_rand_score
+    L = O.lib()
+    L.jo_adjusted_rand_index.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t]
+    L.jo_adjusted_rand_index.restype = C.c_double
+    rng = np.random.default_rng(9)
+    for n, ka, kb in ((12, 2, 2), (40, 2, 3), (60, 4, 4), (160, 3, 2)):
+        a = rng.integers(0, ka, n).astype(np.uintp)
+        b = np.where(rng.random(n) < 0.8, a % kb, rng.integers(0, kb, n)).astype(np.uintp)
+        got = L.jo_adjusted_rand_index(O.szp(a), O.szp(b), n)
+        # the reference halves (lab_match + pred_match) in INTEGER arithmetic (:41-43): it can differ from the closed form by
+        # the dropped 1/2 -- bound that difference instead of hiding it
+        ref = adjusted_rand_score(a, b)
+        assert abs(got - ref) < 2.0 / n, (n, got, ref)
+    a = np.array([0, 0, 1, 1, 2, 2], dtype=np.uintp)
+    assert L.jo_adjusted_rand_index(O.szp(a), O.szp(a), 6) == 1.0
+
+
+def test_rand_index_matches_sklearn(oracle):
+    from sklearn.metrics import rand_score
+    rng = np.random.default_rng(10)
+    a, b = rng.integers(0, 3, 50).astype(np.uintp), rng.integers(0, 2, 50).astype(np.uintp)
+    assert O.lib().jo_rand_index(O.szp(a), O.szp(b), 50) == pytest.approx(rand_score(a, b), rel=1e-12)
