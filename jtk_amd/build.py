@@ -12,7 +12,7 @@ OUT = os.path.join(OUT_DIR, "libjtk_lc.so")
 SYNTH_OUT = os.path.join(OUT_DIR, "libjtk_synth.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["phmm_kernels.hip", "phmm_pair.hip", "phmm_wide.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip", "session.hip", "gains.hip", "correction.hip",
+SOURCES = ["phmm_kernels.hip", "phmm_sweep.hip", "phmm_pair.hip", "phmm_wide.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip", "session.hip", "gains.hip", "correction.hip",
            "host_api.cpp"]
 SYNTH_SOURCES = ["synth.cpp"]
 # -ffp-contract=off: device f64 arithmetic must round exactly like the reference (no implicit fma);
@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
     return OUT
 
 
-PROFILED_SOURCES = ["phmm_kernels.hip", "phmm_pair.hip", "phmm_wide.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip",
+PROFILED_SOURCES = ["phmm_kernels.hip", "phmm_sweep.hip", "phmm_pair.hip", "phmm_wide.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip",
                     "session.hip", "device_common.h"]
 
 

@@ -1,4 +1,6 @@
-// phmm_kernels.hip -- banded pair-HMM forward/backward + modification table for gfx950 (CDNA4).
+// phmm_kernels.hip -- band preparation and table finalisation of the banded pair-HMM for gfx950 (CDNA4); the sweep itself
+// (phmm_kernel) lives in phmm_sweep.hip.  The round-2 sweep is kept below for differential runs only: a build with
+// -DJTK_PHMM_WITH_R2 compiles it as phmm_kernel_r2 and JTK_PHMM_R2=1 selects it at run time; it is not in the product build.
 //
 // Replaces kiley `modification_table_antidiagonal` as called from
 // haplotyper/src/local_clustering/pseudo_mcmc.rs:45-68 and the per-read inner step of
@@ -81,6 +83,18 @@ __global__ void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const 
     for (uint32_t w = 0; w < words; w++) d[w] = 0;
     uint32_t i = 0, j = 0, t = 0;
     bool bad = false;
+    // the interval [f_lo, f_hi] of diagonals whose WHOLE band lies inside the DP matrix (0 <= i <= L, 0 <= j <= n for every
+    // band cell): c - r >= 0, c + r <= L, c + r <= t, c - r >= t - n.  c and t - c are non-decreasing in t, so the set is one
+    // interval; phmm_kernel runs it under an EXEC mask that is the band and takes per-lane predicates outside of it.
+    const int32_t rad = (int32_t)chunks[rm.chunk].radius;
+    uint32_t f_lo = 1, f_hi = 0;
+    auto visit = [&](uint32_t tt, uint32_t cc) {  // diagonal tt has centre cc
+        const int32_t c = (int32_t)cc, td = (int32_t)tt;
+        if (c - rad >= 0 && c + rad <= (int32_t)L && c + rad <= td && c - rad >= td - (int32_t)n) {
+            if (f_hi < f_lo) f_lo = tt;
+            f_hi = tt;
+        }
+    };
     // the walk is one thread per read and latency bound: fetch the ops 8 at a time (ops_off is 8-byte aligned)
     uint64_t chunk8 = 0;
     for (uint32_t k = 0; k < n_ops; k++) {
@@ -89,16 +103,20 @@ __global__ void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const 
         if (op == JTK_OP_INS) {
             t += 1;
             j++;
+            visit(t, i);
         } else if (op == JTK_OP_DEL) {
             t += 1;
             if (t <= T) d[t >> 6] |= 1ull << (t & 63);
             i++;
+            visit(t, i);
         } else if (op <= JTK_OP_MISMATCH) {
             t += 1;
             if (t <= T) d[t >> 6] |= 1ull << (t & 63);
-            t += 1;
             i++;
+            visit(t, i);
+            t += 1;
             j++;
+            visit(t, i);
         } else {
             bad = true;
         }
@@ -108,8 +126,11 @@ __global__ void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const 
         }
     }
     if (bad || i != L || j != n) atomicMin(&st->status, (int)JTK_ERR_OPS_MISMATCH);
+    // the word behind the read's delta words (session.hip sizes the slot from the template CAPACITY: one word to spare)
+    d[((chunks[rm.chunk].tmpl_cap + rm.read_len) >> 6) + 2] = (bad || f_hi < f_lo) ? 1ull : ((uint64_t)f_hi << 32 | f_lo);
 }
 
+#ifdef JTK_PHMM_WITH_R2
 // ------------------------------------------------------------------------------------------------------
 // The per-read forward/backward sweep.
 //
@@ -143,7 +164,7 @@ __global__ void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const 
 #ifndef JTK_PHMM_NUM_VGPR
 #define JTK_PHMM_NUM_VGPR 84
 #endif
-__global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(JTK_PHMM_NUM_VGPR))) void phmm_kernel(uint32_t n_reads, const ReadMeta *reads,
+__global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(JTK_PHMM_NUM_VGPR))) void phmm_kernel_r2(uint32_t n_reads, const ReadMeta *reads,
                                                   const ChunkMeta *chunks, const ChunkState *state,
                                                   DevBufs bufs, const uint8_t *ey_all, const uint64_t *delta_all,
                                                   const HmmDev *hmm2, double *scratch_all,
@@ -524,6 +545,8 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(
     }
 }
 
+#endif  // JTK_PHMM_WITH_R2
+
 // ------------------------------------------------------------------------------------------------------
 // finalize: one thread per (read, position p): the 14 table entries of p from the raw row sums,
 // MINUS the read's lk (pseudo_mcmc.rs:64).  Row iota owns sub[iota-1], ins[iota], copy_c[iota-1],
@@ -606,25 +629,25 @@ void launch_band_prep(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, co
     band_prep_kernel<<<(n_reads + 63) / 64, 64, 0, s>>>(n_reads, reads, chunks, state, bufs, delta, only_active);
 }
 
-size_t phmm_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
+#ifdef JTK_PHMM_WITH_R2
+static size_t phmm_r2_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
     const uint32_t n_blk = ((max_tmpl + max_read) >> 6) + 4;
     size_t b = 8 * RW * 16 + 36 * 8 + (size_t)n_blk * 12;
     b += ((max_tmpl + 2 * PAD + 15) & ~15u) + max_read + 1 + 2 * PAD;
     return (b + 15) & ~(size_t)15;
 }
-
-void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
-                 const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta,
-                 const HmmDev *hmm2, double *scratch, uint64_t scratch_stride, uint32_t n_waves,
-                 uint32_t *work_counter, double *raw, int *rawG, double *lk, uint32_t max_tmpl,
-                 uint32_t max_read, int only_active, uint32_t skip_le_radius) {
+void launch_phmm_r2(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
+                    const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta,
+                    const HmmDev *hmm2, double *scratch, uint64_t scratch_stride, uint32_t n_waves,
+                    uint32_t *work_counter, double *raw, int *rawG, double *lk, uint32_t max_tmpl,
+                    uint32_t max_read, int only_active, uint32_t skip_le_radius) {
     if (n_reads == 0) return;
-    hipMemsetAsync(work_counter, 0, sizeof(uint32_t), s);
-    const size_t lds = phmm_lds_bytes(max_tmpl, max_read);
-    phmm_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch,
-                                         scratch_stride, work_counter, raw, rawG, lk, max_tmpl, max_read,
-                                         only_active, skip_le_radius);
+    (void)hipMemsetAsync(work_counter, 0, sizeof(uint32_t), s);
+    phmm_kernel_r2<<<n_waves, 64, phmm_r2_lds_bytes(max_tmpl, max_read), s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2,
+                                                                             scratch, scratch_stride, work_counter, raw, rawG, lk,
+                                                                             max_tmpl, max_read, only_active, skip_le_radius);
 }
+#endif
 
 void launch_finalize(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                      const ChunkState *state, const HmmDev *hmm2, const double *raw, const int *rawG,

@@ -1,0 +1,774 @@
+// phmm_sweep.hip -- phmm_kernel: banded pair-HMM forward/backward + modification-table row sums for band radius 15..30
+// (ONT at 2 kbp: 30), one wavefront per read, gfx950.
+//
+// Replaces kiley `modification_table_antidiagonal` (haplotyper/src/local_clustering/pseudo_mcmc.rs:45-68) and the per-read
+// inner step of `polish_until_converge_antidiagonal` (local_clustering/mod.rs:105-106).  kiley is not under /root/reference;
+// the arithmetic is the own specification of DESIGN.md section 4 / oracle/phmm.c, reproduced bit for bit.
+//
+// Mapping (round 3 rewrite; the round-2 kernel issued 290 wave-instructions per anti-diagonal, profiles/r03_pmc_issue_phmm_base.txt):
+//  * lane ring as before: an anti-diagonal t = i + j is one wave-wide step, lane l owns the template row i == l (mod 64)
+//    inside [c[t]-r, c[t]-r+63]; <= 61 band cells + 3 spare lanes, neighbours are wave_ror/rol:1 DPP moves;
+//  * the MIDDLE of both sweeps (all band cells inside the DP matrix: band_prep_kernel computes that interval per read) runs in
+//    groups of 8 unrolled diagonals under an EXEC mask that is the band itself (a rotating 64-bit scalar mask,
+//    __builtin_amdgcn_inverse_ballot_w64): no per-lane "does this cell exist" arithmetic, no selects; spare lanes keep
+//    exact zeros because they simply do not execute.  A lane's template row changes only when the band moves past it, so
+//    row index, emission row and the lane's read-byte window are registers updated by ONE lane when a row leaves the band;
+//  * the read's emission bytes of a group's 8 diagonals are two dwords per lane (3 aligned LDS dwords + v_alignbyte);
+//  * band deltas, scaling exponents and the del-3 thresholds are scalar (one LDS byte pair per group);
+//  * row sums of a row that left the band stay in the (now idle) lane and are flushed once per group for all lanes that left;
+//  * the first / last ~2r diagonals of a sweep, and any group with more than 4 band moves, take a generic step (per-lane
+//    predicates, as the round-2 kernel did everywhere);
+//  * forward still streams the pair P_s = (toM of diagonal s-1, toD of diagonal s) per diagonal to an HBM stripe (1 KiB per
+//    diagonal), backward reads it back through a register queue into an 8-slot LDS ring (no wrapped copies: seven address
+//    registers instead).
+#include "device_common.h"
+
+#ifdef JTK_PHMM_WITH_R2
+#include <stdlib.h>
+void launch_phmm_r2(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks, const ChunkState *state,
+                    DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2, double *scratch,
+                    uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *raw, int *rawG, double *lk,
+                    uint32_t max_tmpl, uint32_t max_read, int only_active, uint32_t skip_le_radius);
+#endif
+
+namespace {
+
+#define PAD 64                 // zero padding (bytes) either side of the staged code arrays
+#define RS 1024                // bytes per ring slot: 64 lanes x (toM, toD)
+#define S_EM (8 * RS)          // eM[16] as doubles (32-byte aligned: a row's address can be OR-ed with the column)
+#define S_EI (S_EM + 128)      // eI[20]
+#define S_VAR (S_EI + 160)     // delta words | block exponents | template codes | read codes
+
+__device__ __forceinline__ double rot_from_prev(double v) {  // lane l <- lane (l-1)&63
+    int lo = __double2loint(v), hi = __double2hiint(v);
+#ifdef JTK_PHMM_DPP_OLD
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x13C, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x13C, 0xF, 0xF, false);
+#else
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x13C, 0xF, 0xF, false);  // wave_ror:1 (every lane has a source: no `old` value needed)
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x13C, 0xF, 0xF, false);
+#endif
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rot_from_next(double v) {  // lane l <- lane (l+1)&63
+    int lo = __double2loint(v), hi = __double2hiint(v);
+#ifdef JTK_PHMM_DPP_OLD
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x134, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xF, 0xF, false);
+#else
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x134, 0xF, 0xF, false);  // wave_rol:1
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x134, 0xF, 0xF, false);
+#endif
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double u = __shfl_xor(v, o, 64);
+        v = u > v ? u : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double pow2i(int e) { return jtk_scalbn(1.0, e); }
+__device__ __forceinline__ double fast_pow2(int e) {  // == scalbn(1.0, e) wherever the result is normal
+    if (e == 0) return 1.0;
+    if (e > -1000 && e < 1000) return jtk_bits_f64((uint64_t)(1023 + e) << 52);
+    return jtk_scalbn(1.0, e);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    return (uint64_t)(uint32_t)uni((int)(uint32_t)(v >> 32)) << 32 | (uint32_t)uni((int)(uint32_t)v);
+}
+__device__ __forceinline__ double uni_f64(double v) { return jtk_bits_f64(uni64(jtk_f64_bits(v))); }
+__device__ __forceinline__ uint64_t rotl64(uint64_t m, int s) { return (m << (s & 63)) | (m >> ((64 - s) & 63)); }
+__device__ __forceinline__ bool lanes(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+// A block that must run under an EXEC mask (and not be turned into selects over everything it assigns): an empty volatile
+// asm cannot be speculated, so the block stays a branch.
+#define KEEP_MASKED asm volatile("")
+
+// acc_sub += x_sub * vm and acc_ins += x_ins * vm on the lanes whose read base is `Q` (y8 == 8 Q): the row sums split by
+// read base.  fma(x, 0, acc) == acc exactly, so leaving the other lanes out changes no bit (oracle/phmm.c masks vm).
+#define BASE_FMA(Q, acc_sub, acc_ins, x_sub, x_ins, vmv, y8v)                                                         \
+    {                                                                                                               \
+        uint64_t sv_;                                                                                               \
+        asm("v_cmp_eq_u32_e32 vcc, %[q8], %[y8]\n\t"                                                                \
+            "s_and_saveexec_b64 %[sv], vcc\n\t"                                                                     \
+            "v_fmac_f64_e32 %[a], %[xa], %[vm]\n\t"                                                                 \
+            "v_fmac_f64_e32 %[b], %[xb], %[vm]\n\t"                                                                 \
+            "s_mov_b64 exec, %[sv]"                                                                                 \
+            : [a] "+v"(acc_sub), [b] "+v"(acc_ins), [sv] "=&s"(sv_)                                                 \
+            : [y8] "v"(y8v), [xa] "v"(x_sub), [xb] "v"(x_ins), [vm] "v"(vmv), [q8] "n"(8 * (Q))                      \
+            : "vcc", "scc");                                                                                               \
+    }
+// acc = fma(y, vd, fma(x, hM, acc)) where the x term only counts on lanes with rowv >= thr_x and the y term on lanes with
+// rowv >= thr_y (the del-3 source row i-4 must lie inside the band of ITS diagonal: the one case the three spare lanes of
+// the lane ring cannot tell apart)
+#define DEL3_FMA(accv, xv, yv, hMv, vdv, rowm4, thr_x, thr_y)                                                       \
+    {                                                                                                               \
+        uint64_t sv_;                                                                                               \
+        asm("v_cmp_le_i32_e32 vcc, %[tx], %[r4]\n\t"                                                                \
+            "s_and_saveexec_b64 %[sv], vcc\n\t"                                                                     \
+            "v_fmac_f64_e32 %[a], %[x], %[hm]\n\t"                                                                  \
+            "s_mov_b64 exec, %[sv]\n\t"                                                                             \
+            "v_cmp_le_i32_e32 vcc, %[ty], %[r4]\n\t"                                                                \
+            "s_and_saveexec_b64 %[sv], vcc\n\t"                                                                     \
+            "v_fmac_f64_e32 %[a], %[y], %[vd]\n\t"                                                                  \
+            "s_mov_b64 exec, %[sv]"                                                                                 \
+            : [a] "+v"(accv), [sv] "=&s"(sv_)                                                                       \
+            : [x] "v"(xv), [y] "v"(yv), [hm] "v"(hMv), [vd] "v"(vdv), [r4] "v"(rowm4), [tx] "s"(thr_x), [ty] "s"(thr_y) \
+            : "vcc", "scc");                                                                                               \
+    }
+
+#ifndef JTK_PHMM_NUM_VGPR
+#define JTK_PHMM_NUM_VGPR 84  // amdgpu_num_vgpr counts the unified file in halves: 168 registers = three waves per SIMD
+#endif
+
+// One read: both sweeps.
+__device__ __forceinline__ void sweep_read(const int L, const int n, const int r, const int f_lo, const int f_hi, const HmmDev *h,
+                                           const uint8_t *gx, const uint8_t *gy, const uint64_t *delta, double2 *scratch,
+                                           double *raw, int *rawG, double *lk_out, const uint32_t lds_tmpl,
+                                           const uint32_t lds_read) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int T = L + n;
+    const uint32_t n_blk = ((lds_tmpl + lds_read) >> 6) + 4;
+    const uint32_t S_DELTA = S_VAR, S_EF = S_DELTA + n_blk * 8, S_XS = (S_EF + n_blk * 4 + 15) & ~15u,
+                   S_EY = S_XS + ((lds_tmpl + 2 * PAD + 15) & ~15u);
+    const uint32_t XS0 = S_XS + PAD - 1;  // smem[XS0 + i] = 32 * code(x[i-1]): the eM row of template row i, in bytes
+    const uint32_t EY0 = S_EY + PAD;      // smem[EY0 + j] = 8 * (y[j-1] | ctx(j) << 2): the eI entry of read column j, in bytes
+    uint64_t *s_delta = reinterpret_cast<uint64_t *>(smem + S_DELTA);
+    int *s_EF = reinterpret_cast<int *>(smem + S_EF);
+    const int lane = threadIdx.x;
+    const uint32_t lane16 = lane * 16;
+    // ring entry of row i+k for k = -4 .. +2, as byte offsets inside a slot
+    uint32_t RK[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) RK[k] = (uint32_t)((lane + k - 4) & 63) * 16;
+    auto lds_f64 = [&](uint32_t a) -> double { return *reinterpret_cast<const double *>(smem + a); };
+    auto lds_u8 = [&](uint32_t a) -> uint32_t { return smem[a]; };
+    auto lds_u32 = [&](uint32_t a) -> uint32_t { return *reinterpret_cast<const uint32_t *>(smem + a); };
+    auto ring_at = [&](uint32_t slot, uint32_t off) -> double2 * { return reinterpret_cast<double2 *>(smem + slot * RS + off); };
+    // four bytes smem[a .. a+3] as one dword (a need not be aligned)
+    auto window4 = [&](uint32_t a) -> uint32_t {
+        const uint32_t al = a & ~3u;
+        return __builtin_amdgcn_alignbyte(lds_u32(al + 4), lds_u32(al), a & 3u);
+    };
+    auto delta_bit = [&](int t) -> int {  // c[t] - c[t-1], t >= 1 (uniform)
+        const uint32_t b = lds_u8(S_DELTA + (uint32_t)(t >> 3));
+        return (uni((int)b) >> (t & 7)) & 1;
+    };
+    auto delta_byte = [&](int k) -> uint32_t { return (uint32_t)uni((int)lds_u8(S_DELTA + (uint32_t)k)); };
+    __syncthreads();
+    {  // stage the codes (as byte offsets, zero padded), the emission tables and the band deltas
+                for (int p = lane; p < L + 2 * PAD; p += 64) {
+            const int q = p - PAD;
+            smem[S_XS + p] = (q >= 0 && q < L) ? (uint8_t)(gx[q] << 5) : (uint8_t)0;
+        }
+                for (int p = lane; p < n + 1 + 2 * PAD + 16; p += 64) {
+            const int q = p - PAD;
+            smem[S_EY + p] = (q >= 1 && q <= n) ? (uint8_t)(gy[q] << 3) : (uint8_t)0;
+        }
+        if (lane < 16) reinterpret_cast<double *>(smem + S_EM)[lane] = h->eM[lane];
+        if (lane < 20) reinterpret_cast<double *>(smem + S_EI)[lane] = h->eI[lane];
+        for (int wdx = lane; wdx < (T >> 6) + 2; wdx += 64) s_delta[wdx] = delta[wdx];
+    }
+    __syncthreads();
+    // scalar operands of every FMA of the recurrences
+    const double aMM = uni_f64(h->a[0]), aMI = uni_f64(h->a[1]), aMD = uni_f64(h->a[2]), aIM = uni_f64(h->a[3]),
+                 aII = uni_f64(h->a[4]), aID = uni_f64(h->a[5]), aDM = uni_f64(h->a[6]), aDI = uni_f64(h->a[7]),
+                 aDD = uni_f64(h->a[8]);
+    const uint64_t BAND = (2ull << (2 * r)) - 1;  // 2r+1 ones
+
+    // =========================== forward ===========================
+    int c = 0, EF = 0;                                   // c == c[t-1] between steps
+    double toM_1 = 0, toM_2 = 0, toI_1 = 0, toD_1 = 0;  // combos of diagonals t-1 / t-2; exact zeros outside the band
+    double endM = 0, endI = 0, endD = 0;
+    {  // t == 0: the only cell is (0, 0), on lane 0
+        const double fm = lane == 0 ? 1.0 : 0.0;
+        toM_1 = fm * aMM;
+        toI_1 = fm * aMI;
+        toD_1 = fm * aMD;
+        scratch[lane] = make_double2(0.0, toD_1);
+        if (lane == 0) s_EF[0] = 0;
+        if (T == 0) endM = fm;
+    }
+    int row = 0;        // fast groups: the lane's template row (a spare lane: the row it takes next)
+    uint32_t xrow = 0;  // fast groups: LDS address of the eM row of x[row-1]
+    {
+        int t = 1;
+        bool fast_ready = false;
+        uint64_t band = 0;
+        int lo6 = 0;
+        while (t <= T) {
+            uint32_t db = 0;
+            bool fast = (t & 7) == 0 && t >= f_lo && t + 7 <= f_hi;
+#ifdef JTK_PHMM_NOFAST_FWD
+            fast = false;
+#endif
+            if (fast) {
+                db = delta_byte(t >> 3);
+                // a lane that leaves the band takes its next row at the THIRD move after its own (three spare lanes): its
+                // registers (row, emission row, read-byte window) are refreshed per half group, so a half may hold 3 moves
+                fast = (db & 0xfu) != 0xfu && (db >> 4) != 0xfu;
+            }
+            if (!fast) {
+                // ---- generic step: per-lane predicates (the ends of the sweep)
+                fast_ready = false;
+                c += delta_bit(t);
+                const int lo = c - r, off = (lane - lo) & 63, i = lo + off, j = t - i;
+                const bool active = off <= 2 * r && (unsigned)i <= (unsigned)L && (unsigned)j <= (unsigned)n;
+                const uint32_t ey8 = lds_u8(EY0 + j), xs = lds_u8(XS0 + i);
+                const double eMv = lds_f64(S_EM + xs + (ey8 & 24)), eIv = lds_f64(S_EI + ey8);
+                const double pM = rot_from_prev(toM_2), pD = rot_from_prev(toD_1);
+                double fm = eMv * pM, fi = eIv * toI_1, fd = pD;
+                if (!active) fm = fi = fd = 0.0;
+                const double toM_prev = toM_1;
+                if ((t & (JTK_SCALE_BLOCK - 1)) == 0) {
+                    double mx = fm > fi ? fm : fi;
+                    mx = fd > mx ? fd : mx;
+                    mx = wave_max(mx);
+                    if (mx > 0.0) {
+                        const int e = uni(jtk_ilogb_pos(mx));
+                        const double sc = pow2i(-e);
+                        fm *= sc;
+                        fi *= sc;
+                        fd *= sc;
+                        toM_1 *= sc;
+                        EF += e;
+                    }
+                    if (lane == 0) s_EF[t >> 6] = EF;
+                }
+                const double toM = fma(fd, aDM, fma(fi, aIM, fm * aMM));
+                const double toI = fma(fd, aDI, fma(fi, aII, fm * aMI));
+                const double toD = fma(fd, aDD, fma(fi, aID, fm * aMD));
+                scratch[(int64_t)t * 64 + lane] = make_double2(toM_prev, toD);
+                toM_2 = toM_1;
+                toM_1 = toM;
+                toI_1 = toI;
+                toD_1 = toD;
+                if (t == T) {
+                    endM = fm;
+                    endI = fi;
+                    endD = fd;
+                }
+                t += 1;
+                continue;
+            }
+            // ---- a group of 8 diagonals t .. t+7 inside the interval: EXEC == the band
+            if (!fast_ready) {  // c == c[t-1]
+                const int lo = c - r;
+                lo6 = lo & 63;
+                row = lo + ((lane - lo) & 63);
+                xrow = S_EM + lds_u8(XS0 + row);
+                band = rotl64(BAND, lo6);
+                fast_ready = true;
+            }
+            uint32_t W = 0;  // the read bytes of the half group's columns j .. j+3, j = (t + u) - row
+            double2 *out = scratch + (int64_t)t * 64;
+            const bool block_start = (t & (JTK_SCALE_BLOCK - 1)) == 0;  // step u == 0 opens a scaling block
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if ((u & 3) == 0) W = window4(EY0 + (uint32_t)(t + u - row));
+                const double pM = rot_from_prev(toM_2), pD = rot_from_prev(toD_1);
+                toM_2 = toM_1;  // every lane: a lane outside the band shifts its zeros along
+                if ((db >> u) & 1) {  // the band moves up: row c - r leaves it, its lane is spare for the next three moves
+                    if (lanes(1ull << lo6)) {
+                        KEEP_MASKED;
+                        toM_1 = 0.0;
+                        toI_1 = 0.0;
+                        toD_1 = 0.0;
+                        row += 64;
+                        xrow = S_EM + lds_u8(XS0 + row);
+                    }
+                    lo6 = (lo6 + 1) & 63;
+                    c += 1;
+                    band = (band << 1) | (band >> 63);
+                }
+                const bool in_band = lanes(band);
+                const uint32_t byte = (W >> (8 * (u & 3))) & 0xffu;
+                if (u == 0) {
+                    // the group's first diagonal may open a scaling block (the maximum over the band decides the block's
+                    // exponent): the band's work is split around that rare step
+                    double fm = 0.0, fi = 0.0, fd = 0.0;
+                    if (in_band) {
+                        KEEP_MASKED;
+                        const double eMv = lds_f64(xrow | (byte & 24u)), eIv = lds_f64(S_EI + byte);
+                        fm = eMv * pM;
+                        fi = eIv * toI_1;
+                        fd = pD;
+                    }
+                    double sc = 1.0;
+                    if (block_start) {
+                        KEEP_MASKED;
+                        double mx = fm > fi ? fm : fi;
+                        mx = fd > mx ? fd : mx;
+                        mx = wave_max(mx);
+                        if (mx > 0.0) {
+                            const int e = uni(jtk_ilogb_pos(mx));
+                            sc = pow2i(-e);
+                            EF += e;
+                        }
+                        if (lane == 0) s_EF[t >> 6] = EF;
+                        fm *= sc;
+                        fi *= sc;
+                        fd *= sc;
+                    }
+                    if (in_band) {
+                        KEEP_MASKED;
+                        toM_1 = fma(fd, aDM, fma(fi, aIM, fm * aMM));
+                        toI_1 = fma(fd, aDI, fma(fi, aII, fm * aMI));
+                        toD_1 = fma(fd, aDD, fma(fi, aID, fm * aMD));
+                    }
+                    out[u * 64 + lane] = make_double2(toM_2, toD_1);  // toM of diagonal t-1 goes out in ITS block's scale ...
+                    if (block_start) {
+                        KEEP_MASKED;
+                        toM_2 *= sc;  // ... and is re-expressed for the steps that read it
+                    }
+                } else {
+                    if (in_band) {
+                        KEEP_MASKED;
+                        const double eMv = lds_f64(xrow | (byte & 24u)), eIv = lds_f64(S_EI + byte);
+                        const double fm = eMv * pM, fi = eIv * toI_1, fd = pD;
+                        toM_1 = fma(fd, aDM, fma(fi, aIM, fm * aMM));
+                        toI_1 = fma(fd, aDI, fma(fi, aII, fm * aMI));
+                        toD_1 = fma(fd, aDD, fma(fi, aID, fm * aMD));
+                    }
+                    out[u * 64 + lane] = make_double2(toM_2, toD_1);
+                }
+            }
+            t += 8;
+        }
+    }
+    scratch[(int64_t)(T + 1) * 64 + lane] = make_double2(toM_1, 0.0);  // P_{T+1} = (toM of diagonal T, nothing)
+    const int lane_end = L & 63;  // cell (L, n) sits on the lane that owns row L
+    double tot = (endM + endI) + endD;
+    tot = __shfl(tot, lane_end, 64);
+    const double lk = tot > 0.0 ? jtk_log(tot) + (double)EF * JTK_LN2 : JTK_LOG_ZERO;
+    if (lane == 0) *lk_out = lk;
+    __syncthreads();  // s_EF visible; forward stores are read back by this same wave below
+
+    // =========================== backward + row sums ===========================
+    double acc[JTK_ACC_N];
+#pragma unroll
+    for (int k = 0; k < JTK_ACC_N; k++) acc[k] = 0.0;
+    double hM_1 = 0, hM_2 = 0, hI_1 = 0, bD_1 = 0;  // hatM(t+1), hatM(t+2), hatI(t+1), b_D(t+1)
+    int EB = 0, Gprev = 0;
+    // c == c[T] here (== c[t+1] between steps); c5 = c[t-5], c4 = c[t-4] for the del-3 source rows
+    int c5 = c, c4 = c;
+    {
+        int cc = c, tt = T;
+        for (int k = 0; k < 4 && tt >= 1; k++, tt--) cc -= delta_bit(tt);
+        c4 = cc;
+        if (tt >= 1) cc -= delta_bit(tt);
+        c5 = cc;
+    }
+    auto rel = [&](int d, int blk) -> double {  // 2^(EF[block of diagonal d] - EF[blk])
+        if (d < 0 || d > T) return 1.0;
+        return fast_pow2(uni(s_EF[d >> 6]) - uni(s_EF[blk]));
+    };
+    // ring: slot s & 7 holds P_s, in the scale of the block of the step that reads it
+    *ring_at((T + 2) & 7, lane16) = make_double2(0.0, 0.0);
+    for (int ss = T + 1; ss >= T - 4; ss--) {
+        double2 v = scratch[(int64_t)ss * 64 + lane];
+        v.x *= rel(ss - 1, T >> 6);
+        v.y *= rel(ss, T >> 6);
+        *ring_at(ss & 7, lane16) = v;
+    }
+    int EFcur = uni(s_EF[T >> 6]);  // forward exponent of the block the sweep is in
+    // the row sums of a row: acc[0..3] sub by read base (toM part), acc[4] sub (toD part), acc[5..8] ins, acc[9] ins (toD),
+    // acc[10..12] copy 1..3, acc[13..15] del 1..3; vm / vd / hM are the backward values of the cell, a_k the pair of row i+k
+#define ROW_SUMS_PLAIN(a_m3, a_m2, a_m1, a_0, a_p1, a_p2, vdv, hMv)                                      \
+{                                                                                                  \
+    acc[4] = fma((a_m1).y, vdv, acc[4]);                                                           \
+    acc[9] = fma((a_0).y, vdv, acc[9]);                                                            \
+    acc[10] = fma((a_0).y, vdv, fma((a_0).x, hMv, acc[10]));                                       \
+    acc[11] = fma((a_p1).y, vdv, fma((a_p1).x, hMv, acc[11]));                                     \
+    acc[12] = fma((a_p2).y, vdv, fma((a_p2).x, hMv, acc[12]));                                     \
+    acc[13] = fma((a_m2).y, vdv, fma((a_m2).x, hMv, acc[13]));                                     \
+    acc[14] = fma((a_m3).y, vdv, fma((a_m3).x, hMv, acc[14]));                                     \
+}
+    {
+        int t = T;
+        bool fast_ready = false;
+        uint64_t band = 0;
+        int lo6 = 0;
+        int rowG = 0;  // exponent of the lane's finished row, until the group's flush
+        // pairs on their way from the stripe: qA = those the steps u = 0..3 of the coming group put into the ring (loaded
+        // while the previous group ran its steps 4..7), qB = those of the steps u = 4..7 (loaded at the group's start)
+        double2 qA[4], qB[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) qA[k] = qB[k] = make_double2(0.0, 0.0);
+        while (t >= 0) {
+            uint32_t w16 = 0;
+            bool fast = (t & 7) == 7 && t - 7 >= f_lo && t <= f_hi && t < T && t >= 23;
+#ifdef JTK_PHMM_NOFAST_BWD
+            fast = false;
+#endif
+            int carry = 0;
+            if (fast) {
+                w16 = delta_byte(t >> 3) << 8 | delta_byte((t >> 3) - 1);  // bit k: c[t-15+k] - c[t-16+k]
+                carry = delta_bit(t + 1);
+                // band moves at the steps t .. t-3 / t-4 .. t-7: at most three per half group (see the forward sweep)
+                fast = carry + __builtin_popcount((w16 >> 13) & 7u) <= 3 && ((w16 >> 9) & 0xfu) != 0xfu;
+            }
+            if (!fast) {
+                // ---- generic step
+                fast_ready = false;
+                if (t < T && (t & 63) == 63) {  // the sweep enters the block below: re-express the ring
+                    const int EFabove = EFcur;
+                    EFcur = uni(s_EF[t >> 6]);
+                    const double f = fast_pow2(EFabove - EFcur);
+#pragma unroll
+                    for (int sl = 0; sl < 8; sl++) {
+                        double2 v = *ring_at(sl, lane16);
+                        v.x *= f;
+                        v.y *= f;
+                        *ring_at(sl, lane16) = v;
+                    }
+                }
+                const int dn = t < T ? delta_bit(t + 1) : 0;
+                c -= dn;  // c == c[t]
+                const int lo = c - r, off = (lane - lo) & 63, i = lo + off, j = t - i;
+                const bool active = off <= 2 * r && (unsigned)i <= (unsigned)L && (unsigned)j <= (unsigned)n;
+                if (dn == 1 && off == 2 * r + 1 && (unsigned)i <= (unsigned)L) {  // the row that left the band is final
+#ifdef JTK_PHMM_DEBUG
+                    if (i >= L - 1) printf("flush T %d t %d i %d lane %d acc10 %g acc11 %g acc12 %g acc13 %g G %d\n", T, t, i, lane, acc[10], acc[11], acc[12], acc[13], Gprev);
+#endif
+                    double2 *dst = reinterpret_cast<double2 *>(raw + (uint64_t)i * JTK_ACC_N);
+#pragma unroll
+                    for (int k = 0; k < JTK_ACC_N / 2; k++) dst[k] = make_double2(acc[2 * k], acc[2 * k + 1]);
+                    rawG[i] = Gprev;
+#pragma unroll
+                    for (int k = 0; k < JTK_ACC_N; k++) acc[k] = 0.0;
+                }
+                {  // the pair five diagonals below enters the ring (its slot is not read by this step)
+                    double2 v = scratch[(int64_t)(t - 5) * 64 + lane];
+                    if ((t & 63) <= 5) {
+                        v.x *= rel(t - 6, t >> 6);
+                        v.y *= rel(t - 5, t >> 6);
+                    }
+                    *ring_at((t - 5) & 7, lane16) = v;
+                }
+                double vm, vi, vd;
+                if (t == T) {
+                    vm = vi = vd = 1.0;
+                } else {
+                    const double xm = rot_from_next(hM_2), xd = rot_from_next(bD_1), xi = hI_1;
+                    vm = fma(aMD, xd, fma(aMI, xi, aMM * xm));
+                    vi = fma(aID, xd, fma(aII, xi, aIM * xm));
+                    vd = fma(aDD, xd, fma(aDI, xi, aDM * xm));
+                }
+                if (!active) vm = vi = vd = 0.0;
+                if (t < T && (t & (JTK_SCALE_BLOCK - 1)) == JTK_SCALE_BLOCK - 1) {
+                    double mx = vm > vi ? vm : vi;
+                    mx = vd > mx ? vd : mx;
+                    mx = wave_max(mx);
+                    if (mx > 0.0) {
+                        const int e = uni(jtk_ilogb_pos(mx));
+                        const double sc = pow2i(-e);
+                        vm *= sc;
+                        vi *= sc;
+                        vd *= sc;
+                        hM_1 *= sc;
+                        EB += e;
+                    }
+                }
+                const uint32_t ey8 = lds_u8(EY0 + j), xs = lds_u8(XS0 + i), y8 = ey8 & 24u;
+                const double hM = lds_f64(S_EM + xs + y8) * vm;
+                const double hI = lds_f64(S_EI + ey8) * vi;
+                const int G = EFcur + EB;
+                if (t < T && G != Gprev) {
+                    const double sc = pow2i(Gprev - G);
+#pragma unroll
+                    for (int k = 0; k < JTK_ACC_N; k++) acc[k] *= sc;
+                }
+                Gprev = G;
+                {
+                    const uint32_t s0 = (uint32_t)t;
+                    double2 a_m4 = *ring_at((s0 - 4) & 7, RK[0]);
+                    const double2 a_m3 = *ring_at((s0 - 3) & 7, RK[1]), a_m2 = *ring_at((s0 - 2) & 7, RK[2]),
+                                  a_m1 = *ring_at((s0 - 1) & 7, RK[3]), a_0 = *ring_at(s0 & 7, RK[4]),
+                                  a_p1 = *ring_at((s0 + 1) & 7, RK[5]), a_p2 = *ring_at((s0 + 2) & 7, RK[6]);
+#ifdef JTK_PHMM_DEBUG
+                    if (active && i >= L - 1 && (a_p2.x != 0.0 || a_p2.y != 0.0 || (i == L && (a_p1.x != 0.0 || a_p1.y != 0.0))))
+                        printf("t %d T %d i %d j %d lane %d c %d a_p1 %g %g a_p2 %g %g vd %g hM %g\n", t, T, i, j, lane, c, a_p1.x, a_p1.y, a_p2.x,
+                               a_p2.y, vd, hM);
+#endif
+                    // the only source row the 3 spare lanes cannot disambiguate
+                    if (!(i - 4 >= c5 - r)) a_m4.x = 0.0;
+                    if (!(i - 4 >= c4 - r)) a_m4.y = 0.0;
+                    double vmq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) vmq[q] = y8 == 8u * q ? vm : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        acc[q] = fma(a_m1.x, vmq[q], acc[q]);
+                        acc[5 + q] = fma(a_0.x, vmq[q], acc[5 + q]);
+                    }
+                    ROW_SUMS_PLAIN(a_m3, a_m2, a_m1, a_0, a_p1, a_p2, vd, hM)
+                    acc[15] = fma(a_m4.y, vd, fma(a_m4.x, hM, acc[15]));
+                }
+                hM_2 = hM_1;
+                hM_1 = hM;
+                hI_1 = hI;
+                bD_1 = vd;
+                c4 = c5;
+                if (t - 5 >= 1) c5 -= delta_bit(t - 5);
+                t -= 1;
+                continue;
+            }
+            // ---- a group of 8 diagonals t .. t-7 inside the interval
+            if (!fast_ready) {  // c == c[t+1]
+                const int lo = c - r, off = (lane - lo) & 63;
+                lo6 = lo & 63;
+                row = off <= 2 * r ? lo + off : lo + off - 64;
+                xrow = S_EM + lds_u8(XS0 + row);
+                band = rotl64(BAND, lo6);
+                fast_ready = true;
+#pragma unroll
+                for (int k = 0; k < 4; k++) qA[k] = scratch[(int64_t)(t - 5 - k) * 64 + lane];
+            }
+            const int tb = t;
+#ifdef JTK_PHMM_DEBUG
+            if (T == 3989 && (lane == 15 || lane == 16) && tb > 3900) printf("group T %d tb %d lane %d row %d acc11 %g acc12 %g c %d\n", T, tb, lane, row, acc[11], acc[12], c);
+#endif
+            uint32_t W = 0;     // read bytes of the half group's columns j-3 .. j, j = (tb - u) - row: step u uses byte 3 - (u & 3)
+            uint64_t left = 0;  // lanes whose row left the band in this half group
+            const bool low_group = (tb & 63) == 7;  // pairs entering at u >= 2 come from the block below
+            const bool block_end = (tb & (JTK_SCALE_BLOCK - 1)) == JTK_SCALE_BLOCK - 1;  // step u == 0 closes a scaling block
+            double Fsp = 1.0;
+            if (low_group) Fsp = fast_pow2(uni(s_EF[(tb >> 6) - 1]) - uni(s_EF[tb >> 6]));
+            const double2 *pin = scratch + (int64_t)(tb - 5) * 64 + lane;  // P_{tb-5}; step u puts pin[-64 u] into the ring
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if ((u & 3) == 0) W = window4(EY0 + (uint32_t)(tb - u - row - 3));
+                if (u == 0 && block_end) {  // the sweep enters the block below: re-express the ring
+                    const int EFabove = EFcur;
+                    EFcur = uni(s_EF[tb >> 6]);
+                    const double f = fast_pow2(EFabove - EFcur);
+#pragma unroll
+                    for (int sl = 0; sl < 8; sl++) {
+                        double2 v = *ring_at(sl, lane16);
+                        v.x *= f;
+                        v.y *= f;
+                        *ring_at(sl, lane16) = v;
+                    }
+                }
+                const double xm = rot_from_next(hM_2), xd = rot_from_next(bD_1);
+                hM_2 = hM_1;  // every lane
+                const int dn = u == 0 ? carry : (int)((w16 >> (16 - u)) & 1u);  // c[t+1] - c[t]
+                if (dn) {  // the band moves down: row c + r leaves it, final
+                    const int hi6 = (lo6 + 2 * r) & 63;
+                    if (lanes(1ull << hi6)) {
+                        KEEP_MASKED;
+                        hM_1 = 0.0;
+                        hI_1 = 0.0;
+                        bD_1 = 0.0;
+                        rowG = Gprev;
+                        row -= 64;
+                        xrow = S_EM + lds_u8(XS0 + row);
+                    }
+                    left |= 1ull << hi6;
+                    lo6 = (lo6 - 1) & 63;
+                    c -= 1;
+                    band = (band >> 1) | (band << 63);
+                }
+                if (u == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) qB[k] = pin[-64 * (4 + k)];
+                }
+                {  // the pair five diagonals below enters the ring
+                    double2 v = u < 4 ? qA[u & 3] : qB[u & 3];
+                    if (u == 3) {  // qA is free again: the next group's first four pairs (a group that turns out generic
+                                   // reloads what it needs)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) qA[k] = pin[-64 * (8 + k)];
+                    }
+                    if (u >= 2 && low_group) {
+                        KEEP_MASKED;  // a (rare) uniform branch, not two selects per step
+                        v.x *= Fsp;
+                        if (u >= 3) v.y *= Fsp;
+                    }
+                    *ring_at((7 - u - 5) & 7, lane16) = v;
+                }
+                const bool in_band = lanes(band);
+                const uint32_t byte = (W >> (8 * (3 - (u & 3)))) & 0xffu;
+                const uint32_t y8 = byte & 24u;
+                const int thr_x = c5 - r + 4, thr_y = c4 - r + 4;  // the del-3 source row i-4 must be >= c[t-5]-r / c[t-4]-r
+#ifdef JTK_PHMM_DEBUG
+#define DBG_PRODUCTS(a_p1, a_p2, vdv, hMv)                                                                                     \
+    if ((lane == 15 || lane == 16) && T == 3989 && tb > 3920)                   \
+        printf("fast T %d tb %d u %d row %d lane %d c %d lo6 %d a_p1 %g %g a_p2 %g %g vd %g hM %g acc12 %g\n", T, tb, u, row, lane, c, lo6, \
+               a_p1.x, a_p1.y, a_p2.x, a_p2.y, vdv, hMv, acc[12]);
+#else
+#define DBG_PRODUCTS(a_p1, a_p2, vdv, hMv)
+#endif
+#define BWD_PRODUCTS(vmv, vdv, hMv)                                                                                          \
+{                                                                                                                        \
+    const double2 a_m4 = *ring_at((7 - u - 4) & 7, RK[0]);                                                               \
+    const double2 a_m3 = *ring_at((7 - u - 3) & 7, RK[1]), a_m2 = *ring_at((7 - u - 2) & 7, RK[2]),                       \
+                  a_m1 = *ring_at((7 - u - 1) & 7, RK[3]), a_0 = *ring_at((7 - u) & 7, RK[4]),                           \
+                  a_p1 = *ring_at((7 - u + 1) & 7, RK[5]), a_p2 = *ring_at((7 - u + 2) & 7, RK[6]);                       \
+    DBG_PRODUCTS(a_p1, a_p2, vdv, hMv)                                                                                   \
+    BASE_FMA(0, acc[0], acc[5], a_m1.x, a_0.x, vmv, y8)                                                                  \
+    BASE_FMA(1, acc[1], acc[6], a_m1.x, a_0.x, vmv, y8)                                                                  \
+    BASE_FMA(2, acc[2], acc[7], a_m1.x, a_0.x, vmv, y8)                                                                  \
+    BASE_FMA(3, acc[3], acc[8], a_m1.x, a_0.x, vmv, y8)                                                                  \
+    ROW_SUMS_PLAIN(a_m3, a_m2, a_m1, a_0, a_p1, a_p2, vdv, hMv)                                                          \
+    DEL3_FMA(acc[15], a_m4.x, a_m4.y, hMv, vdv, row, thr_x, thr_y)                                                       \
+}
+                if (u == 0) {
+                    // the group's first diagonal may close a scaling block (the maximum over the band decides the backward
+                    // exponent): the band's work is split around that rare step
+                    double vm = 0.0, vi = 0.0, vd = 0.0;
+                    if (in_band) {
+                        KEEP_MASKED;
+                        vm = fma(aMD, xd, fma(aMI, hI_1, aMM * xm));
+                        vi = fma(aID, xd, fma(aII, hI_1, aIM * xm));
+                        vd = fma(aDD, xd, fma(aDI, hI_1, aDM * xm));
+                    }
+                    if (block_end) {
+                        KEEP_MASKED;
+                        double mx = vm > vi ? vm : vi;
+                        mx = vd > mx ? vd : mx;
+                        mx = wave_max(mx);
+                        if (mx > 0.0) {
+                            const int e = uni(jtk_ilogb_pos(mx));
+                            const double sc = pow2i(-e);
+                            vm *= sc;
+                            vi *= sc;
+                            vd *= sc;
+                            hM_2 *= sc;  // hatM of diagonal t+1 (already shifted), every lane
+                            EB += e;
+                        }
+                        const int G = EFcur + EB;
+                        if (G != Gprev) {
+                            const double sca = pow2i(Gprev - G);
+                            if (in_band) {
+                                KEEP_MASKED;
+#pragma unroll
+                                for (int k = 0; k < JTK_ACC_N; k++) acc[k] *= sca;
+                            }
+                        }
+                        Gprev = G;
+                    }
+                    if (in_band) {
+                        KEEP_MASKED;
+                        const double hM = lds_f64(xrow | y8) * vm, hI = lds_f64(S_EI + byte) * vi;
+                        BWD_PRODUCTS(vm, vd, hM)
+                        hM_1 = hM;
+                        hI_1 = hI;
+                        bD_1 = vd;
+                    }
+                } else {
+                    if (in_band) {
+                        KEEP_MASKED;
+                        const double eMv = lds_f64(xrow | y8), eIv = lds_f64(S_EI + byte);
+                        const double vm = fma(aMD, xd, fma(aMI, hI_1, aMM * xm));
+                        const double vi = fma(aID, xd, fma(aII, hI_1, aIM * xm));
+                        const double vd = fma(aDD, xd, fma(aDI, hI_1, aDM * xm));
+                        const double hM = eMv * vm, hI = eIv * vi;
+                        BWD_PRODUCTS(vm, vd, hM)
+                        hM_1 = hM;
+                        hI_1 = hI;
+                        bD_1 = vd;
+                    }
+                }
+#undef BWD_PRODUCTS
+                c4 = c5;
+                c5 -= (int)((w16 >> (10 - u)) & 1u);  // c[t-5] - c[t-6]
+                // the rows that left the band during the half group are final: they sat untouched in their (idle) lanes
+                if ((u & 3) == 3 && lanes(left)) {
+                KEEP_MASKED;
+#ifdef JTK_PHMM_DEBUG
+                if (row + 64 >= L - 1) printf("fastflush T %d tb %d row %d lane %d acc10 %g acc11 %g acc12 %g acc13 %g G %d\n", T, tb, row + 64, lane, acc[10], acc[11], acc[12], acc[13], rowG);
+#endif
+                double2 *dst = reinterpret_cast<double2 *>(raw + (uint64_t)(row + 64) * JTK_ACC_N);
+#pragma unroll
+                for (int k = 0; k < JTK_ACC_N / 2; k++) dst[k] = make_double2(acc[2 * k], acc[2 * k + 1]);
+                rawG[row + 64] = rowG;
+#pragma unroll
+                for (int k = 0; k < JTK_ACC_N; k++) acc[k] = 0.0;
+                }
+                if ((u & 3) == 3) left = 0;
+            }
+            t -= 8;
+        }
+        // rows still in the band after t == 0; c == c[0]
+        {
+            const int lo = c - r, off = (lane - lo) & 63, i = lo + off;
+            if (off <= 2 * r && (unsigned)i <= (unsigned)L) {
+                double2 *dst = reinterpret_cast<double2 *>(raw + (uint64_t)i * JTK_ACC_N);
+#pragma unroll
+                for (int k = 0; k < JTK_ACC_N / 2; k++) dst[k] = make_double2(acc[2 * k], acc[2 * k + 1]);
+                rawG[i] = Gprev;
+            }
+        }
+    }
+#undef ROW_SUMS_PLAIN
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64, 3) __attribute__((amdgpu_num_vgpr(JTK_PHMM_NUM_VGPR))) void phmm_kernel(
+    uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks, const ChunkState *state, DevBufs bufs,
+    const uint8_t *ey_all, const uint64_t *delta_all, const HmmDev *hmm2, double *scratch_all, uint64_t scratch_stride,
+    uint32_t *work_counter, double *raw_all, int *rawG_all, double *lk_all, uint32_t lds_tmpl, uint32_t lds_read,
+    int only_active, uint32_t skip_le_radius) {
+    const int lane = threadIdx.x;
+    // the stripe starts with JTK_SCRATCH_GUARD rows of zeros: "the pair of a diagonal below 0" is an ordinary load
+    double2 *scratch = reinterpret_cast<double2 *>(scratch_all + (uint64_t)blockIdx.x * scratch_stride) + JTK_SCRATCH_GUARD * 64;
+#pragma unroll
+    for (int g = 1; g <= JTK_SCRATCH_GUARD; g++) scratch[-g * 64 + lane] = make_double2(0.0, 0.0);
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(work_counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_reads) break;
+        const ReadMeta rm = reads[item];
+        const ChunkMeta cm = chunks[rm.chunk];
+        const ChunkState st = state[rm.chunk];
+        if (st.status != 0) continue;
+        if (only_active && !st.active) continue;
+        if (cm.take_num && item - cm.read_first >= cm.take_num) continue;  // this read does not vote
+        if (cm.radius > JTK_MAX_RADIUS) continue;                          // phmm_wide_kernel's read
+        if (cm.radius <= skip_le_radius) continue;                         // phmm_pair_kernel's read
+        const uint64_t *delta = delta_all + rm.delta_off;
+        // the interval of diagonals whose whole band lies inside the DP matrix (band_prep_kernel)
+        const uint64_t fastw = delta[((cm.tmpl_cap + rm.read_len) >> 6) + 2];
+        // everything below was loaded through the vector memory path: make it scalar again (it is the same in every lane),
+        // or the sweeps' control flow and addressing would be per-lane
+        const int strand = uni((int)rm.strand), buf = uni((int)st.buf);
+        sweep_read(uni((int)st.tmpl_len), uni((int)rm.read_len), uni((int)cm.radius), uni((int)(uint32_t)fastw),
+                   uni((int)(uint32_t)(fastw >> 32)), hmm2 + (strand ? 0 : 1), bufs.tmpl[buf] + uni64(cm.tmpl_off),
+                   ey_all + uni64(rm.ey_off), delta_all + uni64(rm.delta_off), scratch, raw_all + uni64(rm.raw_off),
+                   rawG_all + uni64(rm.row_off), lk_all + item, lds_tmpl, lds_read);
+    }
+}
+
+size_t phmm_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
+    const uint32_t n_blk = ((max_tmpl + max_read) >> 6) + 4;
+    size_t b = S_VAR + (size_t)n_blk * 12;
+    b = (b + 15) & ~(size_t)15;
+    b += ((max_tmpl + 2 * PAD + 15) & ~15u) + max_read + 1 + 2 * PAD + 16;
+    return (b + 15) & ~(size_t)15;
+}
+
+void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
+                 const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta,
+                 const HmmDev *hmm2, double *scratch, uint64_t scratch_stride, uint32_t n_waves,
+                 uint32_t *work_counter, double *raw, int *rawG, double *lk, uint32_t max_tmpl,
+                 uint32_t max_read, int only_active, uint32_t skip_le_radius) {
+    if (n_reads == 0) return;
+#ifdef JTK_PHMM_WITH_R2
+    if (getenv("JTK_PHMM_R2")) {
+        launch_phmm_r2(s, n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch, scratch_stride, n_waves, work_counter, raw,
+                       rawG, lk, max_tmpl, max_read, only_active, skip_le_radius);
+        return;
+    }
+#endif
+    (void)hipMemsetAsync(work_counter, 0, sizeof(uint32_t), s);
+    const size_t lds = phmm_lds_bytes(max_tmpl, max_read);
+    phmm_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch,
+                                         scratch_stride, work_counter, raw, rawG, lk, max_tmpl, max_read,
+                                         only_active, skip_le_radius);
+}
