@@ -41,24 +41,14 @@ namespace {
 
 __device__ __forceinline__ double rot_from_prev(double v) {  // lane l <- lane (l-1)&63
     int lo = __double2loint(v), hi = __double2hiint(v);
-#ifdef JTK_PHMM_DPP_OLD
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x13C, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x13C, 0xF, 0xF, false);
-#else
     lo = __builtin_amdgcn_mov_dpp(lo, 0x13C, 0xF, 0xF, false);  // wave_ror:1 (every lane has a source: no `old` value needed)
     hi = __builtin_amdgcn_mov_dpp(hi, 0x13C, 0xF, 0xF, false);
-#endif
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double rot_from_next(double v) {  // lane l <- lane (l+1)&63
     int lo = __double2loint(v), hi = __double2hiint(v);
-#ifdef JTK_PHMM_DPP_OLD
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x134, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xF, 0xF, false);
-#else
     lo = __builtin_amdgcn_mov_dpp(lo, 0x134, 0xF, 0xF, false);  // wave_rol:1
     hi = __builtin_amdgcn_mov_dpp(hi, 0x134, 0xF, 0xF, false);
-#endif
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_max(double v) {
@@ -318,7 +308,9 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                         toI_1 = fma(fd, aDI, fma(fi, aII, fm * aMI));
                         toD_1 = fma(fd, aDD, fma(fi, aID, fm * aMD));
                     }
+#ifndef JTK_PHMM_X_NOSTORE
                     out[u * 64 + lane] = make_double2(toM_2, toD_1);  // toM of diagonal t-1 goes out in ITS block's scale ...
+#endif
                     if (block_start) {
                         KEEP_MASKED;
                         toM_2 *= sc;  // ... and is re-expressed for the steps that read it
@@ -332,7 +324,9 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                         toI_1 = fma(fd, aDI, fma(fi, aII, fm * aMI));
                         toD_1 = fma(fd, aDD, fma(fi, aID, fm * aMD));
                     }
+#ifndef JTK_PHMM_X_NOSTORE
                     out[u * 64 + lane] = make_double2(toM_2, toD_1);
+#endif
                 }
             }
             t += 8;
@@ -430,9 +424,6 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 const int lo = c - r, off = (lane - lo) & 63, i = lo + off, j = t - i;
                 const bool active = off <= 2 * r && (unsigned)i <= (unsigned)L && (unsigned)j <= (unsigned)n;
                 if (dn == 1 && off == 2 * r + 1 && (unsigned)i <= (unsigned)L) {  // the row that left the band is final
-#ifdef JTK_PHMM_DEBUG
-                    if (i >= L - 1) printf("flush T %d t %d i %d lane %d acc10 %g acc11 %g acc12 %g acc13 %g G %d\n", T, t, i, lane, acc[10], acc[11], acc[12], acc[13], Gprev);
-#endif
                     double2 *dst = reinterpret_cast<double2 *>(raw + (uint64_t)i * JTK_ACC_N);
 #pragma unroll
                     for (int k = 0; k < JTK_ACC_N / 2; k++) dst[k] = make_double2(acc[2 * k], acc[2 * k + 1]);
@@ -488,11 +479,6 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                     const double2 a_m3 = *ring_at((s0 - 3) & 7, RK[1]), a_m2 = *ring_at((s0 - 2) & 7, RK[2]),
                                   a_m1 = *ring_at((s0 - 1) & 7, RK[3]), a_0 = *ring_at(s0 & 7, RK[4]),
                                   a_p1 = *ring_at((s0 + 1) & 7, RK[5]), a_p2 = *ring_at((s0 + 2) & 7, RK[6]);
-#ifdef JTK_PHMM_DEBUG
-                    if (active && i >= L - 1 && (a_p2.x != 0.0 || a_p2.y != 0.0 || (i == L && (a_p1.x != 0.0 || a_p1.y != 0.0))))
-                        printf("t %d T %d i %d j %d lane %d c %d a_p1 %g %g a_p2 %g %g vd %g hM %g\n", t, T, i, j, lane, c, a_p1.x, a_p1.y, a_p2.x,
-                               a_p2.y, vd, hM);
-#endif
                     // the only source row the 3 spare lanes cannot disambiguate
                     if (!(i - 4 >= c5 - r)) a_m4.x = 0.0;
                     if (!(i - 4 >= c4 - r)) a_m4.y = 0.0;
@@ -528,9 +514,6 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 for (int k = 0; k < 4; k++) qA[k] = scratch[(int64_t)(t - 5 - k) * 64 + lane];
             }
             const int tb = t;
-#ifdef JTK_PHMM_DEBUG
-            if (T == 3989 && (lane == 15 || lane == 16) && tb > 3900) printf("group T %d tb %d lane %d row %d acc11 %g acc12 %g c %d\n", T, tb, lane, row, acc[11], acc[12], c);
-#endif
             uint32_t W = 0;     // read bytes of the half group's columns j-3 .. j, j = (tb - u) - row: step u uses byte 3 - (u & 3)
             uint64_t left = 0;  // lanes whose row left the band in this half group
             const bool low_group = (tb & 63) == 7;  // pairs entering at u >= 2 come from the block below
@@ -574,14 +557,22 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 }
                 if (u == 0) {
 #pragma unroll
+#ifndef JTK_PHMM_X_NOLOAD
                     for (int k = 0; k < 4; k++) qB[k] = pin[-64 * (4 + k)];
+#else
+                    for (int k = 0; k < 4; k++) qB[k] = make_double2(1e-3 * (tb + k), 0.5);
+#endif
                 }
                 {  // the pair five diagonals below enters the ring
                     double2 v = u < 4 ? qA[u & 3] : qB[u & 3];
                     if (u == 3) {  // qA is free again: the next group's first four pairs (a group that turns out generic
                                    // reloads what it needs)
 #pragma unroll
+#ifndef JTK_PHMM_X_NOLOAD
                         for (int k = 0; k < 4; k++) qA[k] = pin[-64 * (8 + k)];
+#else
+                        for (int k = 0; k < 4; k++) qA[k] = make_double2(1e-3 * (tb - k), 0.25);
+#endif
                     }
                     if (u >= 2 && low_group) {
                         KEEP_MASKED;  // a (rare) uniform branch, not two selects per step
@@ -594,21 +585,12 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 const uint32_t byte = (W >> (8 * (3 - (u & 3)))) & 0xffu;
                 const uint32_t y8 = byte & 24u;
                 const int thr_x = c5 - r + 4, thr_y = c4 - r + 4;  // the del-3 source row i-4 must be >= c[t-5]-r / c[t-4]-r
-#ifdef JTK_PHMM_DEBUG
-#define DBG_PRODUCTS(a_p1, a_p2, vdv, hMv)                                                                                     \
-    if ((lane == 15 || lane == 16) && T == 3989 && tb > 3920)                   \
-        printf("fast T %d tb %d u %d row %d lane %d c %d lo6 %d a_p1 %g %g a_p2 %g %g vd %g hM %g acc12 %g\n", T, tb, u, row, lane, c, lo6, \
-               a_p1.x, a_p1.y, a_p2.x, a_p2.y, vdv, hMv, acc[12]);
-#else
-#define DBG_PRODUCTS(a_p1, a_p2, vdv, hMv)
-#endif
 #define BWD_PRODUCTS(vmv, vdv, hMv)                                                                                          \
 {                                                                                                                        \
     const double2 a_m4 = *ring_at((7 - u - 4) & 7, RK[0]);                                                               \
     const double2 a_m3 = *ring_at((7 - u - 3) & 7, RK[1]), a_m2 = *ring_at((7 - u - 2) & 7, RK[2]),                       \
                   a_m1 = *ring_at((7 - u - 1) & 7, RK[3]), a_0 = *ring_at((7 - u) & 7, RK[4]),                           \
                   a_p1 = *ring_at((7 - u + 1) & 7, RK[5]), a_p2 = *ring_at((7 - u + 2) & 7, RK[6]);                       \
-    DBG_PRODUCTS(a_p1, a_p2, vdv, hMv)                                                                                   \
     BASE_FMA(0, acc[0], acc[5], a_m1.x, a_0.x, vmv, y8)                                                                  \
     BASE_FMA(1, acc[1], acc[6], a_m1.x, a_0.x, vmv, y8)                                                                  \
     BASE_FMA(2, acc[2], acc[7], a_m1.x, a_0.x, vmv, y8)                                                                  \
@@ -679,13 +661,12 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 // the rows that left the band during the half group are final: they sat untouched in their (idle) lanes
                 if ((u & 3) == 3 && lanes(left)) {
                 KEEP_MASKED;
-#ifdef JTK_PHMM_DEBUG
-                if (row + 64 >= L - 1) printf("fastflush T %d tb %d row %d lane %d acc10 %g acc11 %g acc12 %g acc13 %g G %d\n", T, tb, row + 64, lane, acc[10], acc[11], acc[12], acc[13], rowG);
-#endif
+#ifndef JTK_PHMM_X_NOFLUSH
                 double2 *dst = reinterpret_cast<double2 *>(raw + (uint64_t)(row + 64) * JTK_ACC_N);
 #pragma unroll
                 for (int k = 0; k < JTK_ACC_N / 2; k++) dst[k] = make_double2(acc[2 * k], acc[2 * k + 1]);
                 rawG[row + 64] = rowG;
+#endif
 #pragma unroll
                 for (int k = 0; k < JTK_ACC_N; k++) acc[k] = 0.0;
                 }

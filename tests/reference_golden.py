@@ -354,10 +354,14 @@ def compare_pileups(gold, mine, tol=1e-4, table_tol=1e-6, what=("tables", "stage
                     bad.append(f"chunk {cid} read {r}: lk differs by {max_abs([gr['lk']], [mr['lk']]):.3g}")
                 if "bootstrap_lk" in mr and max_abs([gr["bootstrap_lk"]], [mr["bootstrap_lk"]]) > tol:
                     bad.append(f"chunk {cid} read {r}: bootstrap lk differs")
-                if len(gr["table"]) != len(mr["table"]):
-                    bad.append(f"chunk {cid} read {r}: table has {len(gr['table'])} entries, expected {len(mr['table'])}")
-                elif max_abs(gr["table"], mr["table"]) > table_tol:
-                    bad.append(f"chunk {cid} read {r}: table differs by {max_abs(gr['table'], mr['table']):.3g}")
+                if "table_minus_lk" in mr:  # the C ABI returns pseudo_mcmc::modification_table's form: table - lk (pseudo_mcmc.rs:64)
+                    gt, mt = bits_vec(unbits(gr["table"]) - unbits([gr["lk"]])[0]), mr["table_minus_lk"]
+                else:
+                    gt, mt = gr["table"], mr["table"]
+                if len(gt) != len(mt):
+                    bad.append(f"chunk {cid} read {r}: table has {len(gt)} entries, expected {len(mt)}")
+                elif max_abs(gt, mt) > table_tol:
+                    bad.append(f"chunk {cid} read {r}: table differs by {max_abs(gt, mt):.3g}")
         if "stage" in what:
             if g["consensus"] != m["consensus"]:
                 bad.append(f"chunk {cid}: polished consensus differs")
@@ -442,7 +446,7 @@ def device_dump(inputs, gains_features, gains_pileups):
         reads = [sub.read(r) for r in range(sub.n_reads)]
         ops = [sub.read_ops(r) for r in range(sub.n_reads)]
         tab, lk = api.modification_table(p, sub.template(0), reads, ops, sub.strand)
-        tables.append([dict(lk=bits(lk[r]), table=bits_vec(tab[r])) for r in range(sub.n_reads)])
+        tables.append([dict(lk=bits(lk[r]), table_minus_lk=bits_vec(tab[r])) for r in range(sub.n_reads)])
     res = api.cluster_chunks(p, b)
     f1, r1 = api.fit_model(p, b, rounds=1)
     out["pileups"] = dict(pileups=_pileup_results(inp, res, None, b, tables),
