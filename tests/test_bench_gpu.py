@@ -48,6 +48,9 @@ def test_one_rank_line_has_the_contract_fields(jtk_lib):
     assert line["serial_step_agrees"] and line["chunks_ok"] == 32
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["one_thread"]["cores"] == 1
+    # the core count is what the process may really use (affinity mask / cgroup quota), and the ladder is reported
+    assert cb["cores"] == cb["cpus"]["affinity"] or cb["cpus"]["cgroup_quota"] is not None
+    assert cb["threads_used"] in [r["threads"] for r in cb["scaling"]] and cb["scaling"][0]["threads"] == 1
     assert line["parity_on_cpu_sample"]["labels_equal"] and line["parity_on_cpu_sample"]["max_abs_dlogpost"] < 1e-4
     assert line["e2e"]["matches_resident"] and line["e2e"]["chunks_per_s"] > 0
 
@@ -65,6 +68,29 @@ def test_two_rank_strong_scaling_path(jtk_lib):
     assert line["gather_ok"] and line["gathered_reads"] == 24 * 60
     assert line["roofline"]["peak"] == 16000.0
     assert line["cpu_baseline"] is None
+
+
+def test_eight_rank_run_of_the_full_dataset_matches_the_one_rank_run(jtk_lib, tmp_path):
+    """north_star's 8-GPU layout on the ONE GPU of this box: bench.py --gpus 8 over gloo (every rank on device 0) on the full
+    2,500-chunk partition; the labels / k / scores every rank's shard contributes to the one all-gather must be those of the
+    1-rank run, chunk by chunk.  (The collective is gloo here: RCCL has never seen more than one rank of this code.)"""
+    import numpy as np
+    env = dict(os.environ, JTK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", JTK_LC_POOL_GB="16")
+    common = ["--steps", "1", "--warmup", "0", "--no-e2e", "--no-cpu-baseline", "--no-shard8"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-labels", str(tmp_path / "one.npz")]
+                         + common, capture_output=True, text=True, cwd=ROOT, env=env, timeout=1500)
+    assert one.returncode == 0, one.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "8", "--streams", "2", "--dump-labels", str(tmp_path / "eight.npz")] + common,
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = last_json(r.stdout)
+    assert line["n_gpus"] == 8 and line["config"]["chunks_total"] == 2500 and line["gather_ok"]
+    assert line["gathered_reads"] == 2500 * 60 and 300 <= line["config"]["chunks_this_rank"] <= 325
+    a, b = np.load(tmp_path / "one.npz"), np.load(tmp_path / "eight.npz")
+    assert np.array_equal(a["label"], b["label"]) and np.array_equal(a["cluster_num"], b["cluster_num"])
+    assert np.array_equal(a["score"].view(np.uint64), b["score"].view(np.uint64))
 
 
 def test_gpus_flag_must_match_the_launch():
