@@ -129,17 +129,17 @@ def pmc_traffic(workload, sha):
     """HBM bytes per launch per kernel family from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
     doubled per the gfx950 correction), but only when they were taken on THIS build of the library (same kernel sources and flags, or the same .so) and this workload;
     otherwise None: a stale profile says nothing about the kernels being timed."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     try:
         prof = json.load(open(path))
     except (OSError, ValueError):
-        return None, "no profiles/r02_pmc_traffic.json"
+        return None, "no profiles/r03_pmc_traffic.json"
     src = jbuild.source_sha16()
     if prof.get("src_sha16") != src and prof.get("lib_sha16") != sha:
-        return None, (f"profiles/r02_pmc_traffic.json was taken on kernel sources {prof.get('src_sha16')} "
+        return None, (f"profiles/r03_pmc_traffic.json was taken on kernel sources {prof.get('src_sha16')} "
                       f"(library {prof.get('lib_sha16')}), this is {src} ({sha})")
     if prof.get("workload") != workload:
-        return None, f"profiles/r02_pmc_traffic.json is for workload {prof.get('workload')}"
+        return None, f"profiles/r03_pmc_traffic.json is for workload {prof.get('workload')}"
     out = {}
     for fam, kernels in prof["kernel_family"].items():
         tot = 0.0

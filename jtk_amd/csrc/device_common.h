@@ -85,30 +85,35 @@ struct Edit {
     uint32_t row;
 };
 
-// The two ping-pong buffer sets (template codes, per-base ops and their lengths); ChunkState.buf selects
-// the current one.  Passed to kernels by value.
+// The three buffer sets (template codes, per-base ops and their lengths); ChunkState.buf selects the current one.  Set 0
+// holds the batch as uploaded and is never written: a pass starts from it without a device-to-device reset copy; the first
+// polish round that edits a chunk writes set 1, later rounds ping-pong between 1 and 2.  Passed to kernels by value.
 struct DevBufs {
-    uint8_t *tmpl[2];
-    uint8_t *ops[2];
-    uint32_t *ops_len[2];
+    uint8_t *tmpl[3];
+    uint8_t *ops[3];
+    uint32_t *ops_len[3];
 };
+#define JTK_NEXT_BUF(b) ((b) == 0u ? 1u : 3u - (b))
 
 // ---- kernel launchers (definitions in the .hip files) ----
 size_t phmm_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
 void launch_band_prep(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                       ChunkState *state, DevBufs bufs, uint64_t *delta, int only_active);
+// Work queues: `work_counter` is a device ticket counter that is never reset (no fill blit in front of a launch).  A wave
+// takes tickets until one is past the launch's last item, so a launch advances the counter by exactly n_items + n_waves;
+// `ticket_base` (host, owned by the session) is the counter's value when the launch starts and is advanced by the launcher.
 void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                  const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta,
                  const HmmDev *hmm2, double *scratch, uint64_t scratch_stride, uint32_t n_waves,
-                 uint32_t *work_counter, double *raw, int *rawG, double *lk, uint32_t max_tmpl,
+                 uint32_t *work_counter, uint32_t *ticket_base, double *raw, int *rawG, double *lk, uint32_t max_tmpl,
                  uint32_t max_read, int only_active, uint32_t skip_le_radius = 0);
 // phmm_pair.hip: the same sweep for band radius <= JTK_PAIR_MAX_RADIUS, two reads of a chunk per wave.  items[q] = index of
 // the first read of the pair, bit 31 set when the item is a single read; phmm_kernel is then told to skip those chunks.
 size_t phmm_pair_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
 void launch_phmm_pair(hipStream_t s, uint32_t n_items, const uint32_t *items, const ReadMeta *reads, const ChunkMeta *chunks,
                       const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
-                      double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *raw, int *rawG,
-                      double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active);
+                      double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
+                      double *raw, int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active);
 void launch_finalize(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                      const ChunkState *state, const HmmDev *hmm2, const double *raw, const int *rawG,
                      const double *lk, double *table, uint32_t max_tmpl, int only_active);
@@ -117,16 +122,19 @@ size_t phmm_wide_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
 uint64_t phmm_wide_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius);
 void launch_phmm_wide(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                       const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
-                      double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *raw,
-                      int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active);
+                      double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
+                      double *raw, int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active);
 // expected transition / emission counts of every read of a batch (E-step of the model refit); 45 doubles per read
 size_t phmm_counts_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
 uint64_t phmm_counts_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius);
 void launch_phmm_counts(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                         const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
-                        double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *counts,
-                        double *lk, uint32_t max_tmpl, uint32_t max_read);
+                        double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
+                        double *counts, double *lk, uint32_t max_tmpl, uint32_t max_read);
 // polish_kernels.hip
+#define JTK_NACTIVE_SLOTS (JTK_POLISH_MAX_ROUNDS + 3)  // one "chunks still active" counter per polish round of a pass
+void launch_reset_pass(hipStream_t s, uint32_t n_chunks, ChunkState *state, const ChunkState *state0, uint32_t *n_active,
+                       uint32_t n_counters);
 void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, const ReadMeta *reads,
                          const ChunkMeta *chunks, ChunkState *state, DevBufs bufs, const uint8_t *ey,
                          const double *table, double *total, Edit *edits, uint32_t *new_len, uint32_t max_tmpl,

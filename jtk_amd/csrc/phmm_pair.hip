@@ -66,7 +66,7 @@ __device__ __forceinline__ double pr_pow2(int e) {  // 2^e, lane-varying exponen
 __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, const uint32_t *items, const ReadMeta *reads,
                                                          const ChunkMeta *chunks, const ChunkState *state, DevBufs bufs,
                                                          const uint8_t *ey_all, const uint64_t *delta_all, const HmmDev *hmm2,
-                                                         double *scratch_all, uint64_t scratch_stride, uint32_t *work_counter,
+                                                         double *scratch_all, uint64_t scratch_stride, uint32_t *work_counter, uint32_t ticket_base,
                                                          double *raw_all, int *rawG_all, double *lk_all, uint32_t lds_tmpl,
                                                          uint32_t lds_read, int only_active) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, cons
 
     for (;;) {
         uint32_t q = 0;
-        if (lane == 0) q = atomicAdd(work_counter, 1u);
+        if (lane == 0) q = atomicAdd(work_counter, 1u) - ticket_base;  // tickets: the counter is never reset
         q = __builtin_amdgcn_readfirstlane(q);
         if (q >= n_items) break;
         const uint32_t it = items[q], first = it & 0x7fffffffu;
@@ -438,11 +438,12 @@ size_t phmm_pair_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
 
 void launch_phmm_pair(hipStream_t s, uint32_t n_items, const uint32_t *items, const ReadMeta *reads, const ChunkMeta *chunks,
                       const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
-                      double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *raw, int *rawG,
+                      double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base, double *raw, int *rawG,
                       double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active) {
     if (n_items == 0) return;
-    (void)hipMemsetAsync(work_counter, 0, sizeof(uint32_t), s);
+    const uint32_t base = *ticket_base;
+    *ticket_base = base + n_items + n_waves;
     const size_t lds = phmm_pair_lds_bytes(max_tmpl, max_read);
     phmm_pair_kernel<<<n_waves, 64, lds, s>>>(n_items, items, reads, chunks, state, bufs, ey, delta, hmm2, scratch, scratch_stride,
-                                              work_counter, raw, rawG, lk, max_tmpl, max_read, only_active);
+                                              work_counter, base, raw, rawG, lk, max_tmpl, max_read, only_active);
 }

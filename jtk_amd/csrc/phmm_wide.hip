@@ -33,7 +33,7 @@ __device__ __forceinline__ double wave_max_w(double v) {
 __global__ __launch_bounds__(64) void phmm_wide_kernel(uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                                                        const ChunkState *state, DevBufs bufs, const uint8_t *ey_all,
                                                        const uint64_t *delta_all, const HmmDev *hmm2, double *scratch_all,
-                                                       uint64_t scratch_stride, uint32_t *work_counter, double *raw_all,
+                                                       uint64_t scratch_stride, uint32_t *work_counter, uint32_t ticket_base, double *raw_all,
                                                        int *rawG_all, double *lk_all, uint32_t lds_tmpl, uint32_t lds_read,
                                                        int only_active) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void phmm_wide_kernel(uint32_t n_reads, const R
 
     for (;;) {
         uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(work_counter, 1u);
+        if (lane == 0) item = atomicAdd(work_counter, 1u) - ticket_base;  // tickets: the counter is never reset
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_reads) break;
         const ReadMeta rm = reads[item];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64) void phmm_wide_kernel(uint32_t n_reads, const R
 __global__ __launch_bounds__(64) void phmm_counts_kernel(uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                                                          const ChunkState *state, DevBufs bufs, const uint8_t *ey_all,
                                                          const uint64_t *delta_all, const HmmDev *hmm2, double *scratch_all,
-                                                         uint64_t scratch_stride, uint32_t *work_counter, double *counts_all,
+                                                         uint64_t scratch_stride, uint32_t *work_counter, uint32_t ticket_base, double *counts_all,
                                                          double *lk_all, uint32_t lds_tmpl, uint32_t lds_read) {
     extern __shared__ __align__(16) unsigned char smem[];
     double *ring = reinterpret_cast<double *>(smem);
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64) void phmm_counts_kernel(uint32_t n_reads, const
     const int lane = threadIdx.x;
     for (;;) {
         uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(work_counter, 1u);
+        if (lane == 0) item = atomicAdd(work_counter, 1u) - ticket_base;  // tickets: the counter is never reset
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_reads) break;
         const ReadMeta rm = reads[item];
@@ -571,13 +571,14 @@ uint64_t phmm_wide_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint32_
 
 void launch_phmm_wide(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                       const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
-                      double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *raw,
-                      int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active) {
+                      double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
+                      double *raw, int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active) {
     if (n_reads == 0 || n_waves == 0) return;
-    hipMemsetAsync(work_counter, 0, sizeof(uint32_t), s);
+    const uint32_t base = *ticket_base;
+    *ticket_base = base + n_reads + n_waves;
     const size_t lds = phmm_wide_lds_bytes(max_tmpl, max_read);
     phmm_wide_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch, scratch_stride,
-                                              work_counter, raw, rawG, lk, max_tmpl, max_read, only_active);
+                                              work_counter, base, raw, rawG, lk, max_tmpl, max_read, only_active);
 }
 
 size_t phmm_counts_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
@@ -591,11 +592,12 @@ uint64_t phmm_counts_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint3
 }
 void launch_phmm_counts(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                         const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
-                        double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *counts,
-                        double *lk, uint32_t max_tmpl, uint32_t max_read) {
+                        double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
+                        double *counts, double *lk, uint32_t max_tmpl, uint32_t max_read) {
     if (n_reads == 0 || n_waves == 0) return;
-    hipMemsetAsync(work_counter, 0, sizeof(uint32_t), s);
+    const uint32_t base = *ticket_base;
+    *ticket_base = base + n_reads + n_waves;
     const size_t lds = phmm_counts_lds_bytes(max_tmpl, max_read);
     phmm_counts_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch, scratch_stride,
-                                                work_counter, counts, lk, max_tmpl, max_read);
+                                                work_counter, base, counts, lk, max_tmpl, max_read);
 }

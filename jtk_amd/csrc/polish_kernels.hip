@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void select_edits_kernel(const ChunkMeta *chunk
     }
     // edited template into the other buffer
     const uint8_t *src = bufs.tmpl[st->buf] + cm.tmpl_off;
-    uint8_t *dst = bufs.tmpl[st->buf ^ 1] + cm.tmpl_off;
+    uint8_t *dst = bufs.tmpl[JTK_NEXT_BUF(st->buf)] + cm.tmpl_off;
     uint32_t w = 0, e = 0, p = 0;
     while (p < L) {
         if (e < ne && edits[e].pos == p) {
@@ -131,12 +131,12 @@ __global__ void rethread_kernel(uint32_t n_reads, const ReadMeta *reads, const C
     ChunkState *st = &state[rm.chunk];
     if (st->status != 0 || !st->active || st->n_edits == 0) return;
     const ChunkMeta cm = chunks[rm.chunk];
-    const uint32_t L = st->tmpl_len, ne = st->n_edits, b = st->buf;
+    const uint32_t L = st->tmpl_len, ne = st->n_edits, b = st->buf, nb = JTK_NEXT_BUF(b);
     const Edit *edits = edits_all + cm.edit_off;
     const uint8_t *ops = bufs.ops[b] + rm.ops_off;
-    uint8_t *out = bufs.ops[b ^ 1] + rm.ops_off;
+    uint8_t *out = bufs.ops[nb] + rm.ops_off;
     const uint32_t n_ops = bufs.ops_len[b][r];
-    const uint8_t *tmpl = bufs.tmpl[b ^ 1] + cm.tmpl_off;  // the edited template
+    const uint8_t *tmpl = bufs.tmpl[nb] + cm.tmpl_off;  // the edited template
     const uint8_t *ey = ey_all + rm.ey_off;                // read base j is ey[j+1] & 3
     uint32_t w = 0, e = 0, ti = 0;
     uint32_t ni = 0, nj = 0;  // positions in the NEW template / the read, for re-tagging
@@ -149,7 +149,7 @@ __global__ void rethread_kernel(uint32_t n_reads, const ReadMeta *reads, const C
         const uint64_t a = (uint64_t)(cm.tmpl_off + q);  // absolute byte offset: blocks are aligned in the buffer
         const uint32_t blk = (uint32_t)(a >> 3);
         if (blk != t8_at) {
-            t8 = *reinterpret_cast<const uint64_t *>(bufs.tmpl[b ^ 1] + ((uint64_t)blk << 3));
+            t8 = *reinterpret_cast<const uint64_t *>(bufs.tmpl[nb] + ((uint64_t)blk << 3));
             t8_at = blk;
         }
         return (uint8_t)(t8 >> (8 * (a & 7)));
@@ -211,7 +211,7 @@ __global__ void rethread_kernel(uint32_t n_reads, const ReadMeta *reads, const C
         pending_inserts();
     }
     if ((w & 7u) != 0 && !overflow) *reinterpret_cast<uint64_t *>(out + (w & ~7u)) = out8;  // inside the slot: cap % 8 == 0
-    bufs.ops_len[b ^ 1][r] = w;
+    bufs.ops_len[nb][r] = w;
     if (overflow) atomicMin(&st->status, (int)JTK_ERR_CHUNK_FAILED);
 }
 
@@ -224,7 +224,7 @@ __global__ void commit_kernel(uint32_t n_chunks, ChunkState *state, const uint32
     ChunkState *st = &state[ci];
     if (st->status != 0 || !st->active) return;
     if (st->n_edits > 0) {
-        st->buf ^= 1;
+        st->buf = JTK_NEXT_BUF(st->buf);
         st->tmpl_len = new_len[ci];
         st->n_edits = 0;
     }
@@ -232,14 +232,30 @@ __global__ void commit_kernel(uint32_t n_chunks, ChunkState *state, const uint32
     (void)max_rounds;
 }
 
+// A pass starts from the batch as uploaded: every chunk's state from its pristine copy (buffer set 0, round 0, active) and
+// the per-round "chunks still active" counters at zero.  One small kernel instead of the copy / fill blits a host-side
+// reset costs (they queue behind the resident waves of other streams).
+__global__ void reset_pass_kernel(uint32_t n_chunks, ChunkState *state, const ChunkState *state0, uint32_t *n_active,
+                                  uint32_t n_counters) {
+    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci < n_counters) n_active[ci] = 0;
+    if (ci < n_chunks) state[ci] = state0[ci];
+}
+
 }  // namespace
+
+void launch_reset_pass(hipStream_t s, uint32_t n_chunks, ChunkState *state, const ChunkState *state0, uint32_t *n_active,
+                       uint32_t n_counters) {
+    const uint32_t n = n_chunks > n_counters ? n_chunks : n_counters;
+    reset_pass_kernel<<<(n + 127) / 128, 128, 0, s>>>(n_chunks, state, state0, n_active, n_counters);
+}
 
 void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, const ReadMeta *reads,
                          const ChunkMeta *chunks, ChunkState *state, DevBufs bufs, const uint8_t *ey,
                          const double *table, double *total, Edit *edits, uint32_t *new_len, uint32_t max_tmpl,
                          uint32_t ignore_edge, int final_pass, uint32_t *n_active_out) {
     if (n_chunks == 0) return;
-    hipMemsetAsync(n_active_out, 0, sizeof(uint32_t), s);
+    // n_active_out is this round's own counter, zeroed by reset_pass_kernel when the pass began (no fill blit here)
     if (!final_pass) {
         const uint32_t cols = JTK_NUM_ROW * (max_tmpl + 1);
         dim3 grid((cols + 255) / 256, n_chunks);

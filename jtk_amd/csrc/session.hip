@@ -206,6 +206,12 @@ struct jtk_lc_session {
     uint32_t n_wide_reads = 0, max_wide_radius = 0, n_wide_waves = 0;
     uint64_t wide_stride = 0;
     DevPtr d_wide_scratch, d_wide_counter;
+    DevPtr d_state0;                     // pristine per-chunk state: a pass begins with a device-side copy of it
+    // host mirrors of the never-reset device ticket counters of the work queues (device_common.h): d_counter[0] phmm_kernel,
+    // d_counter[1] phmm_pair_kernel, d_wide_counter[0] phmm_wide_kernel
+    uint32_t tk_phmm = 0, tk_pair = 0, tk_wide = 0;
+    uint32_t *h_nactive = nullptr;       // pinned: the per-round "chunks still active" counters as the host reads them back
+    hipEvent_t ev_round[2] = {nullptr, nullptr};
     ~jtk_lc_session() {
         if (stream) (void)hipStreamSynchronize(stream);  // blocks go back to the pool, not through hipFree's implicit sync
         for (auto &t : timers) {
@@ -213,6 +219,9 @@ struct jtk_lc_session {
             if (t.b) (void)hipEventDestroy(t.b);
         }
         if (stream) (void)hipStreamDestroy(stream);
+        if (h_nactive) (void)hipHostFree(h_nactive);
+        for (auto &e : ev_round)
+            if (e) (void)hipEventDestroy(e);
     }
 };
 
@@ -543,7 +552,8 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
     if ((rc = dev_alloc<Edit>(s->d_edits, edit_off))) return rc;
     if ((rc = dev_alloc<uint32_t>(s->d_newlen, n_chunks))) return rc;
     if ((rc = dev_alloc<uint32_t>(s->d_counter, 4))) return rc;
-    if ((rc = dev_alloc<uint32_t>(s->d_nactive, 4))) return rc;
+    HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 4 * sizeof(uint32_t), s->stream));  // once: the ticket counters are never reset
+    if ((rc = dev_alloc<uint32_t>(s->d_nactive, JTK_NACTIVE_SLOTS))) return rc;
     if ((rc = dev_alloc<uint16_t>(s->d_homop, tmpl_off))) return rc;
     if ((rc = dev_upload(s, s->d_homop_off, h_homop_off))) return rc;
     if ((rc = dev_alloc<double>(s->d_aux, aux_off))) return rc;
@@ -621,13 +631,19 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         s->n_wide_waves = (uint32_t)std::min<uint64_t>(s->n_wide_reads, want);
         if ((rc = dev_alloc<double>(s->d_wide_scratch, s->wide_stride * s->n_wide_waves))) return rc;
         if ((rc = dev_alloc<uint32_t>(s->d_wide_counter, 4))) return rc;
+        HIP_TRY(hipMemsetAsync(s->d_wide_counter.p, 0, 4 * sizeof(uint32_t), s->stream));
     }
-    s->bufs.tmpl[0] = s->d_tmpl0.as<uint8_t>();
-    s->bufs.tmpl[1] = s->d_tmpl1.as<uint8_t>();
-    s->bufs.ops[0] = s->d_ops0.as<uint8_t>();
-    s->bufs.ops[1] = s->d_ops1.as<uint8_t>();
-    s->bufs.ops_len[0] = s->d_opslen0.as<uint32_t>();
-    s->bufs.ops_len[1] = s->d_opslen1.as<uint32_t>();
+    // set 0 = the batch as uploaded (never written), sets 1 / 2 = what the polish rounds write (device_common.h DevBufs)
+    s->bufs.tmpl[0] = s->d_tmpl_init.as<uint8_t>();
+    s->bufs.tmpl[1] = s->d_tmpl0.as<uint8_t>();
+    s->bufs.tmpl[2] = s->d_tmpl1.as<uint8_t>();
+    s->bufs.ops[0] = s->d_ops_init.as<uint8_t>();
+    s->bufs.ops[1] = s->d_ops0.as<uint8_t>();
+    s->bufs.ops[2] = s->d_ops1.as<uint8_t>();
+    s->bufs.ops_len[0] = s->d_opslen_init.as<uint32_t>();
+    s->bufs.ops_len[1] = s->d_opslen0.as<uint32_t>();
+    s->bufs.ops_len[2] = s->d_opslen1.as<uint32_t>();
+    if ((rc = dev_upload(s, s->d_state0, s->h_state0))) return rc;
     tstop(s);
     HIP_TRY(hipStreamSynchronize(s->stream));
     {
@@ -672,34 +688,39 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
     HIP_TRY(hipEventRecord(ev0, st));
-    // reset the mutable state from the pristine copies (device-to-device; inputs stay resident)
-    HIP_TRY(hipMemcpyAsync(state, s->h_state0.data(), s->h_state0.size() * sizeof(ChunkState), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_tmpl0.p, s->d_tmpl_init.p, s->tmpl_bytes, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_ops0.p, s->d_ops_init.p, s->ops_bytes, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_opslen0.p, s->d_opslen_init.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToDevice, st));
+    // reset the mutable state: every chunk back to the batch as uploaded (buffer set 0 is never written, so there is
+    // nothing to copy) and the per-round counters to zero -- one small kernel, no blits
+    launch_reset_pass(st, s->n_chunks, state, s->d_state0.as<ChunkState>(), s->d_nactive.as<uint32_t>(), JTK_NACTIVE_SLOTS);
 
     tstart(s, JTK_K_POLISH);
     launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 0);
     tstop(s);
-    uint32_t n_active = s->n_chunks;
+    // The host has to learn when every chunk has converged, but the device never waits for it: round r+1 is queued BEFORE the
+    // host looks at round r's counter (a round without active chunks does nothing: every kernel of a round >= 1 skips the
+    // chunks that are not active), so a pass costs at most one empty round instead of a host round trip per round.
+    if (!s->h_nactive) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_nactive), JTK_NACTIVE_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_round[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_round[1], hipEventDisableTiming));
+    }
     const int max_rounds = skip_polish ? 1 : JTK_POLISH_MAX_ROUNDS + 1;
-    for (int round = 0; round < max_rounds && n_active > 0; round++) {
+    for (int round = 0; round < max_rounds; round++) {
         const int only_active = round > 0;
         const int final_pass = skip_polish || round == JTK_POLISH_MAX_ROUNDS;
         tstart(s, JTK_K_PHMM);
         launch_phmm(st, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(),
-                    hmm2, s->d_scratch.as<double>(), s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(),
+                    hmm2, s->d_scratch.as<double>(), s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(), &s->tk_phmm,
                     s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read,
                     only_active, s->n_pair_items ? JTK_PAIR_MAX_RADIUS : 0);
         if (s->n_pair_items)
             launch_phmm_pair(st, s->n_pair_items, s->d_pair_items.as<uint32_t>(), reads, chunks, state, s->bufs,
                              s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), hmm2, s->d_scratch.as<double>(), s->scratch_stride,
-                             s->n_pair_waves, s->d_counter.as<uint32_t>(), s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                             s->n_pair_waves, s->d_counter.as<uint32_t>() + 1, &s->tk_pair, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                              s->d_lk.as<double>(), s->max_tmpl, s->max_read, only_active);
         if (s->n_wide_reads)
             launch_phmm_wide(st, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(),
                              hmm2, s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves,
-                             s->d_wide_counter.as<uint32_t>(), s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                             s->d_wide_counter.as<uint32_t>(), &s->tk_wide, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                              s->d_lk.as<double>(), s->max_tmpl, s->max_read, only_active);
         launch_finalize(st, s->n_reads, reads, chunks, state, hmm2, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                         s->d_lk.as<double>(), s->d_table.as<double>(), s->max_tmpl, only_active);
@@ -708,13 +729,17 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
         launch_polish_round(st, s->n_chunks, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(),
                             s->d_table.as<double>(), s->d_total.as<double>(), s->d_edits.as<Edit>(),
                             s->d_newlen.as<uint32_t>(), s->max_tmpl, s->ignore_edge, final_pass,
-                            s->d_nactive.as<uint32_t>());
+                            s->d_nactive.as<uint32_t>() + round);
         if (!final_pass)
             launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 1);
         tstop(s);
         if (final_pass) break;
-        HIP_TRY(hipMemcpyAsync(&n_active, s->d_nactive.p, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyAsync(s->h_nactive + round, s->d_nactive.as<uint32_t>() + round, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(s->ev_round[round & 1], st));
+        if (round >= 1) {
+            HIP_TRY(hipEventSynchronize(s->ev_round[(round - 1) & 1]));
+            if (s->h_nactive[round - 1] == 0) break;  // round `round` was already queued and finds nothing to do
+        }
     }
     if (!s->polish_only) {
     tstart(s, JTK_K_FILTER);
@@ -781,24 +806,21 @@ int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post,
     if (label) HIP_TRY(hipMemcpyAsync(label, s->d_label.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToHost, st));
     if (log_post)
         HIP_TRY(hipMemcpyAsync(log_post, s->d_post.p, (size_t)s->n_reads * s->post_stride * 8, hipMemcpyDeviceToHost, st));
-    std::vector<uint8_t> t0, t1, o0, o1;
-    std::vector<uint32_t> l0, l1;
+    // the three buffer sets (DevBufs): a chunk's result lives in the set its state names (0 = never edited)
+    std::vector<uint8_t> tb[3], ob[3];
+    std::vector<uint32_t> lb[3];
     const bool want_cons = cons_out && cons_off, want_ops = ops_out && ops_out_off;
-    if (want_cons) {
-        t0.resize(s->tmpl_bytes);
-        t1.resize(s->tmpl_bytes);
-        HIP_TRY(hipMemcpyAsync(t0.data(), s->d_tmpl0.p, s->tmpl_bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(t1.data(), s->d_tmpl1.p, s->tmpl_bytes, hipMemcpyDeviceToHost, st));
-    }
-    if (want_ops) {
-        o0.resize(s->ops_bytes);
-        o1.resize(s->ops_bytes);
-        l0.resize(s->n_reads);
-        l1.resize(s->n_reads);
-        HIP_TRY(hipMemcpyAsync(o0.data(), s->d_ops0.p, s->ops_bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(o1.data(), s->d_ops1.p, s->ops_bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(l0.data(), s->d_opslen0.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(l1.data(), s->d_opslen1.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToHost, st));
+    for (int b = 0; b < 3; b++) {
+        if (want_cons) {
+            tb[b].resize(s->tmpl_bytes);
+            HIP_TRY(hipMemcpyAsync(tb[b].data(), s->bufs.tmpl[b], s->tmpl_bytes, hipMemcpyDeviceToHost, st));
+        }
+        if (want_ops) {
+            ob[b].resize(s->ops_bytes);
+            lb[b].resize(s->n_reads);
+            HIP_TRY(hipMemcpyAsync(ob[b].data(), s->bufs.ops[b], s->ops_bytes, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(lb[b].data(), s->bufs.ops_len[b], (size_t)s->n_reads * 4, hipMemcpyDeviceToHost, st));
+        }
     }
     HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -825,7 +847,7 @@ int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post,
             cons_off[c] = co;
             if (cs.status == 0) {
                 if (co + cs.tmpl_len > cons_cap) return fail(JTK_ERR_INVALID_ARG, "cons_cap too small");
-                const uint8_t *src = (cs.buf ? t1.data() : t0.data()) + cm.tmpl_off;
+                const uint8_t *src = tb[cs.buf % 3].data() + cm.tmpl_off;
                 for (uint32_t p = 0; p < cs.tmpl_len; p++) cons_out[co + p] = (uint8_t)BASES[src[p] & 3];
                 co += cs.tmpl_len;
             }
@@ -835,9 +857,9 @@ int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post,
                 const uint32_t g = cm.read_first + r;
                 ops_out_off[g] = oo;
                 if (cs.status == 0) {
-                    const uint32_t len = cs.buf ? l1[g] : l0[g];
+                    const uint32_t len = lb[cs.buf % 3][g];
                     if (oo + len > ops_cap) return fail(JTK_ERR_INVALID_ARG, "ops_cap too small");
-                    memcpy(ops_out + oo, (cs.buf ? o1.data() : o0.data()) + s->h_reads[g].ops_off, len);
+                    memcpy(ops_out + oo, ob[cs.buf % 3].data() + s->h_reads[g].ops_off, len);
                     oo += len;
                 }
                 ops_out_off[g + 1] = oo;
@@ -1469,6 +1491,8 @@ int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_l
             if ((rc = dev_alloc<double>(d_counts, (size_t)n_reads * FIT_COUNTS))) return rc;
             if ((rc = dev_alloc<double>(d_lk, n_reads))) return rc;
             if ((rc = dev_alloc<uint32_t>(d_counter, 4))) return rc;
+            HIP_TRY(hipMemsetAsync(d_counter.p, 0, 4 * sizeof(uint32_t), s->stream));  // a fresh ticket counter (once per round)
+            uint32_t tk_counts = 0;
             const size_t lds = phmm_counts_lds_bytes(s->max_tmpl, s->max_read);
             if (lds > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "template + read too long for the LDS staging of phmm_counts_kernel");
             hipDeviceProp_t prop;
@@ -1480,7 +1504,8 @@ int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_l
             launch_phmm_counts(s->stream, s->n_reads, s->d_reads.as<ReadMeta>(), d_wide.as<ChunkMeta>(),
                                s->d_state.as<ChunkState>(), s->bufs, s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(),
                                s->d_hmm2.as<HmmDev>(), d_scratch.as<double>(), stride, (uint32_t)waves,
-                               d_counter.as<uint32_t>(), d_counts.as<double>(), d_lk.as<double>(), s->max_tmpl, s->max_read);
+                               d_counter.as<uint32_t>(), &tk_counts, d_counts.as<double>(), d_lk.as<double>(), s->max_tmpl,
+                               s->max_read);
             HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * 8, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipMemcpyAsync(lks.data(), d_lk.p, lks.size() * 8, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1527,20 +1552,17 @@ int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl
     std::unique_ptr<jtk_lc_session> guard(s);
     hipStream_t st = s->stream;
     ChunkState *state = s->d_state.as<ChunkState>();
-    HIP_TRY(hipMemcpyAsync(state, s->h_state0.data(), sizeof(ChunkState), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_tmpl0.p, s->d_tmpl_init.p, s->tmpl_bytes, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_ops0.p, s->d_ops_init.p, s->ops_bytes, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_opslen0.p, s->d_opslen_init.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToDevice, st));
+    launch_reset_pass(st, s->n_chunks, state, s->d_state0.as<ChunkState>(), s->d_nactive.as<uint32_t>(), JTK_NACTIVE_SLOTS);
     launch_band_prep(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
                      s->d_delta.as<uint64_t>(), 0);
     launch_phmm(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
                 s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(), s->d_scratch.as<double>(),
-                s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(), s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(), &s->tk_phmm, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                 s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
     if (s->n_wide_reads)
         launch_phmm_wide(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
                          s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(),
-                         s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves, s->d_wide_counter.as<uint32_t>(),
+                         s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves, s->d_wide_counter.as<uint32_t>(), &s->tk_wide,
                          s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
     launch_finalize(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state,
                     s->d_hmm2.as<HmmDev>(), s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(),
@@ -1580,20 +1602,17 @@ int jtk_internal_likelihoods(const jtk_lc_params_t *params, size_t n_chunks, con
     std::unique_ptr<jtk_lc_session> guard(s);
     hipStream_t st = s->stream;
     ChunkState *state = s->d_state.as<ChunkState>();
-    HIP_TRY(hipMemcpyAsync(state, s->h_state0.data(), s->h_state0.size() * sizeof(ChunkState), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_tmpl0.p, s->d_tmpl_init.p, s->tmpl_bytes, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_ops0.p, s->d_ops_init.p, s->ops_bytes, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_opslen0.p, s->d_opslen_init.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToDevice, st));
+    launch_reset_pass(st, s->n_chunks, state, s->d_state0.as<ChunkState>(), s->d_nactive.as<uint32_t>(), JTK_NACTIVE_SLOTS);
     launch_band_prep(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
                      s->d_delta.as<uint64_t>(), 0);
     launch_phmm(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
                 s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(), s->d_scratch.as<double>(),
-                s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(), s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(), &s->tk_phmm, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                 s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
     if (s->n_wide_reads)
         launch_phmm_wide(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
                          s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(),
-                         s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves, s->d_wide_counter.as<uint32_t>(),
+                         s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves, s->d_wide_counter.as<uint32_t>(), &s->tk_wide,
                          s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
     std::vector<ChunkState> cs(n_chunks);
     HIP_TRY(hipMemcpyAsync(cs.data(), state, cs.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, st));

@@ -5,7 +5,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
-TAG=${1:-r02}
+TAG=${1:-r03}
 shift || true
 ARGS="${@:---steps 2 --warmup 1 --no-cpu-baseline --no-e2e}"
 mkdir -p $OUT
