@@ -125,6 +125,62 @@ def cpu_baseline(params, batch, budget_s=100.0):
                 one_thread=dict(value=one, unit="chunks/s", cores=1) if one else None), keep[0], keep[1]
 
 
+def stage_e2e(params0, batch, cfg, device, record_path=None):
+    """ONE call of the stage as the pipeline enters it (local_clustering/mod.rs:56-83), from host buffers, with its preambles:
+    update_models_on_both_strands (model_tune.rs:96-156: the 5 training pile-ups, TRAIN_ROUND = 10, both strands) ->
+    estimate_gain_default (likelihood_gains.rs:186-192) -> the batched clustering_on_pileup loop -> normalize_local_clustering
+    (normalize.rs:6-51).  The same calls the C++ host mirror (jtk_amd/csrc/host/local_clustering.hpp) and dataset.py make."""
+    ph = {}
+    t0 = time.perf_counter()
+    n = batch.chunks["n_reads"].astype(np.int64)
+    cov = int(np.sort(n)[len(n) // 2])                                           # select_nth_unstable(len / 2)
+    by_id = np.argsort(batch.chunks["chunk_id"], kind="stable")
+    train = [int(c) for c in by_id if max(cov, 2) - 2 <= n[c] < cov + 2][:5]     # TRAIN_UNIT_SIZE
+    f, r = api.fit_model(params0, batch.subset(train), rounds=10, device=device)
+    ph["fit_model_ms"] = (time.perf_counter() - t0) * 1e3
+    t1 = time.perf_counter()
+    p = ffi.Params.from_buffer_copy(bytes(params0))
+    p.forward, p.reverse = f, r
+    p.gains = api.estimate_gains(f, r, device=device)
+    ph["estimate_gains_ms"] = (time.perf_counter() - t1) * 1e3
+    t2 = time.perf_counter()
+    out = api.cluster_chunks(p, batch, device=device)
+    tm = api.last_timing()
+    ph["cluster_chunks_ms"] = (time.perf_counter() - t2) * 1e3
+    t3 = time.perf_counter()
+    for c in range(batch.n_chunks):
+        rr = batch.chunk_reads(c)
+        k = int(out["result"]["cluster_num"][c])
+        lab, post = api.normalize_pileup(out["label"][rr.start:rr.stop], out["log_post"][rr.start:rr.stop, :k], k)
+        out["label"][rr.start:rr.stop] = lab
+        out["log_post"][rr.start:rr.stop, :k] = post
+    ph["normalize_ms"] = (time.perf_counter() - t3) * 1e3
+    ph["total_ms"] = (time.perf_counter() - t0) * 1e3
+    # RECORD rows (mod.rs:121: chunk id, elapsed ms, polish ms, consensus length, score, coverage): the device runs chunks in
+    # batches, so a chunk's time is its share of the batch's kernel time per family -- pair-HMM and polish by band cells x
+    # passes, the chain by proposals
+    res = out["result"]
+    passes = np.minimum(res["polish_rounds"].astype(np.float64) + 1.0, 21.0)
+    diag = np.array([int(batch.chunks[c]["n_reads"]) * int(batch.chunks[c]["tmpl_len"])
+                     + int(batch.read_off[batch.chunk_reads(c).stop] - batch.read_off[batch.chunk_reads(c).start])
+                     for c in range(batch.n_chunks)], dtype=np.float64)
+    w_dp = passes * diag
+    k_tried = np.maximum(1, np.minimum(int(cfg["copy_num"]), 1 + 2 * res["n_variants"].astype(np.int64)) - 1)
+    w_mc = n * k_tried * (res["n_variants"] > 0)
+    km = tm["kernel_ms"]
+    polish_ms = (km["phmm"] + km["polish"]) * w_dp / max(w_dp.sum(), 1.0)
+    elapsed = polish_ms + km["filter"] / batch.n_chunks + km["mcmc"] * w_mc / max(float(w_mc.sum()), 1.0)
+    clen = np.diff(out["cons_off"]).astype(np.int64)
+    rows = [f"RECORD\t{int(batch.chunks[c]['chunk_id'])}\t{elapsed[c]:.3f}\t{polish_ms[c]:.3f}\t{int(clen[c])}\t"
+            f"{float(res['score'][c]):.3f}\t{int(n[c])}" for c in range(batch.n_chunks)]
+    if record_path:
+        with open(record_path, "w") as fh:
+            fh.write("\n".join(rows) + "\n")
+    ph["record_rows"] = rows[:3]
+    ph["record_file"] = record_path
+    return ph, out
+
+
 def pmc_traffic(workload, sha):
     """HBM bytes per launch per kernel family from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
     doubled per the gfx950 correction), but only when they were taken on THIS build of the library (same kernel sources and flags, or the same .so) and this workload;
@@ -462,6 +518,18 @@ def main():
                            h2d_ms=tm["h2d_ms"], d2h_ms=tm["d2h_ms"], pool_gb=float(os.environ["JTK_LC_POOL_GB"]), matches_resident=bool(np.array_equal(one["label"], out["label"])),
                            note="jtk_lc_cluster_chunks on this rank's shard from host buffers to host buffers; the first call "
                                 "also maps the device workspaces, the second reuses the pooled blocks")
+        # ---- the whole stage call with its preambles (refit + gains calibration + clustering + normalisation), cold and warm
+        api.trim_cache(local_rank)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        cold_ph, _ = stage_e2e(params, batch, cfg, local_rank)
+        warm_ph, st_out = stage_e2e(params, batch, cfg, local_rank, os.path.join(ROOT, "gpurun_out", "record_r03.tsv"))
+        line["stage_e2e"] = dict(
+            cold=cold_ph, warm=warm_ph, chunks_per_s_warm=batch.n_chunks / (warm_ph["total_ms"] / 1e3),
+            chunks_ok=int((st_out["result"]["status"] == 0).sum()),
+            note="one LocalClustering::local_clustering_selected call on this rank's shard from host buffers: model refit (10 rounds "
+                 "x 5 pile-ups x 2 strands) + gains calibration + jtk_lc_cluster_chunks + normalisation; cold = first call "
+                 "(maps the device workspaces), warm = the next one.  The refitted model differs from the resident runs' default "
+                 "model, so labels are not compared with them here")
     api.trim_cache(local_rank)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -21,6 +21,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "device_common.h"
@@ -525,10 +526,9 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
                 const uint32_t c = node_chunk[node_off[r] + idx];
                 if (c != 0xffffffffu) by_chunk[c].emplace_back(r, idx);
             }
+        const std::unordered_set<uint64_t> sel_set(selection, selection + n_selected);  // a genome-scale DataSet has ~1e6 chunks
         for (size_t c = 0; c < n_chunks; c++) {
-            bool sel = false;
-            for (size_t q = 0; q < n_selected; q++) sel = sel || selection[q] == chunks[c].id;
-            if (!(1 < chunks[c].cluster_num && sel)) continue;
+            if (!(1 < chunks[c].cluster_num && sel_set.count(chunks[c].id))) continue;
             Job j;
             j.chunk = c;
             j.mem = by_chunk[c];
@@ -538,13 +538,65 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
             jobs.push_back(std::move(j));
         }
     }
-    std::vector<ArmEnt> arms;
+    // neighbours on chunks outside `chunks` get dense ids behind the real ones (zero-length copy-number entries); the ids are
+    // fixed before the first batch so that the copy-number tables are uploaded once
     std::unordered_map<uint64_t, uint32_t> stray;
+    for (const Job &j : jobs)
+        for (const auto &m : j.mem) {
+            const size_t r = m.first, len = (size_t)(node_off[r + 1] - node_off[r]);
+            for (size_t q = 0; q < len; q++)
+                if (q != m.second && node_chunk[node_off[r] + q] == 0xffffffffu) {
+                    const uint64_t id = nodes[node_off[r] + q].chunk;
+                    if (!stray.count(id)) stray.emplace(id, (uint32_t)(n_chunks + stray.size()));
+                }
+        }
+    const uint32_t max_dense = (uint32_t)(n_chunks + stray.size());
+    std::vector<uint64_t> d_cn_off(max_dense, 0);
+    std::vector<uint32_t> d_cn_len(max_dense, 0);
+    for (size_t c = 0; c < n_chunks; c++) {
+        d_cn_off[c] = cn_off[c];
+        d_cn_len[c] = cn_len[c];
+    }
+    hipStream_t st = nullptr;
+    std::unique_ptr<void, void (*)(void *)> st_guard(nullptr, [](void *s) { if (s) (void)hipStreamDestroy((hipStream_t)s); });
+    DevBuf d_post, d_cn, d_cnoff, d_cnlen, d_panic;
+    if (!jobs.empty()) {
+        CC_HIP(hipStreamCreate(&st));
+        st_guard.reset(st);
+        size_t n_post = 0;
+        for (size_t e = 0; e < n_nodes; e++) n_post = std::max<size_t>(n_post, nodes[e].post_off + nodes[e].post_len);
+        std::vector<double> post_v(posteriors, posteriors + n_post);
+        int rc;
+        if ((rc = d_post.upload(post_v, st)) || (rc = d_cn.upload(cn, st)) || (rc = d_cnoff.upload(d_cn_off, st)) ||
+            (rc = d_cnlen.upload(d_cn_len, st)))
+            return cc_fail(rc, "device upload failed");
+        CC_HIP(hipMalloc(&d_panic.p, sizeof(int)));
+        CC_HIP(hipMemsetAsync(d_panic.p, 0, sizeof(int), st));
+        CC_HIP(hipStreamSynchronize(st));  // post_v goes out of scope
+    }
+    g_first_sims.clear();
+    // The reference corrects one chunk at a time under rayon (phmm_likelihood_correction.rs:37-43).  Here the jobs go through the
+    // device in BATCHES bounded by the bytes of their similarity matrices (sum of n^2 doubles), so host and device memory stay
+    // bounded on a genome-scale DataSet; a batch is: similarity fill on the device, then the spectral step on host threads.
+    uint64_t sims_budget = 64ull << 20;  // doubles: 512 MB per batch
+    if (const char *e = getenv("JTK_CC_SIMS_BUDGET")) {  // tests force several batches on a small problem
+        const long long v = atoll(e);
+        if (v > 0) sims_budget = (uint64_t)v;
+    }
+    for (size_t j0 = 0, j1 = 0; j0 < jobs.size(); j0 = j1) {
+    uint64_t batch_sims = 0;
+    for (j1 = j0; j1 < jobs.size(); j1++) {
+        const uint64_t nn = (uint64_t)jobs[j1].mem.size() * jobs[j1].mem.size();
+        if (j1 > j0 && batch_sims + nn > sims_budget) break;
+        batch_sims += nn;
+    }
+    std::vector<ArmEnt> arms;
     std::vector<Member> members;
     std::vector<PairJob> pjobs;
     uint64_t n_pairs = 0, sims_total = 0;
     uint32_t max_arm = 0;
-    for (const Job &j : jobs) {
+    for (size_t jq = j0; jq < j1; jq++) {
+        const Job &j = jobs[jq];
         PairJob pj;
         pj.first_pair = n_pairs;
         pj.sims_off = sims_total;
@@ -564,9 +616,7 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
                 if (c == 0xffffffffu) {
                     // a neighbour on a chunk outside `chunks`: only ever compared with the same chunk id, whose copy numbers the
                     // reference reads from a zero-length vector -> sim() asserts the lengths: the kernel sees cn_len 0 too
-                    auto it = stray.find(rn[q].chunk);
-                    if (it == stray.end()) it = stray.emplace(rn[q].chunk, (uint32_t)(n_chunks + stray.size())).first;
-                    c = it->second;
+                    c = stray.at(rn[q].chunk);
                 }
                 e.chunk = c;
                 e.post_len = rn[q].post_len;
@@ -592,31 +642,14 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
             max_arm = std::max(max_arm, std::max(mb.n_up, mb.n_down));
         }
     }
-    const uint32_t max_dense = (uint32_t)(n_chunks + stray.size());  // stray ids: zero-length copy-number entries
-    std::vector<uint64_t> d_cn_off(max_dense, 0);
-    std::vector<uint32_t> d_cn_len(max_dense, 0);
-    for (size_t c = 0; c < n_chunks; c++) {
-        d_cn_off[c] = cn_off[c];
-        d_cn_len[c] = cn_len[c];
-    }
     // ---- the similarity fill on the device
     std::vector<double> sims(sims_total);
     if (n_pairs) {
-        hipStream_t st;
-        CC_HIP(hipStreamCreate(&st));
-        std::unique_ptr<void, void (*)(void *)> st_guard(st, [](void *s) { (void)hipStreamDestroy((hipStream_t)s); });
-        size_t n_post = 0;
-        for (size_t e = 0; e < n_nodes; e++) n_post = std::max<size_t>(n_post, nodes[e].post_off + nodes[e].post_len);
-        std::vector<double> post_v(posteriors, posteriors + n_post);
-        DevBuf d_jobs, d_members, d_arms, d_post, d_cn, d_cnoff, d_cnlen, d_sims, d_scratch, d_panic;
+        DevBuf d_jobs, d_members, d_arms, d_sims, d_scratch;
         int rc;
-        if ((rc = d_jobs.upload(pjobs, st)) || (rc = d_members.upload(members, st)) || (rc = d_arms.upload(arms, st)) ||
-            (rc = d_post.upload(post_v, st)) || (rc = d_cn.upload(cn, st)) || (rc = d_cnoff.upload(d_cn_off, st)) ||
-            (rc = d_cnlen.upload(d_cn_len, st)))
+        if ((rc = d_jobs.upload(pjobs, st)) || (rc = d_members.upload(members, st)) || (rc = d_arms.upload(arms, st)))
             return cc_fail(rc, "device upload failed");
         CC_HIP(hipMalloc(&d_sims.p, std::max<size_t>(sims_total, 1) * sizeof(double)));
-        CC_HIP(hipMalloc(&d_panic.p, sizeof(int)));
-        CC_HIP(hipMemsetAsync(d_panic.p, 0, sizeof(int), st));
         const uint32_t row_doubles = 2 * 3 * (max_arm + 1);
         uint64_t threads = std::min<uint64_t>(n_pairs, 256ull * 1024);
         threads = (threads + 255) / 256 * 256;
@@ -632,14 +665,13 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
         CC_HIP(hipGetLastError());
         if (dev_panic) return cc_fail(JTK_ERR_CHUNK_FAILED, "sim(): posterior lengths differ from cluster_num, or a log-probability above 0");
     }
-    g_first_sims.clear();
-    if (g_keep_sims && !pjobs.empty()) g_first_sims.assign(sims.begin(), sims.begin() + (size_t)pjobs[0].n * pjobs[0].n);
+    if (g_keep_sims && j0 == 0 && !pjobs.empty()) g_first_sims.assign(sims.begin(), sims.begin() + (size_t)pjobs[0].n * pjobs[0].n);
     // ---- spectral clustering of every chunk (clustering :290-337), one chunk per host thread
     auto cluster_one = [&](size_t ji) {
         Job &j = jobs[ji];
         const jtk_cc_chunk_t &chunk = chunks[j.chunk];
         const size_t n = j.mem.size();
-        double *S = &sims[pjobs[ji].sims_off];
+        double *S = &sims[pjobs[ji - j0].sims_off];
         if (chunk.copy_num == 0 || n == 0) {
             j.panic = true;
             return;
@@ -740,17 +772,18 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
         j.ari = adj != adj ? 1.0 : adj;
     };
     {
-        std::atomic<size_t> next(0);
+        std::atomic<size_t> next(j0);
         auto work = [&]() {
-            for (size_t ji = next.fetch_add(1); ji < jobs.size(); ji = next.fetch_add(1)) cluster_one(ji);
+            for (size_t ji = next.fetch_add(1); ji < j1; ji = next.fetch_add(1)) cluster_one(ji);
         };
         const unsigned hw = std::thread::hardware_concurrency();
-        const size_t nt = std::min<size_t>(std::max<size_t>(jobs.size(), 1), std::min<size_t>(hw ? hw : 1, 32));
+        const size_t nt = std::min<size_t>(std::max<size_t>(j1 - j0, 1), std::min<size_t>(hw ? hw : 1, 32));
         std::vector<std::thread> threads;
         for (size_t t = 1; t < nt; t++) threads.emplace_back(work);
         work();
         for (auto &t : threads) t.join();
     }
+    }  // batches
     for (const Job &j : jobs)
         if (j.panic) return cc_fail(JTK_ERR_CHUNK_FAILED, "chunk " + std::to_string(chunks[j.chunk].id) + ": the reference panics on this pile-up");
     // ---- get_protected_clusterings :108-127, supress_threshold :100-105, write-back :46-96

@@ -195,10 +195,13 @@ inline void update_models_on_both_strands(DataSet &ds, int device = 0) {
     std::vector<uint64_t> ids;
     for (const auto &kv : pileups) {
         const size_t len = kv.second.size();
-        if (len >= std::max<size_t>(cov, 2) - 2 && len < cov + 2 && chunk_of.count(kv.first)) ids.push_back(kv.first);
+        if (len >= std::max<size_t>(cov, 2) - 2 && len < cov + 2) ids.push_back(kv.first);
     }
+    // model_tune.rs:99-118: sort by id, truncate to TRAIN_UNIT_SIZE, and only THEN drop the pile-ups of chunks that are not
+    // among the selected chunks (the filter_map of :119-122) -- a stray node can cost a training pile-up
     std::sort(ids.begin(), ids.end());
     if (ids.size() > TRAIN_UNIT_SIZE) ids.resize(TRAIN_UNIT_SIZE);
+    ids.erase(std::remove_if(ids.begin(), ids.end(), [&](uint64_t id) { return chunk_of.count(id) == 0; }), ids.end());
     std::vector<jtk_lc_chunk_t> chunks;
     std::vector<uint8_t> tmpl, reads, ops, strand;
     std::vector<uint64_t> read_off{0}, ops_off{0};

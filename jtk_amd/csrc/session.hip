@@ -1372,6 +1372,9 @@ int jtk_lc_polish_chunks(const jtk_lc_params_t *params, size_t n_chunks, const j
                          uint32_t take_num, uint32_t ignore_edge, uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap,
                          uint8_t *ops_out, uint64_t *ops_out_off, uint64_t ops_cap, jtk_lc_result_t *result, int device) {
     g_last_error.clear();
+    if (!params) return fail(JTK_ERR_INVALID_ARG, "null params");
+    if (n_chunks && (!chunks || !tmpl_bases || !read_bases || !read_off || !ops || !ops_off || !strand))
+        return fail(JTK_ERR_INVALID_ARG, "null input");
     if (!cons_out || !cons_off || !ops_out || !ops_out_off) return fail(JTK_ERR_INVALID_ARG, "null output");
     std::vector<ChunkExtra> extra(n_chunks);
     std::vector<jtk_lc_chunk_t> ch(chunks, chunks + (chunks ? n_chunks : 0));

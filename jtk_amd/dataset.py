@@ -165,6 +165,16 @@ def _seq(s):
     return np.frombuffer(s.encode("ascii"), dtype=np.uint8)
 
 
+def training_pileup_ids(piles, chunk_of):
+    """truncate_bucket + the filter_map of estimate_model_parameters_on_both_strands (model_tune.rs:99-133): pile-ups whose
+    coverage lies within 2 of the median, sorted by chunk id, the first TRAIN_UNIT_SIZE = 5 of them, and only THEN without
+    those whose chunk is not among the selected chunks (a stray node can cost a training pile-up)."""
+    covs = sorted(len(v) for v in piles.values())
+    cov = covs[len(covs) // 2]                                       # select_nth_unstable(len / 2)
+    first = sorted(cid for cid, v in piles.items() if max(cov, 2) - 2 <= len(v) < cov + 2)[:5]
+    return [cid for cid in first if cid in chunk_of]
+
+
 def update_models_on_both_strands(ds, device=0):
     """ModelFit::update_models_on_both_strands (model_tune.rs:20-25, :96-156): pick the training pile-ups (:99-118) and
     refit the model on both strands with jtk_lc_fit_model (TRAIN_ROUND = 10)."""
@@ -175,9 +185,7 @@ def update_models_on_both_strands(ds, device=0):
             piles.setdefault(node["chunk"], []).append(node)
     if not piles:
         raise ValueError("update_models_on_both_strands: no pile-up")
-    covs = sorted(len(v) for v in piles.values())
-    cov = covs[len(covs) // 2]                                       # select_nth_unstable(len / 2)
-    ids = sorted(cid for cid, v in piles.items() if max(cov, 2) - 2 <= len(v) < cov + 2 and cid in chunk_of)[:5]
+    ids = training_pileup_ids(piles, chunk_of)
     pile = [(cid, int(chunk_of[cid]["copy_num"]), _seq(chunk_of[cid]["seq"]), [_seq(n["seq"]) for n in piles[cid]],
              [cigar_to_ops(n["cigar"]) for n in piles[cid]], [1 if n["is_forward"] else 0 for n in piles[cid]], None)
             for cid in ids]

@@ -71,6 +71,18 @@ def synthetic_dataset(n_chunks, tmpl_len, rph):
             "processed_stages": [{"stage_name": "encode", "arg": []}]}
 
 
+def test_training_pileups_are_truncated_before_unknown_chunks_are_dropped():
+    """model_tune.rs:99-133: sort by id, take 5, THEN drop pile-ups whose chunk is not selected"""
+    from jtk_amd import dataset
+    piles = {cid: [object()] * 30 for cid in range(1, 9)}
+    piles[0] = [object()] * 30          # nodes of a chunk that is not among the selected chunks
+    piles[9] = [object()] * 80          # coverage far from the median: never a training pile-up
+    chunk_of = {cid: {} for cid in range(1, 10)}
+    assert dataset.training_pileup_ids(piles, chunk_of) == [1, 2, 3, 4]
+    del piles[0]
+    assert dataset.training_pileup_ids(piles, chunk_of) == [1, 2, 3, 4, 5]
+
+
 def test_synthetic_dataset_has_exactly_the_reference_fields():
     """every struct of the wire format carries exactly the fields of its serde derive (definitions/src/lib.rs), in
     particular ErrorRate's `mism_sd` (:906); a missing field or an unknown enum variant is rejected like serde does"""

@@ -50,6 +50,17 @@ def test_correction_matches_oracle(seed, kw):
     assert np.array_equal(och, gch)
 
 
+def test_correction_in_several_device_batches_matches_oracle(monkeypatch):
+    """jtk_lc_correct_clustering runs its jobs through the device in batches bounded by the bytes of their similarity matrices
+    (a genome-scale DataSet must not need all of them at once): with a budget of one matrix per batch the result is unchanged"""
+    import os
+    prob = correction_problem(3, n_chunks=10, n_reads=120, window=(2, 9), wrong=0.03)
+    monkeypatch.setenv("JTK_CC_SIMS_BUDGET", "100")   # fewer doubles than any matrix: every job is its own batch
+    (orc, ocl, ot, och, _), (grc, gcl, gt, gch, _) = both(prob)
+    assert orc == 0 and grc == 0
+    assert np.array_equal(ot, gt) and np.array_equal(ocl, gcl) and np.array_equal(och, gch)
+
+
 def test_correction_protected_and_selected():
     prob = correction_problem(21, n_chunks=8, n_reads=80, wrong=0.05)
     for min_gain in (0.0, 0.2, 1e9):

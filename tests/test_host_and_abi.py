@@ -141,3 +141,15 @@ def test_invalid_arguments_are_rejected(jtk_lib):
     assert jtk_lib.jtk_lc_session_create(None, 1, b.chunks.ctypes.data, ffi.u8p(b.tmpl_bases), ffi.u8p(b.read_bases),
                                          ffi.u64p(b.read_off), ffi.u8p(b.ops), ffi.u64p(b.ops_off),
                                          ffi.u8p(b.strand), 2, 0, C.byref(h)) == -1
+
+
+def test_polish_chunks_rejects_null_arguments(jtk_lib):
+    """jtk_lc_polish_chunks validates before it dereferences (params == NULL or chunks == NULL used to be a crash)"""
+    b, cfg, p = helpers.small_batch(n_chunks=1, tmpl_len=200, reads_per_hap=4)
+    out = api._outputs(b)
+    args = lambda params, chunks: (params, 1, chunks, ffi.u8p(b.tmpl_bases), ffi.u8p(b.read_bases), ffi.u64p(b.read_off),  # noqa: E731
+                                  ffi.u8p(b.ops), ffi.u64p(b.ops_off), ffi.u8p(b.strand), 0, 0, 0, ffi.u8p(out["cons"]),
+                                  ffi.u64p(out["cons_off"]), len(out["cons"]), ffi.u8p(out["ops_out"]), ffi.u64p(out["ops_out_off"]),
+                                  len(out["ops_out"]), out["result"].ctypes.data, 0)
+    assert jtk_lib.jtk_lc_polish_chunks(*args(None, b.chunks.ctypes.data)) == -1
+    assert jtk_lib.jtk_lc_polish_chunks(*args(C.byref(p), None)) == -1
