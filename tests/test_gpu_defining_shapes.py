@@ -1,0 +1,88 @@
+"""GPU parity at the defining shapes, in numbers that exercise the kernels' rare paths (band moves in runs, block boundaries,
+generic groups, flushes): the committed 64-chunk golden of the headline workload (no oracle in the loop), 256 chunks of it
+against the oracle, Poisson(60) coverage, and one call that mixes the three pair-HMM kernels."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers
+import oracle_ffi as O
+from jtk_amd import api, batch as jb, synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def check_equal(dev, ora, b, tol=1e-4):
+    assert np.array_equal(dev["result"]["status"], ora["result"]["status"])
+    assert np.array_equal(dev["result"]["polish_rounds"], ora["result"]["polish_rounds"])
+    assert np.array_equal(dev["result"]["n_variants"], ora["result"]["n_variants"])
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert np.array_equal(dev["label"], ora["label"])
+    assert np.abs(dev["log_post"] - ora["log_post"]).max() < tol
+    assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(ora["log_post"]))       # in fact bit for bit
+    assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(ora["result"]["score"]))
+    n = int(ora["cons_off"][-1])
+    assert np.array_equal(dev["cons_off"], ora["cons_off"]) and bytes(dev["cons"][:n]) == bytes(ora["cons"][:n])
+
+
+def test_cfg3_golden_64_chunks(jtk_lib):
+    """tests/golden/cfg3_64.npz (made by the oracle, tests/golden/make_cfg3_64.py): the device reproduces it with no oracle
+    in the loop -- a regression in a kernel shows here even where the oracle cannot be built"""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_cfg3_64
+    g = np.load(os.path.join(HERE, "golden", "cfg3_64.npz"))
+    b, cfg = synth.make_batch("ont_diploid", 64)
+    assert make_cfg3_64.inputs_digest(b) == str(g["inputs_sha256"][0]), "the generator no longer produces the golden's inputs"
+    p = jb.default_params(cfg["coverage"], cfg["band_frac"])
+    dev = api.cluster_chunks(p, b)
+    check_equal(dev, dict(result=g["result"], label=g["label"], log_post=g["log_post"], cons=g["cons"], cons_off=g["cons_off"]), b)
+
+
+def test_256_chunks_of_the_headline_workload_match_the_oracle(jtk_lib, oracle):
+    """what bench.py's cpu_baseline leg compares on the side, as a test: chunks 64 .. 319 of cfg 3 (other RNG streams and
+    band paths than the golden's)"""
+    b, cfg = synth.make_batch("ont_diploid", 256, first_chunk_id=64)
+    p = jb.default_params(cfg["coverage"], cfg["band_frac"])
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
+    assert ora["rc"] == 0
+    check_equal(dev, ora, b)
+
+
+def test_poisson_coverage_matches_the_oracle(jtk_lib, oracle):
+    """a real 60x data set has Poisson(60) reads per pile-up: a third of them exceed the 63 reads of the one-register chain"""
+    rng = np.random.default_rng(5)
+    base = dict(synth.CONFIGS["ont_diploid"])
+    piles = []
+    for c in range(24):
+        cfg = dict(base)
+        cfg["reads_per_hap"] = max(2, int(rng.poisson(60)) // 2)
+        piles.append(synth.make_pileup(7000 + c, cfg, synth.SEED0, 0))
+    b = jb.pack(piles)
+    assert (b.chunks["n_reads"] > 63).any() and (b.chunks["n_reads"] < 60).any()
+    p = jb.default_params(base["coverage"], base["band_frac"])
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
+    assert ora["rc"] == 0
+    check_equal(dev, ora, b)
+
+
+@pytest.mark.parametrize("config,lens", [("ont_diploid", (700, 2000, 4200, 1500, 900)), ("hifi_diploid", (2000, 2600, 1200)),
+                                          ("ont_noisy", (2000, 1100))])
+def test_one_call_mixing_the_pair_hmm_kernels_matches_the_oracle(jtk_lib, oracle, config, lens):
+    """template lengths that put the chunks of ONE call on phmm_pair_kernel (radius <= 14), phmm_kernel (15 .. 30) and
+    phmm_wide_kernel (> 30) side by side; HiFi (radius 10 .. 13) and the 5 %-error stress profile too"""
+    base = dict(synth.CONFIGS[config])
+    piles = []
+    for c, L in enumerate(lens):
+        cfg = dict(base, tmpl_len=L, reads_per_hap=12)
+        piles.append(synth.make_pileup(9000 + 10 * c, cfg, synth.SEED0, 1))
+    b = jb.pack(piles)
+    p = jb.default_params(12.0, base["band_frac"])
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
+    assert ora["rc"] == 0
+    check_equal(dev, ora, b)
