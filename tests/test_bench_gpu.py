@@ -75,6 +75,8 @@ def test_eight_rank_run_of_the_full_dataset_matches_the_one_rank_run(jtk_lib, tm
     2,500-chunk partition; the labels / k / scores every rank's shard contributes to the one all-gather must be those of the
     1-rank run, chunk by chunk.  (The collective is gloo here: RCCL has never seen more than one rank of this code.)"""
     import numpy as np
+    from jtk_amd import api
+    api.trim_cache(0)  # this (pytest) process may still hold pooled workspaces of earlier tests: nine more processes follow
     env = dict(os.environ, JTK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", JTK_LC_POOL_GB="16")
     common = ["--steps", "1", "--warmup", "0", "--no-e2e", "--no-cpu-baseline", "--no-shard8"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-labels", str(tmp_path / "one.npz")]
@@ -84,7 +86,7 @@ def test_eight_rank_run_of_the_full_dataset_matches_the_one_rank_run(jtk_lib, tm
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
                         "--gpus", "8", "--streams", "2", "--dump-labels", str(tmp_path / "eight.npz")] + common,
                        capture_output=True, text=True, cwd=ROOT, env=env, timeout=1500)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == 0, "8-rank run failed:\n" + r.stderr[-6000:]
     line = last_json(r.stdout)
     assert line["n_gpus"] == 8 and line["config"]["chunks_total"] == 2500 and line["gather_ok"]
     assert line["gathered_reads"] == 2500 * 60 and 300 <= line["config"]["chunks_this_rank"] <= 325
