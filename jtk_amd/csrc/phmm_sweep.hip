@@ -37,7 +37,9 @@ namespace {
 #define RS 1024                // bytes per ring slot: 64 lanes x (toM, toD)
 #define S_EM (8 * RS)          // eM[16] as doubles (32-byte aligned: a row's address can be OR-ed with the column)
 #define S_EI (S_EM + 128)      // eI[20]
-#define S_VAR (S_EI + 160)     // delta words | block exponents | template codes | read codes
+#define S_STAGE (S_EI + 160)   // 3 finished rows x 16 row sums on their way out (a half group retires at most 3 rows)
+#define S_SMETA (S_STAGE + 384)  // their (row, exponent)
+#define S_VAR (S_SMETA + 32)   // delta words | block exponents | template codes | read codes
 
 __device__ __forceinline__ double rot_from_prev(double v) {  // lane l <- lane (l-1)&63
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -122,8 +124,13 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
     const int T = L + n;
     const uint32_t n_blk = ((lds_tmpl + lds_read) >> 6) + 4;
     const uint32_t S_DELTA = S_VAR, S_EF = S_DELTA + n_blk * 8, S_XS = (S_EF + n_blk * 4 + 15) & ~15u,
-                   S_EY = S_XS + ((lds_tmpl + 2 * PAD + 15) & ~15u);
-    const uint32_t XS0 = S_XS + PAD - 1;  // smem[XS0 + i] = 32 * code(x[i-1]): the eM row of template row i, in bytes
+                   S_EY = S_XS + ((((lds_tmpl + 2 * PAD + 3) >> 2) + 15) & ~15u);
+    // template codes: four 2-bit codes per byte, PAD codes of padding either side (the sweeps look a template row up once per
+    // band move and in the generic steps only, so they can afford the unpacking; a byte per code cost a twelfth wave per CU)
+    auto xs_of = [&](int i) -> uint32_t {  // 32 * code(x[i-1]): the eM row of template row i, in bytes
+        const uint32_t q = (uint32_t)(i - 1 + PAD);
+        return ((uint32_t)smem[S_XS + (q >> 2)] >> (2u * (q & 3u)) & 3u) << 5;
+    };
     const uint32_t EY0 = S_EY + PAD;      // smem[EY0 + j] = 8 * (y[j-1] | ctx(j) << 2): the eI entry of read column j, in bytes
     uint64_t *s_delta = reinterpret_cast<uint64_t *>(smem + S_DELTA);
     int *s_EF = reinterpret_cast<int *>(smem + S_EF);
@@ -149,9 +156,14 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
     auto delta_byte = [&](int k) -> uint32_t { return (uint32_t)uni((int)lds_u8(S_DELTA + (uint32_t)k)); };
     __syncthreads();
     {  // stage the codes (as byte offsets, zero padded), the emission tables and the band deltas
-                for (int p = lane; p < L + 2 * PAD; p += 64) {
-            const int q = p - PAD;
-            smem[S_XS + p] = (q >= 0 && q < L) ? (uint8_t)(gx[q] << 5) : (uint8_t)0;
+        for (int pb = lane; pb < (L + 2 * PAD + 3) >> 2; pb += 64) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int q = 4 * pb + k - PAD;
+                v |= (q >= 0 && q < L) ? (uint32_t)(gx[q] & 3u) << (2 * k) : 0u;
+            }
+            smem[S_XS + pb] = (uint8_t)v;
         }
                 for (int p = lane; p < n + 1 + 2 * PAD + 16; p += 64) {
             const int q = p - PAD;
@@ -206,7 +218,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 c += delta_bit(t);
                 const int lo = c - r, off = (lane - lo) & 63, i = lo + off, j = t - i;
                 const bool active = off <= 2 * r && (unsigned)i <= (unsigned)L && (unsigned)j <= (unsigned)n;
-                const uint32_t ey8 = lds_u8(EY0 + j), xs = lds_u8(XS0 + i);
+                const uint32_t ey8 = lds_u8(EY0 + j), xs = xs_of(i);
                 const double eMv = lds_f64(S_EM + xs + (ey8 & 24)), eIv = lds_f64(S_EI + ey8);
                 const double pM = rot_from_prev(toM_2), pD = rot_from_prev(toD_1);
                 double fm = eMv * pM, fi = eIv * toI_1, fd = pD;
@@ -248,7 +260,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 const int lo = c - r;
                 lo6 = lo & 63;
                 row = lo + ((lane - lo) & 63);
-                xrow = S_EM + lds_u8(XS0 + row);
+                xrow = S_EM + xs_of(row);
                 band = rotl64(BAND, lo6);
                 fast_ready = true;
             }
@@ -267,7 +279,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                         toI_1 = 0.0;
                         toD_1 = 0.0;
                         row += 64;
-                        xrow = S_EM + lds_u8(XS0 + row);
+                        xrow = S_EM + xs_of(row);
                     }
                     lo6 = (lo6 + 1) & 63;
                     c += 1;
@@ -463,7 +475,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                         EB += e;
                     }
                 }
-                const uint32_t ey8 = lds_u8(EY0 + j), xs = lds_u8(XS0 + i), y8 = ey8 & 24u;
+                const uint32_t ey8 = lds_u8(EY0 + j), xs = xs_of(i), y8 = ey8 & 24u;
                 const double hM = lds_f64(S_EM + xs + y8) * vm;
                 const double hI = lds_f64(S_EI + ey8) * vi;
                 const int G = EFcur + EB;
@@ -507,7 +519,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 const int lo = c - r, off = (lane - lo) & 63;
                 lo6 = lo & 63;
                 row = off <= 2 * r ? lo + off : lo + off - 64;
-                xrow = S_EM + lds_u8(XS0 + row);
+                xrow = S_EM + xs_of(row);
                 band = rotl64(BAND, lo6);
                 fast_ready = true;
 #pragma unroll
@@ -548,7 +560,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                         bD_1 = 0.0;
                         rowG = Gprev;
                         row -= 64;
-                        xrow = S_EM + lds_u8(XS0 + row);
+                        xrow = S_EM + xs_of(row);
                     }
                     left |= 1ull << hi6;
                     lo6 = (lo6 - 1) & 63;
@@ -658,17 +670,29 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
 #undef BWD_PRODUCTS
                 c4 = c5;
                 c5 -= (int)((w16 >> (10 - u)) & 1u);  // c[t-5] - c[t-6]
-                // the rows that left the band during the half group are final: they sat untouched in their (idle) lanes
-                if ((u & 3) == 3 && lanes(left)) {
-                KEEP_MASKED;
+                // the rows that left the band during the half group are final: they sat untouched in their (idle) lanes.  They
+                // leave through LDS: a row's 128 bytes go out as ONE line (8 lanes x 16 B) instead of 8 stores of one lane.
+                if ((u & 3) == 3 && left != 0) {
+                    const uint32_t nleft = (uint32_t)__builtin_popcountll(left);
+                    if (lanes(left)) {
+                        KEEP_MASKED;
+                        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(left >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)left, 0u));
+                        double2 *sd = reinterpret_cast<double2 *>(smem + S_STAGE + slot * 128u);
+#pragma unroll
+                        for (int k = 0; k < JTK_ACC_N / 2; k++) sd[k] = make_double2(acc[2 * k], acc[2 * k + 1]);
+                        *reinterpret_cast<int2 *>(smem + S_SMETA + slot * 8u) = make_int2(row + 64, rowG);
+#pragma unroll
+                        for (int k = 0; k < JTK_ACC_N; k++) acc[k] = 0.0;
+                    }
 #ifndef JTK_PHMM_X_NOFLUSH
-                double2 *dst = reinterpret_cast<double2 *>(raw + (uint64_t)(row + 64) * JTK_ACC_N);
-#pragma unroll
-                for (int k = 0; k < JTK_ACC_N / 2; k++) dst[k] = make_double2(acc[2 * k], acc[2 * k + 1]);
-                rawG[row + 64] = rowG;
+                    if ((uint32_t)lane < 8u * nleft) {
+                        KEEP_MASKED;
+                        const double2 v = reinterpret_cast<const double2 *>(smem + S_STAGE)[lane];  // slot lane / 8, part lane % 8
+                        const int2 meta = *reinterpret_cast<const int2 *>(smem + S_SMETA + (uint32_t)(lane >> 3) * 8u);
+                        reinterpret_cast<double2 *>(raw + (uint64_t)meta.x * JTK_ACC_N)[lane & 7] = v;
+                        if ((lane & 7) == 0) rawG[meta.x] = meta.y;
+                    }
 #endif
-#pragma unroll
-                for (int k = 0; k < JTK_ACC_N; k++) acc[k] = 0.0;
                 }
                 if ((u & 3) == 3) left = 0;
             }
@@ -730,7 +754,7 @@ size_t phmm_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
     const uint32_t n_blk = ((max_tmpl + max_read) >> 6) + 4;
     size_t b = S_VAR + (size_t)n_blk * 12;
     b = (b + 15) & ~(size_t)15;
-    b += ((max_tmpl + 2 * PAD + 15) & ~15u) + max_read + 1 + 2 * PAD + 16;
+    b += ((((max_tmpl + 2 * PAD + 3) >> 2) + 15) & ~15u) + max_read + 1 + 2 * PAD + 16;
     return (b + 15) & ~(size_t)15;
 }
 

@@ -1,6 +1,9 @@
 #!/bin/bash
+# Diagnostic (GPU box): per (K, n, D) statistics of the table-driven chain on full-size 4-copy pile-ups (-DJTK_MCMC_STATS build
+# into a SEPARATE library: the product .so is left alone).
 set -u
 cd ${GRAFT_REPO_ROOT:-/root/repo}
+N=${1:-2}
 cat > /tmp/tabrun.py <<'PY'
 import sys, time, torch
 sys.path.insert(0, ".")
@@ -14,17 +17,25 @@ with api.Session(p, b) as s:
     r = s.fetch_results()
 print("MCMCMS", t["kernel_ms"]["mcmc"], "k", r["result"]["cluster_num"].tolist(), "D", r["result"]["n_variants"].tolist())
 PY
-JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_STATS" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
-python3 /tmp/tabrun.py 2 > gpurun_out/tabstat_raw.txt 2>&1
+JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_STATS ${JTK_STATS_EXTRA:-}" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
+python3 /tmp/tabrun.py $N > gpurun_out/tabstat_raw.txt 2>&1
 grep MCMCMS gpurun_out/tabstat_raw.txt
-grep -c TABSTAT gpurun_out/tabstat_raw.txt
 python3 - <<'PY'
-import re
-tot = 0
+import re, collections
+acc = collections.defaultdict(lambda: [0] * 10)
 for line in open("gpurun_out/tabstat_raw.txt"):
-    m = re.search(r"cyc_total (\d+)", line)
-    if m: tot += int(m.group(1))
-print("sum of chain cycles over both chunks", tot, "-> per chunk s at 2.4GHz", tot/2/2.4e9)
+    m = re.search(r"TABSTAT chunk \d+ K (\d+) n (\d+) D (\d+) steps (\d+) fast (\d+) events (\d+) accepts (\d+) reloads (\d+) scalars (\d+) cyc_rebuild (\d+) cyc_event (\d+) cyc_total (\d+)", line)
+    if m:
+        v = [int(x) for x in m.groups()]
+        a = acc[(v[0], v[1], v[2])]
+        a[0] += 1
+        for i in range(9):
+            a[i + 1] += v[3 + i]
+for key, a in sorted(acc.items()):
+    st = a[1]
+    print("K %d n %d D %d: %d chains; per step: %.1f cycles total; fast %.1f%% events %.2f%% accepts %.2f%% reloads %.2f%% scalars %.3f%%; "
+          "rebuild %.0f cyc each, event (incl. rebuild) %.0f cyc each"
+          % (*key, a[0], a[9] / st, 100.0 * a[2] / st, 100.0 * a[3] / st, 100.0 * a[4] / st, 100.0 * a[5] / st, 100.0 * a[6] / st,
+             a[7] / max(1, a[4]), a[8] / max(1, a[3])))
 PY
-grep -E "K2PROD|K2WAIT" gpurun_out/tabstat_raw.txt | head -5
 python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
