@@ -292,6 +292,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- a shard whose WORKSPACES do not fit the device beside each other (cfg 4: 2,500 x 160 reads x 555 KB of row sums and
+    #      tables = 220 GB) cannot be held as resident sessions: its step is the library's one-shot call, which streams slices
+    #      through a bounded workspace (session.hip run_once).  Inputs then cross PCIe inside the step (~1 GB: noise next to the
+    #      step), and the line says so.
+    cap_len = int(cfg["tmpl_len"]) + int(cfg["tmpl_len"]) // 8 + 64
+    est_bytes = float(batch.n_reads) * (cap_len + 1) * 256.0 + args.streams * 14e9
+    total_mem = float(torch.cuda.get_device_properties(local_rank).total_memory)
+    if est_bytes > 0.80 * total_mem:
+        def one_step():
+            r = api.cluster_chunks(params, batch, device=local_rank)
+            return r, api.last_timing()
+        for _ in range(args.warmup):
+            one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out, tm = one_step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        value = n_total * args.steps / elapsed
+        alg = batch.algorithmic_bytes(k_per_chunk=out["result"]["cluster_num"]) / max(1, batch.n_chunks)
+        achieved = value * alg / 1e9
+        km = tm["kernel_ms"]
+        if rank == 0:
+            print(json.dumps(dict(
+                metric="chunks clustered/sec (whole node), 60x ONT 2kbp chunks", value=value, unit="chunks/s", n_gpus=world,
+                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
+                scaling=args.scaling, vs_baseline=None, dtype="f64", data="synthetic",
+                config=dict(workload=args.workload, chunks_total=int(n_total), chunks_this_rank=int(batch.n_chunks),
+                            reads_per_chunk=int(reads_per_chunk), chunk_len=int(cfg["tmpl_len"]), copy_num=int(cfg["copy_num"]),
+                            band_frac=cfg["band_frac"], sharding="1 gpu" if world == 1 else f"{args.scaling}: LPT over {world} ranks",
+                            step="ONE-SHOT: jtk_lc_cluster_chunks from host buffers per step (the workspaces of this shard, "
+                                 f"~{est_bytes / 1e9:.0f} GB, do not fit the device as resident sessions; the library streams slices "
+                                 "through a bounded workspace); inputs cross PCIe inside the step"),
+                roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS * world, unit="GB/s",
+                              frac=achieved / (HBM_PEAK_GBPS * world), traffic=None, algorithmic_bytes_per_chunk=alg,
+                              kernel_ms_summed_over_slices=km,
+                              secondary=dict(chain_ms_share=km["mcmc"] / max(1e-9, sum(km.values())))),
+                chunks_ok=int((out["result"]["status"] == 0).sum()), lib_sha16=sha,
+                mean_polish_rounds=float(out["result"]["polish_rounds"].mean()),
+                mean_cluster_num=float(out["result"]["cluster_num"].mean()), cpu_baseline=None)))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # ---- the rank's shard as `streams` resident slices (equal shares of the reads, contiguous chunk ranges)
     n_streams = max(1, min(args.streams, batch.n_chunks))
     bounds = [round(i * batch.n_chunks / n_streams) for i in range(n_streams + 1)]

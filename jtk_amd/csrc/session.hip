@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -1224,7 +1225,36 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
     size_t per_dev = std::min<size_t>(4, n_chunks / n_devices / 500);  // 2500 chunks: 2.08 / 1.80 / 2.08 / 2.17 s in 3 / 4 / 5 / 6 slices
     if (const char *e = getenv("JTK_LC_SLICES")) per_dev = (size_t)atoi(e);
     if (per_dev < 1) per_dev = 1;
-    size_t n_slices = per_dev * n_devices;
+    // per_dev slices of a device run side by side.  A batch whose workspaces do not fit beside each other that way (4-copy
+    // pile-ups: 160 reads x 555 KB of row sums + tables per chunk) is cut into MORE slices, which the per_dev worker threads
+    // of the device take one after the other: the workspace in use stays bounded by what per_dev slices need, and the
+    // blocks a finished slice returns to the pool are what the next one takes.
+    size_t slices_per_dev = per_dev;
+    if (chunks && n_chunks) {
+        uint64_t est = 0, max_len = 0, max_rd = 0;
+        for (size_t c = 0; c < n_chunks; c++) {
+            const uint64_t cap = chunks[c].tmpl_len + chunks[c].tmpl_len / 8 + 64;
+            est += (uint64_t)chunks[c].n_reads * (cap + 1) * ((JTK_ACC_N + JTK_NUM_ROW) * 8 + 16);  // raw + table + ops / deltas
+            max_len = std::max<uint64_t>(max_len, cap);
+            if (read_off) {
+                const uint64_t r0 = chunks[c].read_first, r1 = r0 + chunks[c].n_reads;
+                if (r1 > r0) max_rd = std::max<uint64_t>(max_rd, (read_off[r1] - read_off[r0]) / (r1 - r0) + 64);
+            }
+        }
+        size_t free_b = 0, total_b = 0;
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (hipSetDevice(devices[0]) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+            const uint64_t scratch = 3072ull * (max_len + max_rd + 32) * 64 * 16;       // the pair-HMM stripes of one slice
+            const double budget = 0.80 * (double)total_b / (double)per_dev - (double)scratch;  // pooled blocks count as free
+            if (budget > 0) {
+                const size_t need = (size_t)std::ceil((double)est / (double)n_devices / budget);
+                if (need > slices_per_dev) slices_per_dev = need;
+            }
+        }
+        (void)hipSetDevice(cur);
+    }
+    size_t n_slices = slices_per_dev * n_devices;
     if (n_slices > n_chunks) n_slices = n_chunks;
     if (n_slices < 2 || !params || !chunks || !read_off || !ops_off || !label || !log_post || !result)
         return run_slice(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, skip_polish, label,
@@ -1256,7 +1286,7 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
         jtk_lc_timing_t timing;
     };
     std::vector<Slice> slices(n_slices);
-    std::vector<std::thread> threads;
+    std::vector<std::function<void()>> jobs(n_slices);
     for (size_t sl = 0; sl < n_slices; sl++) {
         Slice &S = slices[sl];
         const size_t c0 = first[sl], c1 = first[sl + 1];
@@ -1279,8 +1309,8 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
             S.ops.resize(ops_need);
             S.ops_off.resize(r1 - r0 + 1);
         }
-        const int device = devices[std::min(sl / per_dev, n_devices - 1)];
-        threads.emplace_back([=, &S]() {
+        const int device = devices[std::min(sl / slices_per_dev, n_devices - 1)];
+        jobs[sl] = ([=, &S]() {
             S.rc = run_slice(params, c1 - c0, S.chunks.data(), tmpl_bases, read_bases, read_off + r0, ops, ops_off + r0,
                              strand + r0, skip_polish, label + r0, log_post + r0 * post_stride, post_stride, result + c0,
                              want_cons ? S.cons.data() : nullptr, want_cons ? S.cons_off.data() : nullptr, S.cons.size(),
@@ -1289,7 +1319,20 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
             S.timing = g_timing;
         });
     }
-    for (auto &t : threads) t.join();
+    {   // per device: per_dev worker threads take the device's slices in order
+        std::vector<std::thread> threads;
+        std::vector<std::atomic<size_t>> next(n_devices);
+        for (size_t d = 0; d < n_devices; d++) next[d] = d * slices_per_dev;
+        for (size_t d = 0; d < n_devices; d++) {
+            const size_t end = std::min(n_slices, (d + 1) * slices_per_dev);
+            for (size_t w = 0; w < per_dev && d * slices_per_dev + w < end; w++)
+                threads.emplace_back([&, d, end]() {
+                    for (size_t sl = next[d].fetch_add(1); sl < end; sl = next[d].fetch_add(1))
+                        if (jobs[sl]) jobs[sl]();
+                });
+        }
+        for (auto &t : threads) t.join();
+    }
     // stitch the variable-length outputs together in chunk order
     int rc = 0;
     uint64_t co = 0, oo = 0;
