@@ -1,12 +1,12 @@
 #!/bin/bash
 # Diagnostic (GPU box): the chain kernel's ring size (JTK_MCMC_SEG_LOG: 5 = 4096 draws / 70 KB of LDS per workgroup,
-# 4 = 2048 draws / 46 KB) against parity, the serial step and the 4-in-flight throughput.
+# 4 = 2048 draws / 24 KB of ring, 3 = 1024 draws / 12 KB) against parity, the serial step and the 4-in-flight throughput.
 set -u
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-for seg in 4 5; do
+for seg in ${SEGS:-3 4}; do
   JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_SEG_LOG=$seg" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
   echo "== SEG_LOG $seg"
-  if [ $seg = 4 ]; then timeout 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "chain or size_only or features or full_size" 2>&1 | tail -2; fi
+  if [ $seg != 4 ]; then timeout 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "chain or size_only or features or full_size" 2>&1 | tail -2; fi
   timeout 300 python3 bench.py --streams 1 --steps 2 --no-cpu-baseline | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('serial', round(d['value'],1), d['roofline']['all_kernels_ms_per_step'])"
   timeout 300 python3 bench.py --steps 12 --no-cpu-baseline | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('4 in flight', round(d['value'],1), d['roofline']['all_kernels_ms_per_step'])"
 done
