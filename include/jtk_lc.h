@@ -130,8 +130,9 @@ int jtk_lc_cluster_chunks(const jtk_lc_params_t *params, size_t n_chunks, const 
                           uint64_t *ops_out_off, uint64_t ops_cap, int device);
 
 /* The same call over several GPUs of one node from one host process (SURVEY 8b's `device_mask`, as a list): chunks are
- * dealt to `devices` in contiguous, read-balanced shares, each share runs as on a single device (sliced, overlapped), the
- * outputs are written in place as above.  Chunks are independent (one RNG stream per chunk id), so results do not depend on
+ * dealt to `devices` by longest-processing-time-first over a cost model (pair-HMM cells + Metropolis steps per candidate k;
+ * the partition bench.py / jtk_amd.sharding use between ranks), each share is gathered into its own batch and runs as on a
+ * single device (sliced, overlapped), and the outputs are scattered back into the caller's order, laid out as above.  Chunks are independent (one RNG stream per chunk id), so results do not depend on
  * the device list; the path has no exchange step and no collective runs.  A device may be listed more than once. */
 int jtk_lc_cluster_chunks_multi(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
                                 const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
@@ -313,6 +314,8 @@ typedef struct jtk_lc_timing {
     double h2d_ms, d2h_ms;
     double kernel_ms[JTK_K_COUNT];
     uint32_t kernel_launches[JTK_K_COUNT];
+    uint32_t chain_lds_bytes[2]; /* LDS work area per chain workgroup of the two launch classes (0: class not used); class 0
+                                  * stays <= 80 KiB (two workgroups per CU), class 1 <= 160 KiB */
 } jtk_lc_timing_t;
 int jtk_lc_last_timing(jtk_lc_timing_t *out);
 

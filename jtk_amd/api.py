@@ -164,7 +164,8 @@ def last_timing():
     check(ffi.lib().jtk_lc_last_timing(C.byref(t)))
     return dict(total_ms=t.total_ms, h2d_ms=t.h2d_ms, d2h_ms=t.d2h_ms,
                 kernel_ms={n: t.kernel_ms[i] for i, n in enumerate(ffi.KERNEL_NAMES)},
-                kernel_launches={n: int(t.kernel_launches[i]) for i, n in enumerate(ffi.KERNEL_NAMES)})
+                kernel_launches={n: int(t.kernel_launches[i]) for i, n in enumerate(ffi.KERNEL_NAMES)},
+                chain_lds_bytes=[int(t.chain_lds_bytes[0]), int(t.chain_lds_bytes[1])])
 
 
 class Session:

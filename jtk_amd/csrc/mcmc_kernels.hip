@@ -48,6 +48,8 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 }
 
 // The ring of raw xoshiro256** outputs.  `wr` draws have been produced, the consumer has released `rd`.
+#define JTK_LIGHT_MAX_READS 63u  // what mcmc_kernel_light takes: diploid pile-ups of <= 63 reads ...
+#define JTK_LIGHT_MAX_DIM 2u     // ... with <= 2 variant columns (mcmc_chain_k2<1,..> / <2,..>: 168 registers)
 #ifndef JTK_MCMC_SEG_LOG
 #define JTK_MCMC_SEG_LOG 4
 #endif
@@ -2172,20 +2174,29 @@ __device__ __noinline__ double fresh_lk(const Lds &m, uint32_t n, uint32_t D, do
     return S;
 }
 
-template <int K>
+template <int K, bool LIGHT>
 __device__ __forceinline__ double mcmc_chain_dispatch(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane);
 
 // mcmc_with_filter (:704-762): the chain, then the reference's closing self-check.  NaN = the reference panics.
-template <int K>
+template <int K, bool LIGHT>
 __device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
-    const double max = mcmc_chain_dispatch<K>(m, n, D, cov, rng, lane);
+    const double max = mcmc_chain_dispatch<K, LIGHT>(m, n, D, cov, rng, lane);
     const double fresh = fresh_lk<K>(m, n, D, cov, m.assign, lane);
     if (!ubool(fabs(max - fresh) < 0.0001)) return __builtin_nan("");
     return max;
 }
 
-template <int K>
+template <int K, bool LIGHT>
 __device__ __forceinline__ double mcmc_chain_dispatch(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
+    if (LIGHT) {
+        // the light kernel (mcmc_kernel_light) holds only the two chain variants that fit 168 registers; chain_split_kernel
+        // sends it nothing else.  NaN = the chunk fails, loudly, should that ever not hold.
+        if (!(K == 2 && n <= JTK_LIGHT_MAX_READS && D >= 1 && D <= JTK_LIGHT_MAX_DIM)) return __builtin_nan("");
+        rng_set_parse_mode(rng, PM_K2, lane);
+        const K2Mem km = {m.data, m.lfact, m.assign, m.k2_stats};
+        if (D == 1) return mcmc_chain_k2<1, true, 1>(km, n, D, cov, &rng, lane);
+        return mcmc_chain_k2<2, true, 1>(km, n, D, cov, &rng, lane);
+    }
     if (K == 2 && n <= 127 && D >= 1 && D <= 8) {
         rng_set_parse_mode(rng, PM_K2, lane);
         const K2Mem km = {m.data, m.lfact, m.assign, m.k2_stats};
@@ -2257,14 +2268,14 @@ __device__ __forceinline__ void get_likelihood_gain(const Lds &m, uint32_t n, ui
 }
 
 // mcmc_clustering (:649-670): labels -> m.best, per-read gains -> m.fbuf, used columns -> m.used
-template <int K>
+template <int K, bool LIGHT>
 __device__ __forceinline__ bool mcmc_clustering(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score,
                                 uint32_t lane) {
     double best = 0.0;
     bool have = false;
     for (int it = 0; it < 20; it++) {
         if (!kmeans(m, n, D, K, rng, lane)) return false;
-        const double lk = mcmc_with_filter<K>(m, n, D, cov, rng, lane);
+        const double lk = mcmc_with_filter<K, LIGHT>(m, n, D, cov, rng, lane);
         if (ubool(lk != lk)) return false;  // the reference panicked inside mcmc_with_filter
 #ifdef JTK_DEBUG_LK
         if (lane == 0 && n == 65) printf("DEVLK n %u D %u it %d lk %.17g pos %u\n", n, D, it, lk, rng.pos);
@@ -2294,26 +2305,34 @@ __device__ __forceinline__ bool mcmc_clustering(const Lds &m, uint32_t n, uint32
 }
 
 // out of line: one candidate cluster count per call keeps the kernel body (k-means, model selection, posteriors) small
-template <int K>
+template <int K, bool LIGHT>
 __device__ __attribute__((noinline)) bool run_k(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score, uint32_t lane) {
-    return mcmc_clustering<K>(m, n, D, cov, rng, score, lane);
+    return mcmc_clustering<K, LIGHT>(m, n, D, cov, rng, score, lane);
 }
 
+template <bool LIGHT>
 __device__ __forceinline__ bool run_k_dyn(uint32_t k, const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score,
                           uint32_t lane) {
+    if (LIGHT) return k == 2 ? run_k<2, true>(m, n, D, cov, rng, score, lane) : false;
     switch (k) {
-        case 2: return run_k<2>(m, n, D, cov, rng, score, lane);
-        case 3: return run_k<3>(m, n, D, cov, rng, score, lane);
-        case 4: return run_k<4>(m, n, D, cov, rng, score, lane);
-        case 5: return run_k<5>(m, n, D, cov, rng, score, lane);
-        case 6: return run_k<6>(m, n, D, cov, rng, score, lane);
-        case 7: return run_k<7>(m, n, D, cov, rng, score, lane);
+        case 2: return run_k<2, false>(m, n, D, cov, rng, score, lane);
+        case 3: return run_k<3, false>(m, n, D, cov, rng, score, lane);
+        case 4: return run_k<4, false>(m, n, D, cov, rng, score, lane);
+        case 5: return run_k<5, false>(m, n, D, cov, rng, score, lane);
+        case 6: return run_k<6, false>(m, n, D, cov, rng, score, lane);
+        case 7: return run_k<7, false>(m, n, D, cov, rng, score, lane);
         default: return false;
     }
 }
 
+template <bool LIGHT>
 __device__ __forceinline__ void likelihood_gain_dyn(uint32_t k, const Lds &m, uint32_t n, uint32_t D, const uint8_t *assign,
                                     double *out, uint32_t lane) {
+    if (LIGHT) {  // copy number 2: one or two clusters
+        if (k == 1) get_likelihood_gain<1>(m, n, D, assign, out, lane);
+        else get_likelihood_gain<2>(m, n, D, assign, out, lane);
+        return;
+    }
     switch (k) {
         case 1: get_likelihood_gain<1>(m, n, D, assign, out, lane); break;
         case 2: get_likelihood_gain<2>(m, n, D, assign, out, lane); break;
@@ -2337,20 +2356,30 @@ __device__ __forceinline__ double gains_expected(const jtk_gains_t *g, uint32_t 
 // that leave their SIMDs idle most of the time: at 360 registers (the legacy chain inlined) a chain wave had its SIMD to itself
 // and 625 workgroups shut every other kernel out of the machine; at 248 two of them share a SIMD, or one sits beside a
 // pair-HMM wave of another batch (152 registers) -- bench.py overlaps batches: 1,680 -> 1,820 chunks/s.
+//
+// Two entry points share the body.  `mcmc_kernel` holds every chain variant (248 registers).  `mcmc_kernel_light` holds only
+// what a diploid pile-up of <= 63 reads with one or two variant columns needs -- 80 % of the headline's chunks have D <= 1,
+// 97 % D <= 2 -- and fits 168 registers: three of its waves share a SIMD, or one of them sits beside TWO pair-HMM waves of
+// another batch (168 + 2 x 168 <= 512) where a 248-register chain wave leaves room for one.  Which chunk goes where is
+// decided on the device (chain_split_kernel: D is known only after the filter), with no host round trip.
 #ifndef JTK_MCMC_WAVES
 #define JTK_MCMC_WAVES 2
 #endif
-__global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(const ChunkMeta *chunks, ChunkState *state,
+template <bool LIGHT>
+__device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *state,
                                                   const jtk_lc_params_t *params, const double *feat_all,
                                                   const uint32_t *vtype_all, const uint64_t *vt_off_all,
                                                   uint32_t vt_stride_mode, uint32_t *label_all, double *post_all,
                                                   uint32_t post_stride, double *lg_all, const uint64_t *lg_off,
                                                   uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, uint32_t jump_in_lds,
-                                                  uint32_t flags, const uint64_t *rng_resume, const uint32_t *order) {
+                                                  uint32_t flags, const uint64_t *rng_resume, const uint32_t *order,
+                                                  const uint32_t *order_count) {
     extern __shared__ __align__(16) unsigned char smem[];
     // workgroups are dispatched in blockIdx order: `order` lists the chunks with the longest chains first (their
     // length is 20 x 2000 x n proposals per candidate k), so that on ragged batches the kernel does not end on a
-    // long chain that started late
+    // long chain that started late.  `order_count`, if given, is the device-side length of the list (the grid is the
+    // upper bound the host knows).
+    if (order_count && blockIdx.x >= uni(*order_count)) return;
     const uint32_t ci = order ? order[blockIdx.x] : blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     ChunkState *st = &state[ci];
     if (st->status != 0) return;
@@ -2489,7 +2518,7 @@ __global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(const ChunkMe
     bool failed = false;
     for (uint32_t k = start; k <= end; k++) {
         double score;
-        if (!run_k_dyn(k, m, n, D, coverage, rng, &score, lane)) {
+        if (!run_k_dyn<LIGHT>(k, m, n, D, coverage, rng, &score, lane)) {
             failed = true;
             break;
         }
@@ -2559,7 +2588,7 @@ __global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(const ChunkMe
     }
     // ---- likelihood gains of the accepted clustering, re-assignment, posterior (:272, :98-105, :342-347)
     double *lg = lg_all + lg_off[ci];  // n x max_k
-    likelihood_gain_dyn(max_k, m, n, D, m.accepted, lg, lane);
+    likelihood_gain_dyn<LIGHT>(max_k, m, n, D, m.accepted, lg, lane);
     __threadfence_block();
     for (uint32_t i = lane; i < n; i += 64) {
         double *lks = lg + (uint64_t)i * max_k;
@@ -2581,6 +2610,52 @@ __global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(const ChunkMe
     if (lane == 0) {
         st->score = max;
         st->k = max_k;
+    }
+}
+
+#define MCMC_KERNEL_PARAMS                                                                                                  \
+    const ChunkMeta *chunks, ChunkState *state, const jtk_lc_params_t *params, const double *feat_all,                      \
+        const uint32_t *vtype_all, const uint64_t *vt_off_all, uint32_t vt_stride_mode, uint32_t *label_all,                \
+        double *post_all, uint32_t post_stride, double *lg_all, const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d,     \
+        uint32_t lds_k, uint32_t jump_in_lds, uint32_t flags, const uint64_t *rng_resume, const uint32_t *order,            \
+        const uint32_t *order_count
+#define MCMC_KERNEL_ARGS                                                                                                    \
+    chunks, state, params, feat_all, vtype_all, vt_off_all, vt_stride_mode, label_all, post_all, post_stride, lg_all,       \
+        lg_off, lds_n, lds_d, lds_k, jump_in_lds, flags, rng_resume, order, order_count
+__global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(MCMC_KERNEL_PARAMS) { mcmc_body<false>(MCMC_KERNEL_ARGS); }
+__global__ __launch_bounds__(128, 3) void mcmc_kernel_light(MCMC_KERNEL_PARAMS) { mcmc_body<true>(MCMC_KERNEL_ARGS); }
+
+// One wave splits a launch's chunk list (order[] or 0 .. count-1) into the chunks the light kernel can run and the rest,
+// keeping the order (longest chain first) in both: out = counts[2] | light[count] | heavy[count].  Chunks with a trivial
+// outcome (no variant column, failed earlier, copy number < 2) go to the light list: they return at once in either kernel.
+__global__ __launch_bounds__(64) void chain_split_kernel(uint32_t count, const uint32_t *order, const ChunkMeta *chunks,
+                                                         const ChunkState *state, uint32_t *out) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t *light = out + 2, *heavy = out + 2 + count;
+    uint32_t nl = 0, nh = 0;
+    for (uint32_t base = 0; base < count; base += 64) {
+        const uint32_t idx = base + lane;
+        const bool valid = idx < count;
+        uint32_t ci = 0;
+        bool is_light = false;
+        if (valid) {
+            ci = order ? order[idx] : idx;
+            const uint32_t n = chunks[ci].n_reads, copy_num = chunks[ci].copy_num, D = state[ci].dim;
+            const bool trivial = state[ci].status != 0 || copy_num < 2 || D == 0 || n <= copy_num;
+            is_light = trivial || (copy_num == 2 && n <= JTK_LIGHT_MAX_READS && D <= JTK_LIGHT_MAX_DIM);
+        }
+        const uint64_t ml = __ballot(valid && is_light), mh = __ballot(valid && !is_light);
+        const uint64_t below = (1ull << lane) - 1ull;
+        if (valid) {
+            if (is_light) light[nl + __popcll(ml & below)] = ci;
+            else heavy[nh + __popcll(mh & below)] = ci;
+        }
+        nl += __popcll(ml);
+        nh += __popcll(mh);
+    }
+    if (lane == 0) {
+        out[0] = nl;
+        out[1] = nh;
     }
 }
 
@@ -2689,18 +2764,41 @@ int mcmc_upload_jump_table(hipStream_t s) {
     return (int)e;
 }
 
+// `split`: 2 + 2 * n_chunks words of device scratch, or null.  With it the launch is two kernels: the light one (168
+// registers, the diploid chunks of <= 63 reads with <= 2 variant columns) and the general one for the rest; without it (or
+// with JTK_MCMC_SPLIT=0) the general kernel runs everything.  `side` (with its two events), if given, is a second stream the
+// general kernel runs on, beside the light one instead of before it.
 int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
                 const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
                 uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
                 const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, const uint64_t *rng_resume,
-                const uint32_t *order) {
+                const uint32_t *order, uint32_t *split, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (n_chunks == 0) return 0;
     lds_k = clamp_k(lds_k);
     const size_t lds = mcmc_lds_bytes(lds_n, lds_d, lds_k);
     if (mcmc_upload_jump_table(s) != 0) return -1;  // the caller fails the call: nothing was launched
     static const uint32_t flags = getenv("JTK_MCMC_LEGACY") ? 1u : 0u;  // differential testing only
-    mcmc_kernel<<<n_chunks, 128, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
-                                          post_stride, lg, lg_off, lds_n, lds_d, lds_k,
-                                          mcmc_jump_in_lds(lds_n, lds_d, lds_k) ? 1u : 0u, flags, rng_resume, order);
+    static const bool no_split = getenv("JTK_MCMC_SPLIT") && atoi(getenv("JTK_MCMC_SPLIT")) == 0;
+    if (!split || no_split || flags || rng_resume) {
+        mcmc_kernel<<<n_chunks, 128, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
+                                              post_stride, lg, lg_off, lds_n, lds_d, lds_k,
+                                              mcmc_jump_in_lds(lds_n, lds_d, lds_k) ? 1u : 0u, flags, rng_resume, order, nullptr);
+        return 0;
+    }
+    chain_split_kernel<<<1, 64, 0, s>>>(n_chunks, order, chunks, state, split);
+    hipStream_t hs = s;
+    if (side && ev_fork && ev_join && hipEventRecord(ev_fork, s) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess)
+        hs = side;
+    mcmc_kernel<<<n_chunks, 128, lds, hs>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post, post_stride,
+                                           lg, lg_off, lds_n, lds_d, lds_k, mcmc_jump_in_lds(lds_n, lds_d, lds_k) ? 1u : 0u, 0u,
+                                           nullptr, split + 2 + n_chunks, split + 1);
+    const uint32_t ln = std::min<uint32_t>(lds_n, JTK_LIGHT_MAX_READS), ld = std::min<uint32_t>(lds_d, JTK_LIGHT_MAX_DIM);
+    mcmc_kernel_light<<<n_chunks, 128, mcmc_lds_bytes(ln, ld, 2), s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode,
+                                                                       label, post, post_stride, lg, lg_off, ln, ld, 2u,
+                                                                       mcmc_jump_in_lds(ln, ld, 2) ? 1u : 0u, 0u, nullptr,
+                                                                       split + 2, split);
+    if (hs != s) {
+        if (hipEventRecord(ev_join, hs) != hipSuccess || hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return -1;
+    }
     return 0;
 }

@@ -217,19 +217,31 @@ __global__ void rethread_kernel(uint32_t n_reads, const ReadMeta *reads, const C
 
 // reads of chunks WITHOUT edits keep their ops: copy them so both buffers stay valid is unnecessary --
 // only chunks with edits flip.
-__global__ void commit_kernel(uint32_t n_chunks, ChunkState *state, const uint32_t *new_len, uint32_t max_rounds,
-                              uint32_t *n_active) {
-    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ci >= n_chunks) return;
-    ChunkState *st = &state[ci];
-    if (st->status != 0 || !st->active) return;
-    if (st->n_edits > 0) {
-        st->buf = JTK_NEXT_BUF(st->buf);
-        st->tmpl_len = new_len[ci];
-        st->n_edits = 0;
+// One workgroup walks all chunks (a few words of state each), so the round's "chunks still active" count is known to one
+// thread when the kernel ends: it goes straight to the host through mapped pinned memory -- no read-back blit, whose
+// 4-byte copy kernel would wait for a wave slot behind the resident waves of the other streams.
+__global__ __launch_bounds__(256) void commit_kernel(uint32_t n_chunks, ChunkState *state, const uint32_t *new_len,
+                                                     uint32_t *n_active, uint32_t *n_active_host) {
+    uint32_t mine = 0;
+    for (uint32_t ci = threadIdx.x; ci < n_chunks; ci += 256) {
+        ChunkState *st = &state[ci];
+        if (st->status != 0 || !st->active) continue;
+        if (st->n_edits > 0) {
+            st->buf = JTK_NEXT_BUF(st->buf);
+            st->tmpl_len = new_len[ci];
+            st->n_edits = 0;
+        }
+        mine++;
     }
-    atomicAdd(n_active, 1u);
-    (void)max_rounds;
+    __shared__ uint32_t s_total;
+    if (threadIdx.x == 0) s_total = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&s_total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *n_active = s_total;
+        if (n_active_host) __hip_atomic_store(n_active_host, s_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // A pass starts from the batch as uploaded: every chunk's state from its pristine copy (buffer set 0, round 0, active) and
@@ -253,9 +265,10 @@ void launch_reset_pass(hipStream_t s, uint32_t n_chunks, ChunkState *state, cons
 void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, const ReadMeta *reads,
                          const ChunkMeta *chunks, ChunkState *state, DevBufs bufs, const uint8_t *ey,
                          const double *table, double *total, Edit *edits, uint32_t *new_len, uint32_t max_tmpl,
-                         uint32_t ignore_edge, int final_pass, uint32_t *n_active_out) {
+                         uint32_t ignore_edge, int final_pass, uint32_t *n_active_out, uint32_t *n_active_host) {
     if (n_chunks == 0) return;
-    // n_active_out is this round's own counter, zeroed by reset_pass_kernel when the pass began (no fill blit here)
+    // n_active_out is this round's own counter (commit_kernel stores it; no fill blit here); n_active_host, if given, is a
+    // device-visible pointer into pinned host memory that receives the same number
     if (!final_pass) {
         const uint32_t cols = JTK_NUM_ROW * (max_tmpl + 1);
         dim3 grid((cols + 255) / 256, n_chunks);
@@ -265,7 +278,6 @@ void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, con
                                                             ignore_edge, final_pass);
     if (!final_pass) {
         rethread_kernel<<<(n_reads + 63) / 64, 64, 0, s>>>(n_reads, reads, chunks, state, bufs, ey, edits);
-        commit_kernel<<<(n_chunks + 63) / 64, 64, 0, s>>>(n_chunks, state, new_len, JTK_POLISH_MAX_ROUNDS,
-                                                          n_active_out);
+        commit_kernel<<<1, 256, 0, s>>>(n_chunks, state, new_len, n_active_out, n_active_host);
     }
 }

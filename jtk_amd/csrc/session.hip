@@ -42,7 +42,7 @@ int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, Chunk
                 const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
                 uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
                 const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, const uint64_t *rng_resume,
-                const uint32_t *order);
+                const uint32_t *order, uint32_t *split, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join);
 
 namespace {
 
@@ -167,7 +167,7 @@ struct ChunkExtra {
 }  // namespace
 
 struct ChainClass {
-    uint32_t first = 0, count = 0, lds_n = 0, lds_d = 0, lds_k = 0;
+    uint32_t first = 0, count = 0, lds_n = 0, lds_d = 0, lds_k = 0, lds_bytes = 0;
 };
 
 struct jtk_lc_session {
@@ -211,10 +211,21 @@ struct jtk_lc_session {
     // host mirrors of the never-reset device ticket counters of the work queues (device_common.h): d_counter[0] phmm_kernel,
     // d_counter[1] phmm_pair_kernel, d_wide_counter[0] phmm_wide_kernel
     uint32_t tk_phmm = 0, tk_pair = 0, tk_wide = 0;
-    uint32_t *h_nactive = nullptr;       // pinned: the per-round "chunks still active" counters as the host reads them back
+    uint32_t *h_nactive = nullptr;       // pinned + mapped: the per-round "chunks still active" counters, written by commit_kernel
+    uint32_t *h_nactive_dev = nullptr;   // the same memory as the device addresses it
     hipEvent_t ev_round[2] = {nullptr, nullptr};
+    // the chain launch: light / general chunk lists made on the device (mcmc_kernels.hip), the general kernel on its own stream
+    DevPtr d_chain_split;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_chain[2] = {nullptr, nullptr};
     ~jtk_lc_session() {
         if (stream) (void)hipStreamSynchronize(stream);  // blocks go back to the pool, not through hipFree's implicit sync
+        if (side) {
+            (void)hipStreamSynchronize(side);
+            (void)hipStreamDestroy(side);
+        }
+        for (auto &e : ev_chain)
+            if (e) (void)hipEventDestroy(e);
         for (auto &t : timers) {
             if (t.a) (void)hipEventDestroy(t.a);
             if (t.b) (void)hipEventDestroy(t.b);
@@ -290,7 +301,7 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
                              const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
                              const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
                              uint32_t post_stride, int device, const ChunkExtra *extra, uint32_t ignore_edge,
-                             jtk_lc_session_t **out) {
+                             jtk_lc_session_t **out, bool polish_only = false) {
     g_last_error.clear();
     if (!params || !out || (n_chunks && (!chunks || !tmpl_bases || !read_bases || !read_off || !ops || !ops_off || !strand)))
         return fail(JTK_ERR_INVALID_ARG, "null argument");
@@ -307,6 +318,7 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
     s->post_stride = post_stride;
     s->n_chunks = (uint32_t)n_chunks;
     s->ignore_edge = ignore_edge;
+    s->polish_only = polish_only;  // no variant search, no chain: none of their limits or workspaces apply
     s->h_copy0.resize(n_chunks);
     HIP_TRY(hipStreamCreate(&s->stream));
 
@@ -483,7 +495,7 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
             *d = std::min<uint32_t>(JTK_MAX_DIM, 3u * std::max<uint32_t>(cm.copy_num, 2u));
         };
         std::vector<uint32_t> cls[2];
-        for (uint32_t c = 0; c < s->h_chunks.size(); c++) {
+        for (uint32_t c = 0; c < s->h_chunks.size() && !polish_only; c++) {
             uint32_t n, d, k;
             dims_of(s->h_chunks[c], &n, &d, &k);
             if (n > JTK_MAX_PILEUP || s->h_chunks[c].copy_num > JTK_MAX_COPY) {
@@ -510,7 +522,10 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
                     cc.lds_d = std::max(cc.lds_d, d);
                     cc.lds_k = std::max(cc.lds_k, k);
                 }
-                if (v.empty() || mcmc_lds_bytes(cc.lds_n, cc.lds_d, cc.lds_k) <= 160 * 1024) break;
+                // class 0 is launched with its members' maxima of (reads, columns, clusters): THAT combination has to stay
+                // below 80 KiB for two workgroups to share a CU, not just every member's own need
+                cc.lds_bytes = v.empty() ? 0 : (uint32_t)mcmc_lds_bytes(cc.lds_n, cc.lds_d, cc.lds_k);
+                if (v.empty() || cc.lds_bytes <= (q == 0 ? 80u : 160u) * 1024u) break;
                 auto worst = std::max_element(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return need(a) < need(b); });
                 if (q == 0) {
                     cls[1].push_back(*worst);  // class 0's maxima can combine beyond one member's need: hand it over
@@ -555,6 +570,11 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
     if ((rc = dev_alloc<uint32_t>(s->d_counter, 4))) return rc;
     HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 4 * sizeof(uint32_t), s->stream));  // once: the ticket counters are never reset
     if ((rc = dev_alloc<uint32_t>(s->d_nactive, JTK_NACTIVE_SLOTS))) return rc;
+    if ((rc = dev_alloc<uint32_t>(s->d_chain_split, 2 * n_chunks + 8))) return rc;
+    HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_chain[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_chain[1], hipEventDisableTiming));
+    if (!polish_only) {  // the filter's and the chain's workspaces
     if ((rc = dev_alloc<uint16_t>(s->d_homop, tmpl_off))) return rc;
     if ((rc = dev_upload(s, s->d_homop_off, h_homop_off))) return rc;
     if ((rc = dev_alloc<double>(s->d_aux, aux_off))) return rc;
@@ -569,6 +589,7 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
     if ((rc = dev_alloc<double>(s->d_post, (uint64_t)n_reads * post_stride))) return rc;
     if ((rc = dev_alloc<double>(s->d_lg, lg_off))) return rc;
     if ((rc = dev_upload(s, s->d_lg_off, h_lg_off))) return rc;
+    }
     if (extra) {
         std::vector<uint64_t> h_rng(4 * n_chunks);
         for (size_t c = 0; c < n_chunks; c++) memcpy(&h_rng[4 * c], extra[c].rng, 32);
@@ -700,7 +721,8 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
     // host looks at round r's counter (a round without active chunks does nothing: every kernel of a round >= 1 skips the
     // chunks that are not active), so a pass costs at most one empty round instead of a host round trip per round.
     if (!s->h_nactive) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_nactive), JTK_NACTIVE_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_nactive), JTK_NACTIVE_SLOTS * sizeof(uint32_t), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->h_nactive_dev), s->h_nactive, 0));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_round[0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_round[1], hipEventDisableTiming));
     }
@@ -730,12 +752,12 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
         launch_polish_round(st, s->n_chunks, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(),
                             s->d_table.as<double>(), s->d_total.as<double>(), s->d_edits.as<Edit>(),
                             s->d_newlen.as<uint32_t>(), s->max_tmpl, s->ignore_edge, final_pass,
-                            s->d_nactive.as<uint32_t>() + round);
+                            s->d_nactive.as<uint32_t>() + round, s->h_nactive_dev + round);
         if (!final_pass)
             launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 1);
         tstop(s);
         if (final_pass) break;
-        HIP_TRY(hipMemcpyAsync(s->h_nactive + round, s->d_nactive.as<uint32_t>() + round, 4, hipMemcpyDeviceToHost, st));
+        // commit_kernel has stored the round's count in h_nactive[round] itself (mapped pinned memory): no read-back copy
         HIP_TRY(hipEventRecord(s->ev_round[round & 1], st));
         if (round >= 1) {
             HIP_TRY(hipEventSynchronize(s->ev_round[(round - 1) & 1]));
@@ -752,12 +774,15 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
     tstop(s);
     tstart(s, JTK_K_MCMC);
     int mcmc_rc = 0;
-    for (const ChainClass &cc : s->chain_class) {
+    for (int j = 0; j < 2; j++) {
+        const ChainClass &cc = s->chain_class[j];
         if (cc.count == 0 || mcmc_rc != 0) continue;
+        // the class's own stretch of the split scratch: 2 + 2 * count words from 2 * first + 4 * j
         mcmc_rc = launch_mcmc(st, cc.count, chunks, state, s->d_params.as<jtk_lc_params_t>(), s->d_feat.as<double>(),
                               s->d_vtype.as<uint32_t>(), nullptr, 0, s->d_label.as<uint32_t>(), s->d_post.as<double>(),
                               s->post_stride, s->d_lg.as<double>(), s->d_lg_off.as<uint64_t>(), cc.lds_n, cc.lds_d, cc.lds_k,
-                              s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr, s->d_order.as<uint32_t>() + cc.first);
+                              s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr, s->d_order.as<uint32_t>() + cc.first,
+                              s->d_chain_split.as<uint32_t>() + 2 * cc.first + 4 * j, s->side, s->ev_chain[0], s->ev_chain[1]);
     }
     tstop(s);
     if (mcmc_rc != 0) {
@@ -771,6 +796,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev0, ev1);
     g_timing.total_ms = ms;
+    for (int j = 0; j < 2; j++) g_timing.chain_lds_bytes[j] = s->chain_class[j].count ? s->chain_class[j].lds_bytes : 0;
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     for (auto &t : s->timers) {
@@ -1364,6 +1390,7 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
         g_timing.h2d_ms += S.timing.h2d_ms;
         g_timing.d2h_ms += S.timing.d2h_ms;
         g_timing.total_ms = std::max(g_timing.total_ms, S.timing.total_ms);   // the slices run side by side
+        for (int j = 0; j < 2; j++) g_timing.chain_lds_bytes[j] = std::max(g_timing.chain_lds_bytes[j], S.timing.chain_lds_bytes[j]);
         for (int k = 0; k < JTK_K_COUNT; k++) {
             g_timing.kernel_ms[k] += S.timing.kernel_ms[k];
             g_timing.kernel_launches[k] += S.timing.kernel_launches[k];
@@ -1383,9 +1410,17 @@ int jtk_lc_cluster_chunks(const jtk_lc_params_t *params, size_t n_chunks, const 
                     log_post, post_stride, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap, &device, 1);
 }
 
-// The same stage call over several GPUs of one node from ONE host process: contiguous, read-balanced shares of the
-// chunks per device, each share sliced and overlapped as on a single device, results written in place.  The path has no
-// exchange step, so there is no collective: this is SURVEY 8(b)'s `device_mask` as an explicit list.
+// The same stage call over several GPUs of one node from ONE host process.  The chunks are dealt to the listed devices by
+// longest-processing-time-first over the cost model of jtk_amd/sharding.py (`chunk_cost`: pair-HMM cells of the polishing
+// passes + Metropolis steps per candidate k), the partition `bench.py --gpus N` uses between ranks: a device's share is in
+// general NOT a contiguous range, so it is gathered into its own flat batch (templates stay where they are: chunks carry
+// offsets), run as on a single device (sliced and overlapped), and its results are scattered back to the caller's order.
+// The path has no exchange step, so there is no collective: this is SURVEY 8(b)'s `device_mask` as an explicit list.
+static double chunk_cost(const jtk_lc_chunk_t &c) {
+    const double n_k = (double)std::max<uint32_t>(1, std::min<uint32_t>(c.copy_num, 7) - (c.copy_num ? 1 : 0));
+    return (double)c.n_reads * (double)c.tmpl_len * 3 * 61 * 2 + 20.0 * 2000.0 * (double)c.n_reads * n_k * 40.0;
+}
+
 int jtk_lc_cluster_chunks_multi(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
                                 const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
                                 const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t *label,
@@ -1393,9 +1428,157 @@ int jtk_lc_cluster_chunks_multi(const jtk_lc_params_t *params, size_t n_chunks, 
                                 uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out, uint64_t *ops_out_off,
                                 uint64_t ops_cap, const int *devices, size_t n_devices) {
     g_last_error.clear();
-    return run_once(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, 0, label,
-                    log_post, post_stride, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap, devices,
-                    n_devices);
+    if (!devices || n_devices == 0) return fail(JTK_ERR_INVALID_ARG, "no device given");
+    if (n_devices == 1 || n_chunks < 2 * n_devices || !params || !chunks || !read_bases || !read_off || !ops || !ops_off ||
+        !strand || !label || !log_post || !result)  // one device, a tiny batch, or arguments the single-device path reports on
+        return run_once(params, n_chunks, chunks, tmpl_bases, read_bases, read_off, ops, ops_off, strand, 0, label,
+                        log_post, post_stride, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap, devices, 1);
+    uint64_t n_reads = 0;
+    for (size_t c = 0; c < n_chunks; c++) {
+        if (chunks[c].read_first != n_reads) return fail(JTK_ERR_INVALID_ARG, "chunks must list their reads contiguously in order");
+        n_reads += chunks[c].n_reads;
+    }
+    // LPT: costliest chunk first (ties: input order), each to the device with the least load so far (ties: first listed)
+    std::vector<size_t> by_cost(n_chunks);
+    std::vector<double> cost(n_chunks);
+    for (size_t c = 0; c < n_chunks; c++) {
+        by_cost[c] = c;
+        cost[c] = chunk_cost(chunks[c]);
+    }
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+    std::vector<double> load(n_devices, 0.0);
+    std::vector<std::vector<size_t>> share(n_devices);
+    for (size_t c : by_cost) {
+        const size_t d = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+        share[d].push_back(c);
+        load[d] += cost[c];
+    }
+    const bool want_cons = cons_out && cons_off, want_ops = ops_out && ops_out_off;
+    struct Share {
+        std::vector<jtk_lc_chunk_t> chunks;
+        std::vector<uint8_t> read_bases, ops, strand, cons, ops_o;
+        std::vector<uint64_t> read_off, ops_off, cons_off, ops_o_off;
+        std::vector<uint32_t> label;
+        std::vector<double> post;
+        std::vector<jtk_lc_result_t> result;
+        int rc = 0;
+        std::string error;
+        jtk_lc_timing_t timing;
+    };
+    std::vector<Share> shares(n_devices);
+    std::vector<std::thread> threads;
+    for (size_t d = 0; d < n_devices; d++) {
+        std::sort(share[d].begin(), share[d].end());  // a device's chunks keep the caller's order
+        threads.emplace_back([&, d]() {
+            Share &S = shares[d];
+            const std::vector<size_t> &ids = share[d];
+            memset(&S.timing, 0, sizeof S.timing);
+            if (ids.empty()) return;
+            uint64_t nr = 0, nb = 0, no = 0, cons_need = 64, ops_need = 64;
+            for (size_t c : ids) {
+                const uint64_t r0 = chunks[c].read_first, r1 = r0 + chunks[c].n_reads;
+                nr += r1 - r0;
+                nb += read_off[r1] - read_off[r0];
+                no += ops_off[r1] - ops_off[r0];
+                cons_need += chunks[c].tmpl_len + chunks[c].tmpl_len / 4 + 64;
+                ops_need += (uint64_t)chunks[c].n_reads * (chunks[c].tmpl_len / 4 + 72);
+            }
+            ops_need += no;
+            S.chunks.reserve(ids.size());
+            S.read_bases.resize(nb ? nb : 1);
+            S.ops.resize(no ? no : 1);
+            S.strand.resize(nr ? nr : 1);
+            S.read_off.resize(nr + 1);
+            S.ops_off.resize(nr + 1);
+            S.label.resize(nr ? nr : 1);
+            S.post.resize(nr ? nr * (size_t)post_stride : 1);
+            S.result.resize(ids.size());
+            if (want_cons) {
+                S.cons.resize(cons_need);
+                S.cons_off.resize(ids.size() + 1);
+            }
+            if (want_ops) {
+                S.ops_o.resize(ops_need);
+                S.ops_o_off.resize(nr + 1);
+            }
+            uint64_t r = 0, b = 0, o = 0;
+            for (size_t c : ids) {
+                jtk_lc_chunk_t ch = chunks[c];
+                const uint64_t r0 = ch.read_first, r1 = r0 + ch.n_reads;
+                ch.read_first = r;
+                S.chunks.push_back(ch);
+                memcpy(S.read_bases.data() + b, read_bases + read_off[r0], read_off[r1] - read_off[r0]);
+                memcpy(S.ops.data() + o, ops + ops_off[r0], ops_off[r1] - ops_off[r0]);
+                memcpy(S.strand.data() + r, strand + r0, r1 - r0);
+                for (uint64_t g = r0; g < r1; g++, r++) {
+                    S.read_off[r] = b + (read_off[g] - read_off[r0]);
+                    S.ops_off[r] = o + (ops_off[g] - ops_off[r0]);
+                }
+                b += read_off[r1] - read_off[r0];
+                o += ops_off[r1] - ops_off[r0];
+            }
+            S.read_off[nr] = b;
+            S.ops_off[nr] = o;
+            S.rc = run_once(params, ids.size(), S.chunks.data(), tmpl_bases, S.read_bases.data(), S.read_off.data(), S.ops.data(),
+                            S.ops_off.data(), S.strand.data(), 0, S.label.data(), S.post.data(), post_stride, S.result.data(),
+                            want_cons ? S.cons.data() : nullptr, want_cons ? S.cons_off.data() : nullptr, S.cons.size(),
+                            want_ops ? S.ops_o.data() : nullptr, want_ops ? S.ops_o_off.data() : nullptr, S.ops_o.size(),
+                            &devices[d], 1);
+            S.error = g_last_error;  // thread-local in the share's thread
+            S.timing = g_timing;
+        });
+    }
+    for (auto &t : threads) t.join();
+    // scatter the shares back into the caller's order
+    int rc = 0;
+    memset(&g_timing, 0, sizeof g_timing);
+    std::vector<uint32_t> dev_of(n_chunks), idx_of(n_chunks);
+    for (size_t d = 0; d < n_devices; d++) {
+        const Share &S = shares[d];
+        if (S.rc != 0 && (rc == 0 || rc == JTK_ERR_CHUNK_FAILED)) {
+            rc = S.rc;
+            g_last_error = S.error;
+        }
+        g_timing.h2d_ms += S.timing.h2d_ms;
+        g_timing.d2h_ms += S.timing.d2h_ms;
+        g_timing.total_ms = std::max(g_timing.total_ms, S.timing.total_ms);  // the devices run side by side
+        for (int j = 0; j < 2; j++) g_timing.chain_lds_bytes[j] = std::max(g_timing.chain_lds_bytes[j], S.timing.chain_lds_bytes[j]);
+        for (int k = 0; k < JTK_K_COUNT; k++) {
+            g_timing.kernel_ms[k] += S.timing.kernel_ms[k];
+            g_timing.kernel_launches[k] += S.timing.kernel_launches[k];
+        }
+        for (size_t i = 0; i < share[d].size(); i++) {
+            dev_of[share[d][i]] = (uint32_t)d;
+            idx_of[share[d][i]] = (uint32_t)i;
+        }
+    }
+    if (rc != 0 && rc != JTK_ERR_CHUNK_FAILED) return rc;
+    uint64_t co = 0, oo = 0;
+    for (size_t c = 0; c < n_chunks; c++) {
+        const Share &S = shares[dev_of[c]];
+        const size_t i = idx_of[c];
+        const uint64_t r0 = chunks[c].read_first, nr = chunks[c].n_reads, g0 = S.chunks[i].read_first;
+        result[c] = S.result[i];
+        memcpy(label + r0, S.label.data() + g0, nr * sizeof(uint32_t));
+        memcpy(log_post + r0 * post_stride, S.post.data() + g0 * post_stride, nr * post_stride * sizeof(double));
+        if (want_cons) {
+            const uint64_t a = S.cons_off[i], len = S.cons_off[i + 1] - a;
+            if (co + len > cons_cap) return fail(JTK_ERR_INVALID_ARG, "cons_cap too small");
+            memcpy(cons_out + co, S.cons.data() + a, len);
+            cons_off[c] = co;
+            co += len;
+        }
+        if (want_ops) {
+            const uint64_t a = S.ops_o_off[g0], len = S.ops_o_off[g0 + nr] - a;
+            if (oo + len > ops_cap) return fail(JTK_ERR_INVALID_ARG, "ops_cap too small");
+            memcpy(ops_out + oo, S.ops_o.data() + a, len);
+            for (uint64_t g = 0; g < nr; g++) ops_out_off[r0 + g] = oo + (S.ops_o_off[g0 + g] - a);
+            oo += len;
+        }
+    }
+    if (want_cons) cons_off[n_chunks] = co;
+    if (want_ops) ops_out_off[n_reads] = oo;
+    return rc;
 }
 
 int jtk_lc_cluster_polished(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
@@ -1432,10 +1615,9 @@ int jtk_lc_polish_chunks(const jtk_lc_params_t *params, size_t n_chunks, const j
     if (pp.gains.max_homopolymer_len == 0) pp.gains.max_homopolymer_len = 1;  // polishing does not use the gains
     jtk_lc_session_t *s = nullptr;
     int rc = session_create_ex(&pp, n_chunks, ch.data(), tmpl_bases, read_bases, read_off, ops, ops_off, strand, 1, device,
-                               extra.data(), ignore_edge, &s);
+                               extra.data(), ignore_edge, &s, true);
     if (rc) return rc;
     std::unique_ptr<jtk_lc_session> guard(s);
-    s->polish_only = true;
     s->resume_rng = false;
     if ((rc = run_batch(s, 0))) return rc;
     return jtk_lc_session_fetch(s, nullptr, nullptr, result, cons_out, cons_off, cons_cap, ops_out, ops_out_off, ops_cap);
@@ -1516,10 +1698,9 @@ int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_l
         }
         jtk_lc_session_t *s = nullptr;
         int rc = session_create_ex(&cur, n_chunks, ch.data(), cons.data(), read_bases, read_off, cops.data(), ooff.data(), strand,
-                                   1, device, extra.data(), 0 /* ignore_edge, model_tune.rs:140 */, &s);
+                                   1, device, extra.data(), 0 /* ignore_edge, model_tune.rs:140 */, &s, true);
         if (rc) return rc;
         std::unique_ptr<jtk_lc_session> guard(s);
-        s->polish_only = true;
         s->resume_rng = false;
         if ((rc = run_batch(s, 0))) return rc;
         rc = jtk_lc_session_fetch(s, nullptr, nullptr, res.data(), cons2.data(), coff2.data(), cons2.size(), cops2.data(),
@@ -1734,10 +1915,12 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
     HIP_TRY(hipEventRecord(ev0, s->stream));
+    DevPtr d_split;  // light / general chunk lists of the chain launch
+    if ((rc = dev_alloc<uint32_t>(d_split, 2 * n_chunks + 8))) return rc;
     if (launch_mcmc(s->stream, (uint32_t)n_chunks, d_chunks.as<ChunkMeta>(), d_state.as<ChunkState>(),
                     d_params.as<jtk_lc_params_t>(), d_var.as<double>(), d_vt.as<uint32_t>(), d_vtoff.as<uint64_t>(), 1,
                     d_label.as<uint32_t>(), d_post.as<double>(), post_stride, d_lg.as<double>(), d_lgoff.as<uint64_t>(),
-                    max_n, max_d, max_k, nullptr, nullptr) != 0)
+                    max_n, max_d, max_k, nullptr, nullptr, d_split.as<uint32_t>(), nullptr, nullptr, nullptr) != 0)
         return fail(JTK_ERR_INTERNAL, "the chain kernel could not be launched (jump table upload failed)");
     HIP_TRY(hipEventRecord(ev1, s->stream));
     HIP_TRY(hipMemcpyAsync(sts.data(), d_state.p, sts.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, s->stream));

@@ -59,7 +59,8 @@ class SynthCfg(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
-                ("kernel_ms", C.c_double * K_COUNT), ("kernel_launches", C.c_uint32 * K_COUNT)]
+                ("kernel_ms", C.c_double * K_COUNT), ("kernel_launches", C.c_uint32 * K_COUNT),
+                ("chain_lds_bytes", C.c_uint32 * 2)]
 
 
 CHUNK_DT = np.dtype([("chunk_id", "<u8"), ("copy_num", "<u4"), ("n_reads", "<u4"), ("tmpl_off", "<u8"),

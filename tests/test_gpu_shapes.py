@@ -221,6 +221,21 @@ def test_window_polishing_matches_oracle(lib, radius, take_num, ignore_edge):
         assert full["rc"] == 0
 
 
+def test_deep_window_polishes_beyond_the_chain_limit(lib):
+    """consensus::polish_seg windows can be deeper than any pile-up the chain kernel takes (JTK_MAX_PILEUP = 1,023 reads):
+    a polish-only call has no chain and no such limit -- 1,100 reads on a 180-bp window, 30 of them voting"""
+    b, cfg, p = helpers.small_batch(config="ont_noisy", n_chunks=1, tmpl_len=180, reads_per_hap=550, first=77, tmpl_err=1e-2)
+    assert int(b.chunks["n_reads"][0]) == 1100
+    dev = api.polish_chunks(p, b, radius=20, take_num=30, ignore_edge=0)
+    ora = O.polish_chunks(helpers.oracle_params(p), b, radius=20, take_num=30, ignore_edge=0)
+    assert ora["rc"] == 0 and dev["rc"] == 0 and int(dev["result"]["status"][0]) == 0
+    assert np.array_equal(dev["result"]["polish_rounds"], ora["result"]["polish_rounds"])
+    n = int(dev["cons_off"][-1])
+    assert np.array_equal(dev["cons_off"], ora["cons_off"]) and bytes(dev["cons"][:n]) == bytes(ora["cons"][:n])
+    m = int(dev["ops_out_off"][-1])
+    assert np.array_equal(dev["ops_out_off"], ora["ops_out_off"]) and np.array_equal(dev["ops_out"][:m], ora["ops_out"][:m])
+
+
 # ---- bands wider than one wavefront (phmm_wide_kernel): CLR / None reads, ONT chunks longer than 2,033 bp
 
 @pytest.mark.parametrize("tmpl_len,band_frac,radius", [(600, 0.11, 33), (2000, 0.05, 50), (2100, 0.03, 31), (1000, 0.254, 127)])
@@ -295,12 +310,24 @@ def test_model_refit_matches_oracle(lib, config, rounds):
 
 
 def test_multi_device_call_matches_single_device(lib):
-    """jtk_lc_cluster_chunks_multi: shares of the chunks per listed device, results in place.  One GPU here, listed twice and
-    three times: the partition, the per-share slicing and the stitching of the variable-length outputs are what is tested."""
+    """jtk_lc_cluster_chunks_multi: LPT shares of the chunks per listed device, gathered, run, scattered back.  One GPU here,
+    listed twice and three times: the partition, the gather / scatter and the stitching of the variable-length outputs are
+    what is tested."""
     b, cfg, p = helpers.small_batch(n_chunks=7, tmpl_len=300, reads_per_hap=6)
     one = api.cluster_chunks(p, b)
     for devices in ([0, 0], [0, 0, 0], [0]):
         many = api.cluster_chunks(p, b, devices=devices)
+        for k in ("label", "log_post", "result", "cons_off", "ops_out_off"):
+            assert np.array_equal(one[k], many[k]), (devices, k)
+        assert np.array_equal(one["cons"][:int(one["cons_off"][-1])], many["cons"][:int(many["cons_off"][-1])])
+        assert np.array_equal(one["ops_out"][:int(one["ops_out_off"][-1])], many["ops_out"][:int(many["ops_out_off"][-1])])
+    # a ragged batch: the cost-ordered deal (longest processing time first) gives every device a non-contiguous share
+    shapes = ((300, 4), (420, 9), (260, 6), (380, 5), (300, 11), (340, 7), (280, 4))
+    rb = jb.pack([synth.make_pileup(5000 + i, dict(synth.CONFIGS["ont_diploid"], tmpl_len=L, reads_per_hap=r))
+                  for i, (L, r) in enumerate(shapes)])
+    one = api.cluster_chunks(p, rb)
+    for devices in ([0, 0], [0, 0, 0]):
+        many = api.cluster_chunks(p, rb, devices=devices)
         for k in ("label", "log_post", "result", "cons_off", "ops_out_off"):
             assert np.array_equal(one[k], many[k]), (devices, k)
         assert np.array_equal(one["cons"][:int(one["cons_off"][-1])], many["cons"][:int(many["cons_off"][-1])])
