@@ -147,6 +147,11 @@ def stage_e2e(params0, batch, cfg, device, record_path=None):
     out = api.cluster_chunks(p, batch, device=device)
     tm = api.last_timing()
     ph["cluster_chunks_ms"] = (time.perf_counter() - t2) * 1e3
+    ph["cluster_chunks_detail"] = dict(kernel_ms_summed_over_slices={k: round(v, 1) for k, v in tm["kernel_ms"].items()},
+                                       h2d_ms=round(tm["h2d_ms"], 1), d2h_ms=round(tm["d2h_ms"], 1),
+                                       mean_polish_rounds=float(out["result"]["polish_rounds"].mean()),
+                                       mean_n_variants=float(out["result"]["n_variants"].mean()),
+                                       mean_cluster_num=float(out["result"]["cluster_num"].mean()))
     t3 = time.perf_counter()
     for c in range(batch.n_chunks):
         rr = batch.chunk_reads(c)
@@ -292,12 +297,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- a shard whose WORKSPACES do not fit the device beside each other (cfg 4: 2,500 x 160 reads x 555 KB of row sums and
-    #      tables = 220 GB) cannot be held as resident sessions: its step is the library's one-shot call, which streams slices
+    # ---- a shard whose WORKSPACES do not fit the device beside each other (cfg 4: 2,500 x 160 reads x 296 KB of row sums /
+    #      tables + scratch) cannot be held as resident sessions: its step is the library's one-shot call, which streams slices
     #      through a bounded workspace (session.hip run_once).  Inputs then cross PCIe inside the step (~1 GB: noise next to the
     #      step), and the line says so.
     cap_len = int(cfg["tmpl_len"]) + int(cfg["tmpl_len"]) // 8 + 64
-    est_bytes = float(batch.n_reads) * (cap_len + 1) * 256.0 + args.streams * 14e9
+    est_bytes = float(batch.n_reads) * (cap_len + 1) * 144.0 + args.streams * 14e9   # 16 f64 + ops / deltas per row; scratch
     total_mem = float(torch.cuda.get_device_properties(local_rank).total_memory)
     if est_bytes > 0.80 * total_mem:
         def one_step():

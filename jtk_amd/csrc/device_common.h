@@ -36,8 +36,8 @@ struct ReadMeta {
     uint32_t ops_cap;
     uint32_t strand;     // 1 = forward model
     uint64_t delta_off;  // into d_delta (u64 words)
-    uint64_t table_off;  // into d_table (doubles): JTK_NUM_ROW * (tmpl_cap + 1) per read
-    uint64_t raw_off;    // into d_raw (doubles): JTK_ACC_N * (tmpl_cap + 1) per read
+    uint64_t table_off;  // the read's table, JTK_NUM_ROW doubles per position: == raw_off (finalize_kernel works in place)
+    uint64_t raw_off;    // into d_raw (doubles): JTK_ACC_N * (tmpl_cap + 1) per read; row sums, then the table
     uint64_t row_off;    // into d_rawG (ints): tmpl_cap + 1 per read
 };
 
@@ -115,8 +115,8 @@ void launch_phmm_pair(hipStream_t s, uint32_t n_items, const uint32_t *items, co
                       double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
                       double *raw, int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active);
 void launch_finalize(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
-                     const ChunkState *state, const HmmDev *hmm2, const double *raw, const int *rawG,
-                     const double *lk, double *table, uint32_t max_tmpl, int only_active);
+                     const ChunkState *state, const HmmDev *hmm2, double *raw, const int *rawG, const double *lk,
+                     uint32_t max_tmpl, int only_active);  // in place: a read's table takes the place of its row sums
 // phmm_wide.hip: the reads of chunks whose band radius exceeds JTK_MAX_RADIUS (phmm_kernel skips them)
 size_t phmm_wide_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
 uint64_t phmm_wide_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius);

@@ -548,26 +548,30 @@ __global__ __launch_bounds__(64, JTK_PHMM_WAVES) __attribute__((amdgpu_num_vgpr(
 #endif  // JTK_PHMM_WITH_R2
 
 // ------------------------------------------------------------------------------------------------------
-// finalize: one thread per (read, position p): the 14 table entries of p from the raw row sums,
-// MINUS the read's lk (pseudo_mcmc.rs:64).  Row iota owns sub[iota-1], ins[iota], copy_c[iota-1],
-// del_d[iota-d-1].
+// finalize: the 14 table entries of every position p of a read from its raw row sums, MINUS the read's lk
+// (pseudo_mcmc.rs:64).  Row iota owns sub[iota-1], ins[iota], copy_c[iota-1], del_d[iota-d-1].
+//
+// IN PLACE: the table of a read (14 doubles per position) takes the place of its row sums (16 per position, the same
+// region of HBM): position p reads rows p .. p+4 and its 14 entries land in [14p, 14p+14) -- inside rows <= p, which no later
+// position reads.  One workgroup walks a read's tiles of 128 positions in order (a tile's rows are staged in LDS before
+// anything of the tile is written, and its writes end below the first row of the next tile), so the per-read table costs no
+// memory of its own: 9.7 GB less per 625-chunk slice of the headline workload.
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double fin_log(double v, int G, double lk) {
     return (v > 0.0 ? jtk_log(v) + (double)G * JTK_LN2 : JTK_LOG_ZERO) - lk;
 }
 
-#define FIN_TILE 128                   // positions per workgroup
+#define FIN_TILE 128                   // positions per tile
 #define FIN_ROWS (FIN_TILE + 4)        // raw rows a tile reads: p .. p+4 for its last position
 #define FIN_PITCH (JTK_ACC_N + 1)      // doubles per staged row: 17 keeps the 128-byte rows off each other's LDS banks
 __global__ __launch_bounds__(FIN_TILE) void finalize_kernel(uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
-                                                           const ChunkState *state, const HmmDev *hmm2, const double *raw_all,
-                                                           const int *rawG_all, const double *lk_all, double *table_all,
-                                                           int only_active) {
-    // The tile's raw rows come in through LDS with coalesced 16-byte loads and its 14 x 128 table entries leave the same way:
+                                                           const ChunkState *state, const HmmDev *hmm2, double *raw_all,
+                                                           const int *rawG_all, const double *lk_all, int only_active) {
+    // A tile's raw rows come in through LDS with coalesced 16-byte loads and its 14 x 128 table entries leave the same way:
     // a thread's own rows (128 B apart) and its 112 bytes of output would otherwise be 16-byte pieces of different lines.
     __shared__ __align__(16) double s_raw[FIN_ROWS * FIN_PITCH];
     __shared__ int s_G[FIN_ROWS];
-    const uint32_t item = blockIdx.y;
+    const uint32_t item = blockIdx.x;
     const ReadMeta rm = reads[item];
     const ChunkState st = state[rm.chunk];
     if (st.status != 0) return;
@@ -577,77 +581,82 @@ __global__ __launch_bounds__(FIN_TILE) void finalize_kernel(uint32_t n_reads, co
         if (cm.take_num && item - cm.read_first >= cm.take_num) return;
     }
     const int L = (int)st.tmpl_len;
-    const int p0 = blockIdx.x * FIN_TILE;
-    if (p0 > L) return;
-    const int tid = threadIdx.x, p = p0 + tid;
+    const int tid = threadIdx.x;
     const HmmDev *h = hmm2 + (rm.strand ? 0 : 1);
-    const double *raw = raw_all + rm.raw_off;
+    double *raw = raw_all + rm.raw_off;  // == the read's table (ReadMeta.table_off == raw_off)
     const int *rawG = rawG_all + rm.row_off;
     const double lk = lk_all[item];
     const bool dead = !(lk > JTK_LOG_ZERO);
-    const int n_rows = min(FIN_ROWS, L + 1 - p0);  // rows p0 .. min(p0 + FIN_ROWS - 1, L)
-    if (!dead) {
-        const double2 *src = reinterpret_cast<const double2 *>(raw + (uint64_t)p0 * JTK_ACC_N);
-        for (int e = tid; e < n_rows * (JTK_ACC_N / 2); e += FIN_TILE) {
-            const double2 v = src[e];
-            const int row = e / (JTK_ACC_N / 2), k = e % (JTK_ACC_N / 2);
-            s_raw[row * FIN_PITCH + 2 * k] = v.x;
-            s_raw[row * FIN_PITCH + 2 * k + 1] = v.y;
+    double eM[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) eM[k] = h->eM[k];
+    for (int p0 = 0; p0 <= L; p0 += FIN_TILE) {
+        const int p = p0 + tid;
+        const int n_rows = min(FIN_ROWS, L + 1 - p0);  // rows p0 .. min(p0 + FIN_ROWS - 1, L)
+        if (!dead) {
+            const double2 *src = reinterpret_cast<const double2 *>(raw + (uint64_t)p0 * JTK_ACC_N);
+            for (int e = tid; e < n_rows * (JTK_ACC_N / 2); e += FIN_TILE) {
+                const double2 v = src[e];
+                const int row = e / (JTK_ACC_N / 2), k = e % (JTK_ACC_N / 2);
+                s_raw[row * FIN_PITCH + 2 * k] = v.x;
+                s_raw[row * FIN_PITCH + 2 * k + 1] = v.y;
+            }
+            for (int e = tid; e < n_rows; e += FIN_TILE) s_G[e] = rawG[p0 + e];
         }
-        for (int e = tid; e < n_rows; e += FIN_TILE) s_G[e] = rawG[p0 + e];
-    }
-    __syncthreads();
-    double res[JTK_NUM_ROW];
+        __syncthreads();
+        double res[JTK_NUM_ROW];
 #pragma unroll
-    for (int k = 0; k < JTK_NUM_ROW; k++) res[k] = JTK_LOG_ZERO - (dead ? 0.0 : lk);
-    if (!dead && p <= L) {
-        if (p + 1 <= L) {  // row p+1: sub[p], copy_c[p]
-            const double *a = s_raw + (tid + 1) * FIN_PITCH;
-            const int G = s_G[tid + 1];
+        for (int k = 0; k < JTK_NUM_ROW; k++) res[k] = JTK_LOG_ZERO - (dead ? 0.0 : lk);
+        if (!dead && p <= L) {
+            if (p + 1 <= L) {  // row p+1: sub[p], copy_c[p]
+                const double *a = s_raw + (tid + 1) * FIN_PITCH;
+                const int G = s_G[tid + 1];
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                double v = h->eM[4 * b + 0] * a[0];
-                v = fma(h->eM[4 * b + 1], a[1], v);
-                v = fma(h->eM[4 * b + 2], a[2], v);
-                v = fma(h->eM[4 * b + 3], a[3], v);
-                v = v + a[4];
-                res[b] = fin_log(v, G, lk);
+                for (int b = 0; b < 4; b++) {
+                    double v = eM[4 * b + 0] * a[0];
+                    v = fma(eM[4 * b + 1], a[1], v);
+                    v = fma(eM[4 * b + 2], a[2], v);
+                    v = fma(eM[4 * b + 3], a[3], v);
+                    v = v + a[4];
+                    res[b] = fin_log(v, G, lk);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) res[8 + cc] = fin_log(a[10 + cc], G, lk);
+            }
+            {  // row p: ins[p]
+                const double *a = s_raw + tid * FIN_PITCH;
+                const int G = s_G[tid];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    double v = eM[4 * b + 0] * a[5];
+                    v = fma(eM[4 * b + 1], a[6], v);
+                    v = fma(eM[4 * b + 2], a[7], v);
+                    v = fma(eM[4 * b + 3], a[8], v);
+                    v = v + a[9];
+                    res[4 + b] = fin_log(v, G, lk);
+                }
             }
 #pragma unroll
-            for (int cc = 0; cc < 3; cc++) res[8 + cc] = fin_log(a[10 + cc], G, lk);
-        }
-        {  // row p: ins[p]
-            const double *a = s_raw + tid * FIN_PITCH;
-            const int G = s_G[tid];
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                double v = h->eM[4 * b + 0] * a[5];
-                v = fma(h->eM[4 * b + 1], a[6], v);
-                v = fma(h->eM[4 * b + 2], a[7], v);
-                v = fma(h->eM[4 * b + 3], a[8], v);
-                v = v + a[9];
-                res[4 + b] = fin_log(v, G, lk);
+            for (int dd = 1; dd <= 3; dd++) {  // row p+d+1: del_d[p]
+                if (p + dd + 1 <= L) {
+                    const double *a = s_raw + (tid + dd + 1) * FIN_PITCH;
+                    res[11 + dd - 1] = fin_log(a[13 + dd - 1], s_G[tid + dd + 1], lk);
+                }
             }
         }
+        __syncthreads();  // the staged rows are not needed any more: the tile's table entries take their place
+        double *s_out = s_raw;  // FIN_TILE x 14 doubles <= FIN_ROWS x 17
+        if (p <= L) {
 #pragma unroll
-        for (int dd = 1; dd <= 3; dd++) {  // row p+d+1: del_d[p]
-            if (p + dd + 1 <= L) {
-                const double *a = s_raw + (tid + dd + 1) * FIN_PITCH;
-                res[11 + dd - 1] = fin_log(a[13 + dd - 1], s_G[tid + dd + 1], lk);
-            }
+            for (int k = 0; k < JTK_NUM_ROW; k++) s_out[tid * JTK_NUM_ROW + k] = res[k];
         }
+        __syncthreads();
+        const int n_pos = min(FIN_TILE, L + 1 - p0);
+        double2 *dst = reinterpret_cast<double2 *>(raw + (uint64_t)p0 * JTK_NUM_ROW);
+        const double2 *so = reinterpret_cast<const double2 *>(s_out);
+        for (int e = tid; e < n_pos * (JTK_NUM_ROW / 2); e += FIN_TILE) dst[e] = so[e];
+        __syncthreads();  // before the next tile is staged over s_out
     }
-    __syncthreads();  // the staged rows are not needed any more: the tile's table entries take their place
-    double *s_out = s_raw;  // FIN_TILE x 14 doubles <= FIN_ROWS x 17
-    if (p <= L) {
-#pragma unroll
-        for (int k = 0; k < JTK_NUM_ROW; k++) s_out[tid * JTK_NUM_ROW + k] = res[k];
-    }
-    __syncthreads();
-    const int n_pos = min(FIN_TILE, L + 1 - p0);
-    double2 *dst = reinterpret_cast<double2 *>(table_all + rm.table_off + (uint64_t)p0 * JTK_NUM_ROW);
-    const double2 *so = reinterpret_cast<const double2 *>(s_out);
-    for (int e = tid; e < n_pos * (JTK_NUM_ROW / 2); e += FIN_TILE) dst[e] = so[e];
 }
 
 }  // namespace
@@ -679,9 +688,9 @@ void launch_phmm_r2(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, cons
 #endif
 
 void launch_finalize(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
-                     const ChunkState *state, const HmmDev *hmm2, const double *raw, const int *rawG,
-                     const double *lk, double *table, uint32_t max_tmpl, int only_active) {
+                     const ChunkState *state, const HmmDev *hmm2, double *raw, const int *rawG, const double *lk,
+                     uint32_t max_tmpl, int only_active) {
     if (n_reads == 0) return;
-    dim3 grid((max_tmpl + 1 + FIN_TILE - 1) / FIN_TILE, n_reads);
-    finalize_kernel<<<grid, FIN_TILE, 0, s>>>(n_reads, reads, chunks, state, hmm2, raw, rawG, lk, table, only_active);
+    (void)max_tmpl;
+    finalize_kernel<<<n_reads, FIN_TILE, 0, s>>>(n_reads, reads, chunks, state, hmm2, raw, rawG, lk, only_active);
 }

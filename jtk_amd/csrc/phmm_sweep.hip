@@ -15,8 +15,10 @@
 //    row index, emission row and the lane's read-byte window are registers updated by ONE lane when a row leaves the band;
 //  * the read's emission bytes of a group's 8 diagonals are two dwords per lane (3 aligned LDS dwords + v_alignbyte);
 //  * band deltas, scaling exponents and the del-3 thresholds are scalar (one LDS byte pair per group);
-//  * row sums of a row that left the band stay in the (now idle) lane and are flushed once per group for all lanes that left;
-//  * the first / last ~2r diagonals of a sweep, and any group with more than 4 band moves, take a generic step (per-lane
+//  * row sums of a row that left the band stay in the (now idle) lane and are flushed once per HALF group (4 diagonals) for
+//    all lanes that left: a lane that leaves the band re-enters it with its next row at the third later band move, so a half
+//    group may hold at most 3 band moves (its read-byte window and its staged rows are per half group for the same reason);
+//  * the first / last ~2r diagonals of a sweep, and any group with a half of 4 band moves, take a generic step (per-lane
 //    predicates, as the round-2 kernel did everywhere);
 //  * forward still streams the pair P_s = (toM of diagonal s-1, toD of diagonal s) per diagonal to an HBM stripe (1 KiB per
 //    diagonal), backward reads it back through a register queue into an 8-slot LDS ring (no wrapped copies: seven address

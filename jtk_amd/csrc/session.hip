@@ -187,7 +187,7 @@ struct jtk_lc_session {
     std::vector<uint64_t> h_in_tmpl_off;
     // device memory
     DevPtr d_params, d_hmm2, d_chunks, d_reads, d_state, d_tmpl0, d_tmpl1, d_ops0, d_ops1, d_opslen0, d_opslen1,
-        d_ey, d_delta, d_scratch, d_raw, d_rawG, d_lk, d_table, d_total, d_edits, d_newlen, d_counter, d_nactive,
+        d_ey, d_delta, d_scratch, d_raw, d_rawG, d_lk, d_total, d_edits, d_newlen, d_counter, d_nactive,
         d_homop, d_homop_off, d_aux, d_aux_off, d_cand, d_list, d_sel, d_feat, d_vtype, d_pos, d_label, d_post,
         d_lg, d_lg_off, d_vt_off, d_tmpl_init, d_ops_init, d_opslen_init, d_order;
     size_t tmpl_bytes = 0, ops_bytes = 0;
@@ -394,7 +394,7 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
             rm.ops_cap = ((uint32_t)ol + tl / 8 + 64 + 7u) & ~7u;  // slots stay 8-byte aligned: the walkers fetch 8 ops at a time
             rm.strand = strand[g] ? 1 : 0;
             rm.delta_off = delta_off;
-            rm.table_off = table_off;
+            rm.table_off = raw_off;  // finalize_kernel turns the row sums into the table in place
             rm.raw_off = raw_off;
             rm.row_off = row_off;
             h_opslen[g] = (uint32_t)ol;
@@ -563,7 +563,7 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
     if ((rc = dev_alloc<double>(s->d_raw, raw_off))) return rc;
     if ((rc = dev_alloc<int>(s->d_rawG, row_off))) return rc;
     if ((rc = dev_alloc<double>(s->d_lk, n_reads))) return rc;
-    if ((rc = dev_alloc<double>(s->d_table, table_off))) return rc;
+    (void)table_off;  // no buffer of its own: the tables live where the row sums were (d_raw)
     if ((rc = dev_alloc<double>(s->d_total, total_off))) return rc;
     if ((rc = dev_alloc<Edit>(s->d_edits, edit_off))) return rc;
     if ((rc = dev_alloc<uint32_t>(s->d_newlen, n_chunks))) return rc;
@@ -746,11 +746,11 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                              s->d_wide_counter.as<uint32_t>(), &s->tk_wide, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                              s->d_lk.as<double>(), s->max_tmpl, s->max_read, only_active);
         launch_finalize(st, s->n_reads, reads, chunks, state, hmm2, s->d_raw.as<double>(), s->d_rawG.as<int>(),
-                        s->d_lk.as<double>(), s->d_table.as<double>(), s->max_tmpl, only_active);
+                        s->d_lk.as<double>(), s->max_tmpl, only_active);
         tstop(s);
         tstart(s, JTK_K_POLISH);
         launch_polish_round(st, s->n_chunks, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(),
-                            s->d_table.as<double>(), s->d_total.as<double>(), s->d_edits.as<Edit>(),
+                            s->d_raw.as<double>(), s->d_total.as<double>(), s->d_edits.as<Edit>(),
                             s->d_newlen.as<uint32_t>(), s->max_tmpl, s->ignore_edge, final_pass,
                             s->d_nactive.as<uint32_t>() + round, s->h_nactive_dev + round);
         if (!final_pass)
@@ -767,7 +767,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
     if (!s->polish_only) {
     tstart(s, JTK_K_FILTER);
     launch_filter(st, s->n_chunks, reads, chunks, state, s->bufs, s->d_params.as<jtk_lc_params_t>(),
-                  s->d_table.as<double>(), s->d_homop.as<uint16_t>(), s->d_homop_off.as<uint64_t>(),
+                  s->d_raw.as<double>(), s->d_homop.as<uint16_t>(), s->d_homop_off.as<uint64_t>(),
                   s->d_aux.as<double>(), s->d_aux_off.as<uint64_t>(), s->d_cand.as<double>(), s->d_list.as<uint32_t>(),
                   s->d_sel.as<uint8_t>(), s->d_feat.as<double>(), s->d_vtype.as<uint32_t>(), s->d_pos.as<uint32_t>(),
                   s->max_tmpl);
@@ -1260,7 +1260,7 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
         uint64_t est = 0, max_len = 0, max_rd = 0;
         for (size_t c = 0; c < n_chunks; c++) {
             const uint64_t cap = chunks[c].tmpl_len + chunks[c].tmpl_len / 8 + 64;
-            est += (uint64_t)chunks[c].n_reads * (cap + 1) * ((JTK_ACC_N + JTK_NUM_ROW) * 8 + 16);  // raw + table + ops / deltas
+            est += (uint64_t)chunks[c].n_reads * (cap + 1) * (JTK_ACC_N * 8 + 16);  // row sums / tables + ops / deltas
             max_len = std::max<uint64_t>(max_len, cap);
             if (read_off) {
                 const uint64_t r0 = chunks[c].read_first, r1 = r0 + chunks[c].n_reads;
@@ -1792,14 +1792,13 @@ int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl
                          s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves, s->d_wide_counter.as<uint32_t>(), &s->tk_wide,
                          s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
     launch_finalize(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state,
-                    s->d_hmm2.as<HmmDev>(), s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(),
-                    s->d_table.as<double>(), s->max_tmpl, 0);
+                    s->d_hmm2.as<HmmDev>(), s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, 0);
     ChunkState cs;
     HIP_TRY(hipMemcpyAsync(&cs, state, sizeof cs, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(lk, s->d_lk.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, st));
     const size_t cols = (size_t)JTK_NUM_ROW * (tmpl_len + 1);
     for (uint32_t r = 0; r < n_reads; r++)
-        HIP_TRY(hipMemcpyAsync(table + (size_t)r * cols, s->d_table.as<double>() + s->h_reads[r].table_off, cols * 8,
+        HIP_TRY(hipMemcpyAsync(table + (size_t)r * cols, s->d_raw.as<double>() + s->h_reads[r].table_off, cols * 8,
                                hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
