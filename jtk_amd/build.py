@@ -61,6 +61,29 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def build_experiment(name, extra_flags):
+    """A diagnostic build (statistics counters, kernel variants) of the library beside the product: objects and
+    libjtk_lc_<name>.so under _build/exp_<name>/, every source compiled with `extra_flags` added.  The product library is not
+    touched; scripts point JTK_LC_LIB (jtk_amd/ffi.py) at the returned path."""
+    out_dir = os.path.join(OUT_DIR, "exp_" + name)
+    os.makedirs(out_dir, exist_ok=True)
+    extra = extra_flags.split() if isinstance(extra_flags, str) else list(extra_flags)
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(out_dir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError("hipcc failed on " + src)
+    lib = os.path.join(out_dir, "libjtk_lc_%s.so" % name)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 PROFILED_SOURCES = ["phmm_kernels.hip", "phmm_sweep.hip", "phmm_pair.hip", "phmm_wide.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip",
                     "session.hip", "device_common.h"]
 

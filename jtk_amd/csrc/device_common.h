@@ -102,9 +102,46 @@ void launch_band_prep(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, co
 // Work queues: `work_counter` is a device ticket counter that is never reset (no fill blit in front of a launch).  A wave
 // takes tickets until one is past the launch's last item, so a launch advances the counter by exactly n_items + n_waves;
 // `ticket_base` (host, owned by the session) is the counter's value when the launch starts and is advanced by the launcher.
+// The forward scratch of the lane-ring pair-HMM kernels: stripes of (template + read + guard) x 1 KiB, one per RESIDENT wave.
+// The set is shared by every session of a device (session.hip: StripePool): however many batches are in flight, no more
+// waves than the device holds are ever inside a sweep, so a wave takes a free stripe when it starts and gives it back when it
+// ends (owner[]: 0 = free).  Release / acquire at agent scope on the hand-over: a stripe may move between XCDs, whose L2s are
+// not coherent with each other -- nothing depends on where a wave runs.
+struct StripeSet {
+    double *mem;
+    uint64_t stride;  // doubles per stripe
+    uint32_t *owner;
+    uint32_t n;       // stripes (>= the waves the device can hold: nobody ever waits for long)
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t jtk_stripe_acquire(const StripeSet &ss) {
+    uint32_t got = 0;
+    if (threadIdx.x == 0) {
+        // start anywhere (the cycle counter differs between waves and launches), probe linearly; holders never wait for anything,
+        // so a full table only means a short wait
+        uint32_t h = (uint32_t)((__builtin_readcyclecounter() * 0x9E3779B97F4A7C15ull) >> 40) % ss.n;
+        for (uint32_t tries = 0;; tries++) {
+            uint32_t expected = 0;
+            if (__hip_atomic_compare_exchange_strong(&ss.owner[h], &expected, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT))
+                break;
+            if (++h == ss.n) h = 0;
+            if ((tries & 255u) == 255u) __builtin_amdgcn_s_sleep(16);
+        }
+        got = h;
+    }
+    got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every lane: what the previous holder wrote is not read stale
+    return got;
+}
+__device__ __forceinline__ void jtk_stripe_release(const StripeSet &ss, uint32_t stripe) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every lane's stores to the stripe are out of this XCD's L2 first
+    if (threadIdx.x == 0) __hip_atomic_store(&ss.owner[stripe], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
 void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                  const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta,
-                 const HmmDev *hmm2, double *scratch, uint64_t scratch_stride, uint32_t n_waves,
+                 const HmmDev *hmm2, StripeSet stripes, uint32_t n_waves,
                  uint32_t *work_counter, uint32_t *ticket_base, double *raw, int *rawG, double *lk, uint32_t max_tmpl,
                  uint32_t max_read, int only_active, uint32_t skip_le_radius = 0);
 // phmm_pair.hip: the same sweep for band radius <= JTK_PAIR_MAX_RADIUS, two reads of a chunk per wave.  items[q] = index of
@@ -112,7 +149,7 @@ void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const C
 size_t phmm_pair_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
 void launch_phmm_pair(hipStream_t s, uint32_t n_items, const uint32_t *items, const ReadMeta *reads, const ChunkMeta *chunks,
                       const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
-                      double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
+                      StripeSet stripes, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
                       double *raw, int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active);
 void launch_finalize(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                      const ChunkState *state, const HmmDev *hmm2, double *raw, const int *rawG, const double *lk,

@@ -66,7 +66,7 @@ __device__ __forceinline__ double pr_pow2(int e) {  // 2^e, lane-varying exponen
 __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, const uint32_t *items, const ReadMeta *reads,
                                                          const ChunkMeta *chunks, const ChunkState *state, DevBufs bufs,
                                                          const uint8_t *ey_all, const uint64_t *delta_all, const HmmDev *hmm2,
-                                                         double *scratch_all, uint64_t scratch_stride, uint32_t *work_counter, uint32_t ticket_base,
+                                                         StripeSet stripes, uint32_t *work_counter, uint32_t ticket_base,
                                                          double *raw_all, int *rawG_all, double *lk_all, uint32_t lds_tmpl,
                                                          uint32_t lds_read, int only_active) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, cons
     uint8_t *s_ey = s_xs + xs_bytes;  // [2][ey_bytes]
     const int lane = threadIdx.x, hb = lane >> 5, l32 = lane & 31;
     // the stripe starts with JTK_SCRATCH_GUARD rows of zeros: "the pair of a diagonal below 0" is then an ordinary load
-    double2 *scratch = reinterpret_cast<double2 *>(scratch_all + (uint64_t)blockIdx.x * scratch_stride) + JTK_SCRATCH_GUARD * 64;
+    const uint32_t stripe = jtk_stripe_acquire(stripes);  // for as long as the wave lives (device_common.h: StripeSet)
+    double2 *scratch = reinterpret_cast<double2 *>(stripes.mem + (uint64_t)stripe * stripes.stride) + JTK_SCRATCH_GUARD * 64;
 #pragma unroll
     for (int g = 1; g <= JTK_SCRATCH_GUARD; g++) scratch[-g * 64 + lane] = make_double2(0.0, 0.0);
     // this half's views
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, cons
             }
         }
     }
+    jtk_stripe_release(stripes, stripe);
 }
 
 }  // namespace
@@ -438,12 +440,12 @@ size_t phmm_pair_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
 
 void launch_phmm_pair(hipStream_t s, uint32_t n_items, const uint32_t *items, const ReadMeta *reads, const ChunkMeta *chunks,
                       const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
-                      double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base, double *raw, int *rawG,
+                      StripeSet stripes, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base, double *raw, int *rawG,
                       double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active) {
     if (n_items == 0) return;
     const uint32_t base = *ticket_base;
     *ticket_base = base + n_items + n_waves;
     const size_t lds = phmm_pair_lds_bytes(max_tmpl, max_read);
-    phmm_pair_kernel<<<n_waves, 64, lds, s>>>(n_items, items, reads, chunks, state, bufs, ey, delta, hmm2, scratch, scratch_stride,
+    phmm_pair_kernel<<<n_waves, 64, lds, s>>>(n_items, items, reads, chunks, state, bufs, ey, delta, hmm2, stripes,
                                               work_counter, base, raw, rawG, lk, max_tmpl, max_read, only_active);
 }

@@ -718,12 +718,14 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
 
 __global__ __launch_bounds__(64, 3) __attribute__((amdgpu_num_vgpr(JTK_PHMM_NUM_VGPR))) void phmm_kernel(
     uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks, const ChunkState *state, DevBufs bufs,
-    const uint8_t *ey_all, const uint64_t *delta_all, const HmmDev *hmm2, double *scratch_all, uint64_t scratch_stride,
+    const uint8_t *ey_all, const uint64_t *delta_all, const HmmDev *hmm2, StripeSet stripes,
     uint32_t *work_counter, uint32_t ticket_base, double *raw_all, int *rawG_all, double *lk_all, uint32_t lds_tmpl,
     uint32_t lds_read, int only_active, uint32_t skip_le_radius) {
     const int lane = threadIdx.x;
+    // this wave's stripe of the device's forward scratch, for as long as the wave lives (device_common.h: StripeSet);
     // the stripe starts with JTK_SCRATCH_GUARD rows of zeros: "the pair of a diagonal below 0" is an ordinary load
-    double2 *scratch = reinterpret_cast<double2 *>(scratch_all + (uint64_t)blockIdx.x * scratch_stride) + JTK_SCRATCH_GUARD * 64;
+    const uint32_t stripe = jtk_stripe_acquire(stripes);
+    double2 *scratch = reinterpret_cast<double2 *>(stripes.mem + (uint64_t)stripe * stripes.stride) + JTK_SCRATCH_GUARD * 64;
 #pragma unroll
     for (int g = 1; g <= JTK_SCRATCH_GUARD; g++) scratch[-g * 64 + lane] = make_double2(0.0, 0.0);
     for (;;) {
@@ -750,6 +752,7 @@ __global__ __launch_bounds__(64, 3) __attribute__((amdgpu_num_vgpr(JTK_PHMM_NUM_
                    ey_all + uni64(rm.ey_off), delta_all + uni64(rm.delta_off), scratch, raw_all + uni64(rm.raw_off),
                    rawG_all + uni64(rm.row_off), lk_all + item, lds_tmpl, lds_read);
     }
+    jtk_stripe_release(stripes, stripe);
 }
 
 size_t phmm_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
@@ -762,14 +765,14 @@ size_t phmm_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
 
 void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                  const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta,
-                 const HmmDev *hmm2, double *scratch, uint64_t scratch_stride, uint32_t n_waves,
+                 const HmmDev *hmm2, StripeSet stripes, uint32_t n_waves,
                  uint32_t *work_counter, uint32_t *ticket_base, double *raw, int *rawG, double *lk, uint32_t max_tmpl,
                  uint32_t max_read, int only_active, uint32_t skip_le_radius) {
     if (n_reads == 0) return;
 #ifdef JTK_PHMM_WITH_R2
     if (getenv("JTK_PHMM_R2")) {
         // the round-2 kernel resets its counter: give it the spare slot behind the ticket counters
-        launch_phmm_r2(s, n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch, scratch_stride, n_waves, work_counter + 3, raw,
+        launch_phmm_r2(s, n_reads, reads, chunks, state, bufs, ey, delta, hmm2, stripes.mem, stripes.stride, n_waves, work_counter + 3, raw,
                        rawG, lk, max_tmpl, max_read, only_active, skip_le_radius);
         return;
     }
@@ -777,7 +780,6 @@ void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const C
     const size_t lds = phmm_lds_bytes(max_tmpl, max_read);
     const uint32_t base = *ticket_base;
     *ticket_base = base + n_reads + n_waves;  // every wave takes exactly one ticket past the end
-    phmm_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch,
-                                         scratch_stride, work_counter, base, raw, rawG, lk, max_tmpl, max_read,
-                                         only_active, skip_le_radius);
+    phmm_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, stripes, work_counter, base, raw,
+                                         rawG, lk, max_tmpl, max_read, only_active, skip_le_radius);
 }

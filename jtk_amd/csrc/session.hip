@@ -142,6 +142,19 @@ struct DevPtr {
     }
 };
 
+// The forward scratch of phmm_kernel / phmm_pair_kernel (device_common.h: StripeSet): one set of stripes per device, shared by
+// every session on it -- four slices in flight used to hold four sets of 3,072 x 4.1 MB, of which the device's resident waves
+// could only ever use one set's worth.  A session that needs longer stripes than the current set has replaces it (sessions
+// that still run keep theirs through the shared_ptr).
+struct StripePool {
+    DevPtr mem, owner;
+    uint64_t stride = 0;  // doubles
+    uint32_t n = 0;
+    StripeSet set() const { return StripeSet{mem.as<double>(), stride, owner.as<uint32_t>(), n}; }
+};
+std::mutex g_stripe_mutex;
+std::shared_ptr<StripePool> g_stripes[JTK_POOL_DEVICES];
+
 struct KernelTimer {
     hipEvent_t a = nullptr, b = nullptr;
     int kind = 0;
@@ -179,7 +192,7 @@ struct jtk_lc_session {
     ChainClass chain_class[2];  // the chain kernel's launches (by LDS need), as ranges of d_order
     uint32_t n_pair_items = 0, n_pair_waves = 0;  // phmm_pair_kernel: chunks with band radius <= JTK_PAIR_MAX_RADIUS
     DevPtr d_pair_items;
-    uint64_t scratch_stride = 0;
+    std::shared_ptr<StripePool> stripes;  // the device's forward scratch (shared)
     bool features_only = false;
     std::vector<ChunkMeta> h_chunks;
     std::vector<ReadMeta> h_reads;
@@ -187,7 +200,7 @@ struct jtk_lc_session {
     std::vector<uint64_t> h_in_tmpl_off;
     // device memory
     DevPtr d_params, d_hmm2, d_chunks, d_reads, d_state, d_tmpl0, d_tmpl1, d_ops0, d_ops1, d_opslen0, d_opslen1,
-        d_ey, d_delta, d_scratch, d_raw, d_rawG, d_lk, d_total, d_edits, d_newlen, d_counter, d_nactive,
+        d_ey, d_delta, d_raw, d_rawG, d_lk, d_total, d_edits, d_newlen, d_counter, d_nactive,
         d_homop, d_homop_off, d_aux, d_aux_off, d_cand, d_list, d_sel, d_feat, d_vtype, d_pos, d_label, d_post,
         d_lg, d_lg_off, d_vt_off, d_tmpl_init, d_ops_init, d_opslen_init, d_order;
     size_t tmpl_bytes = 0, ops_bytes = 0;
@@ -609,8 +622,22 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         const uint32_t want = (uint32_t)prop.multiProcessorCount * per_cu;
         s->n_waves = n_reads < want ? (uint32_t)n_reads : want;
         if (s->n_waves == 0) s->n_waves = 1;
-        s->scratch_stride = (uint64_t)(s->max_tmpl + s->max_read + 8 + JTK_SCRATCH_GUARD) * 64 * 2;  // doubles
-        if ((rc = dev_alloc<double>(s->d_scratch, s->scratch_stride * s->n_waves))) return rc;
+        // one stripe per wave the DEVICE can hold (3 per SIMD by registers = 12 per CU; 16 leaves room): the set is shared
+        const uint64_t stride = (uint64_t)(s->max_tmpl + s->max_read + 8 + JTK_SCRATCH_GUARD) * 64 * 2;  // doubles
+        const uint32_t n_stripes = (uint32_t)prop.multiProcessorCount * 16;
+        std::lock_guard<std::mutex> lock(g_stripe_mutex);
+        std::shared_ptr<StripePool> &cur = g_stripes[device];
+        if (!cur || cur->stride < stride || cur->n < n_stripes) {
+            auto p = std::make_shared<StripePool>();
+            p->stride = std::max<uint64_t>(stride, cur ? cur->stride : 0);
+            p->n = std::max<uint32_t>(n_stripes, cur ? cur->n : 0);
+            cur.reset();  // its blocks go back to the block cache first (if no session holds it any more)
+            if ((rc = dev_alloc<double>(p->mem, p->stride * p->n))) return rc;
+            if ((rc = dev_alloc<uint32_t>(p->owner, p->n))) return rc;
+            HIP_TRY(hipMemset(p->owner.p, 0, (size_t)p->n * sizeof(uint32_t)));  // every stripe free; blocking, under the lock
+            cur = p;
+        }
+        s->stripes = cur;
     }
     {  // narrow bands: two reads of a chunk per wave (phmm_pair.hip); JTK_PHMM_PAIR=0 keeps them on phmm_kernel
         static const bool pair_on = []() {
@@ -732,12 +759,12 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
         const int final_pass = skip_polish || round == JTK_POLISH_MAX_ROUNDS;
         tstart(s, JTK_K_PHMM);
         launch_phmm(st, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(),
-                    hmm2, s->d_scratch.as<double>(), s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(), &s->tk_phmm,
+                    hmm2, s->stripes->set(), s->n_waves, s->d_counter.as<uint32_t>(), &s->tk_phmm,
                     s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read,
                     only_active, s->n_pair_items ? JTK_PAIR_MAX_RADIUS : 0);
         if (s->n_pair_items)
             launch_phmm_pair(st, s->n_pair_items, s->d_pair_items.as<uint32_t>(), reads, chunks, state, s->bufs,
-                             s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), hmm2, s->d_scratch.as<double>(), s->scratch_stride,
+                             s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), hmm2, s->stripes->set(),
                              s->n_pair_waves, s->d_counter.as<uint32_t>() + 1, &s->tk_pair, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                              s->d_lk.as<double>(), s->max_tmpl, s->max_read, only_active);
         if (s->n_wide_reads)
@@ -1783,8 +1810,7 @@ int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl
     launch_band_prep(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
                      s->d_delta.as<uint64_t>(), 0);
     launch_phmm(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
-                s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(), s->d_scratch.as<double>(),
-                s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(), &s->tk_phmm, s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(), s->stripes->set(), s->n_waves, s->d_counter.as<uint32_t>(), &s->tk_phmm, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                 s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
     if (s->n_wide_reads)
         launch_phmm_wide(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
@@ -1832,8 +1858,7 @@ int jtk_internal_likelihoods(const jtk_lc_params_t *params, size_t n_chunks, con
     launch_band_prep(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
                      s->d_delta.as<uint64_t>(), 0);
     launch_phmm(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
-                s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(), s->d_scratch.as<double>(),
-                s->scratch_stride, s->n_waves, s->d_counter.as<uint32_t>(), &s->tk_phmm, s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(), s->stripes->set(), s->n_waves, s->d_counter.as<uint32_t>(), &s->tk_phmm, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                 s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
     if (s->n_wide_reads)
         launch_phmm_wide(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
@@ -1952,6 +1977,10 @@ int jtk_lc_trim_cache(int device) {
     int cur = 0;
     if (hipGetDevice(&cur) != hipSuccess) return JTK_ERR_NO_DEVICE;
     (void)hipSetDevice(device);
+    {
+        std::lock_guard<std::mutex> lock(g_stripe_mutex);
+        g_stripes[device].reset();  // running sessions keep the set they hold
+    }
     g_pool.trim(device);
     (void)hipSetDevice(cur);
     return 0;

@@ -2,7 +2,7 @@
 # Diagnostic (GPU box): where the generic chain (K > 2, or n > 127) spends its cycles, on full-size 4-copy pile-ups.
 set -u
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_STATS" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
+export JTK_LC_LIB=$(python3 -c "import jtk_amd.build as b; print(b.build_experiment('probe1', '''-DJTK_MCMC_STATS'''))") || exit 1
 python3 - > gpurun_out/genstat_raw.txt 2>&1 <<'PY'
 import torch
 from jtk_amd import api, batch as jb, synth
@@ -25,4 +25,4 @@ for key, a in sorted(acc.items()):
     print("K %d n %d D %d: %d chains, per step: draws %.0f flip %.0f approx %.0f decide %.0f tail %.0f cycles; exact evaluations %.2f%%"
           % (*key, a[0], a[2] / st, a[3] / st, a[4] / st, a[5] / st, a[6] / st, 100.0 * a[7] / st))
 PY
-python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
+unset JTK_LC_LIB   # the product library was never touched

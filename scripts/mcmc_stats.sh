@@ -2,7 +2,7 @@
 # Diagnostic (GPU box): rebuild with per-chunk chain counters, run one bench pass, keep the slowest chunks.
 set -u
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_STATS" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i error
+export JTK_LC_LIB=$(python3 -c "import jtk_amd.build as b; print(b.build_experiment('probe1', '''-DJTK_MCMC_STATS'''))") || exit 1
 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/stats_raw.txt 2>&1
 python3 - <<'PY'
 import re, numpy as np
@@ -26,4 +26,4 @@ if pr:
 i=np.argsort(-a[:,3])[:6]
 for r in a[i]: print("slow chunk %d D %d cyc %.4g events %d (cycles in general events %.3g) inline %d windows %d"%(r[0],r[2],r[3],r[8],r[5],r[4],r[7]))
 PY
-python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i error
+unset JTK_LC_LIB   # the product library was never touched

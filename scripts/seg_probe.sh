@@ -4,10 +4,10 @@
 set -u
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for seg in ${SEGS:-3 4}; do
-  JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_SEG_LOG=$seg" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
+  export JTK_LC_LIB=$(python3 -c "import jtk_amd.build as b; print(b.build_experiment('probe1', '''-DJTK_MCMC_SEG_LOG=$seg'''))") || exit 1
   echo "== SEG_LOG $seg"
   if [ $seg != 4 ]; then timeout 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "chain or size_only or features or full_size" 2>&1 | tail -2; fi
   timeout 300 python3 bench.py --streams 1 --steps 2 --no-cpu-baseline --no-e2e --no-shard8 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('serial', round(d['value'],1), d['roofline']['serial_pass'])"
   timeout 300 python3 bench.py --steps 12 --no-cpu-baseline --no-e2e --no-shard8 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('4 in flight', round(d['value'],1), d['roofline']['serial_pass'])"
 done
-python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
+unset JTK_LC_LIB   # the product library was never touched

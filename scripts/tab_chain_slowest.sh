@@ -15,7 +15,7 @@ with api.Session(p, b) as s:
     t = api.last_timing()
 print("MCMCMS", t["kernel_ms"]["mcmc"])
 PY
-JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_STATS" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
+export JTK_LC_LIB=$(python3 -c "import jtk_amd.build as b; print(b.build_experiment('probe1', '''-DJTK_MCMC_STATS'''))") || exit 1
 python3 /tmp/tabrun.py $N > gpurun_out/tabstat_raw.txt 2>&1
 grep MCMCMS gpurun_out/tabstat_raw.txt
 python3 - <<'PY'
@@ -38,4 +38,4 @@ for c in order[:6] + order[-2:]:
         print("   K %d D %d: %.0f cyc/step; events %.2f%% accepts %.2f%% reloads %.1f%%; event %.0f cyc (rebuild %.0f)" % (
             K, D, a[8]/st, 100*a[2]/st, 100*a[3]/st, 100*a[4]/st, a[7]/max(1,a[2]), a[6]/max(1,a[3])))
 PY
-python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
+unset JTK_LC_LIB   # the product library was never touched

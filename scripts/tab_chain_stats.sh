@@ -18,9 +18,9 @@ print("MCMCMS", t["kernel_ms"]["mcmc"], "k", r["result"]["cluster_num"].tolist()
 PY
 python3 /tmp/tabrun.py 8 2>&1 | grep MCMCMS
 # the legacy chain is not in the product build: build it in (one register-hungry wave per SIMD), run, rebuild
-JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_WITH_LEGACY -DJTK_MCMC_WAVES=1" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
+export JTK_LC_LIB=$(python3 -c "import jtk_amd.build as b; print(b.build_experiment('probe1', '''-DJTK_MCMC_WITH_LEGACY -DJTK_MCMC_WAVES=1'''))") || exit 1
 JTK_MCMC_LEGACY=1 python3 /tmp/tabrun.py 8 2>&1 | grep MCMCMS
-JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_STATS" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
+export JTK_LC_LIB=$(python3 -c "import jtk_amd.build as b; print(b.build_experiment('probe2', '''-DJTK_MCMC_STATS'''))") || exit 1
 python3 /tmp/tabrun.py 2 > gpurun_out/tabstat_raw.txt 2>&1
 python3 - <<'PY'
 import re, collections
@@ -40,4 +40,4 @@ for key, a in sorted(acc.items()):
           % (*key, a[0], a[9] / st, 100.0 * a[2] / st, 100.0 * a[3] / st, 100.0 * a[4] / st, 100.0 * a[5] / st, 100.0 * a[6] / st,
              a[7] / max(1, a[4]), a[8] / max(1, a[3])))
 PY
-python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
+unset JTK_LC_LIB   # the product library was never touched

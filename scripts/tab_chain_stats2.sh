@@ -17,7 +17,7 @@ with api.Session(p, b) as s:
     r = s.fetch_results()
 print("MCMCMS", t["kernel_ms"]["mcmc"], "k", r["result"]["cluster_num"].tolist(), "D", r["result"]["n_variants"].tolist())
 PY
-JTK_EXTRA_HIPCC_FLAGS="-DJTK_MCMC_STATS ${JTK_STATS_EXTRA:-}" python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
+export JTK_LC_LIB=$(python3 -c "import jtk_amd.build as b; print(b.build_experiment('probe1', '''-DJTK_MCMC_STATS ${JTK_STATS_EXTRA:-}'''))") || exit 1
 python3 /tmp/tabrun.py $N > gpurun_out/tabstat_raw.txt 2>&1
 grep MCMCMS gpurun_out/tabstat_raw.txt
 python3 - <<'PY'
@@ -38,4 +38,4 @@ for key, a in sorted(acc.items()):
           % (*key, a[0], a[9] / st, 100.0 * a[2] / st, 100.0 * a[3] / st, 100.0 * a[4] / st, 100.0 * a[5] / st, 100.0 * a[6] / st,
              a[7] / max(1, a[4]), a[8] / max(1, a[3])))
 PY
-python3 -c "import jtk_amd.build as b; b.build(force=True)" 2>&1 | grep -i ' error'
+unset JTK_LC_LIB   # the product library was never touched
