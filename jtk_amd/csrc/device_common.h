@@ -112,6 +112,7 @@ struct StripeSet {
     uint64_t stride;  // doubles per stripe
     uint32_t *owner;
     uint32_t n;       // stripes (>= the waves the device can hold: nobody ever waits for long)
+    uint32_t unfenced;  // measurement only (JTK_STRIPE_UNFENCED=1): hand over without the acquire / release fences
 };
 #ifdef __HIPCC__
 __device__ __forceinline__ uint32_t jtk_stripe_acquire(const StripeSet &ss) {
@@ -131,11 +132,11 @@ __device__ __forceinline__ uint32_t jtk_stripe_acquire(const StripeSet &ss) {
         got = h;
     }
     got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every lane: what the previous holder wrote is not read stale
+    if (!ss.unfenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every lane: what the previous holder wrote is not read stale
     return got;
 }
 __device__ __forceinline__ void jtk_stripe_release(const StripeSet &ss, uint32_t stripe) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every lane's stores to the stripe are out of this XCD's L2 first
+    if (!ss.unfenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every lane's stores to the stripe are out of this XCD's L2 first
     if (threadIdx.x == 0) __hip_atomic_store(&ss.owner[stripe], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif

@@ -150,7 +150,10 @@ struct StripePool {
     DevPtr mem, owner;
     uint64_t stride = 0;  // doubles
     uint32_t n = 0;
-    StripeSet set() const { return StripeSet{mem.as<double>(), stride, owner.as<uint32_t>(), n}; }
+    StripeSet set() const {
+        static const uint32_t unfenced = getenv("JTK_STRIPE_UNFENCED") ? 1u : 0u;  // measurement only
+        return StripeSet{mem.as<double>(), stride, owner.as<uint32_t>(), n, unfenced};
+    }
 };
 std::mutex g_stripe_mutex;
 std::shared_ptr<StripePool> g_stripes[JTK_POOL_DEVICES];
