@@ -47,6 +47,14 @@ WORKLOADS = {
 # f64 operations of the pair-HMM specification per band cell and pass (an fma counts 2):
 # forward 2 emission products + 3 x (mul + 2 fma) = 17, backward the same, 22 fma into the row accumulators = 44
 PHMM_FLOP_PER_CELL = 17 + 17 + 44
+# the kernels behind the timing families of jtk_lc_last_timing (what rocprofv3 --stats lists); a chain "launch" is
+# mcmc_kernel_light on the slice's stream with mcmc_kernel (the general one, few workgroups) beside it on a second stream
+KERNELS_OF_FAMILY = {
+    "mcmc": ["mcmc_kernel_light", "mcmc_kernel", "chain_split_kernel"],
+    "phmm": ["phmm_kernel", "phmm_pair_kernel", "phmm_wide_kernel", "finalize_kernel"],
+    "polish": ["sum_tables_kernel", "select_edits_kernel", "rethread_kernel", "commit_kernel", "band_prep_kernel"],
+    "filter": ["homop_kernel", "chunk_tables_kernel", "column_filter_kernel", "pick_kernel"],
+}
 
 
 def make_batch_parallel(config, chunk_ids, threads=8):
@@ -473,7 +481,7 @@ def main():
                     traffic=(traffic or {}).get(dom) if traffic else None, traffic_note=traffic_note,
                     algorithmic_bytes_per_chunk=alg_bytes_per_chunk,
                     dominant_kernel=dict(
-                        name=dom, launches_per_pass=serial_launch[dom], ms_per_pass=serial_k[dom],
+                        name=dom, kernels=KERNELS_OF_FAMILY.get(dom), launches_per_pass=serial_launch[dom], ms_per_pass=serial_k[dom],
                         avg_launch_ms=serial_k[dom] / max(1, serial_launch[dom]),
                         # per-launch form: the algorithmic bytes of the chunks one launch processes / its mean duration
                         achieved_GBps_per_launch=(alg_bytes_shard / n_streams / 1e9) /

@@ -48,8 +48,10 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 }
 
 // The ring of raw xoshiro256** outputs.  `wr` draws have been produced, the consumer has released `rd`.
-#define JTK_LIGHT_MAX_READS 63u  // what mcmc_kernel_light takes: diploid pile-ups of <= 63 reads ...
-#define JTK_LIGHT_MAX_DIM 2u     // ... with <= 2 variant columns (mcmc_chain_k2<1,..> / <2,..>: 168 registers)
+#ifndef JTK_LIGHT_MAX_READS
+#define JTK_LIGHT_MAX_READS 127u  // what mcmc_kernel_light takes: diploid pile-ups of <= 127 reads ...
+#endif
+#define JTK_LIGHT_MAX_DIM 2u      // ... with <= 2 variant columns (mcmc_chain_k2<1,..> / <2,..>: 168 registers)
 #ifndef JTK_MCMC_SEG_LOG
 #define JTK_MCMC_SEG_LOG 4
 #endif
@@ -2194,8 +2196,12 @@ __device__ __forceinline__ double mcmc_chain_dispatch(const Lds &m, uint32_t n, 
         if (!(K == 2 && n <= JTK_LIGHT_MAX_READS && D >= 1 && D <= JTK_LIGHT_MAX_DIM)) return __builtin_nan("");
         rng_set_parse_mode(rng, PM_K2, lane);
         const K2Mem km = {m.data, m.lfact, m.assign, m.k2_stats};
-        if (D == 1) return mcmc_chain_k2<1, true, 1>(km, n, D, cov, &rng, lane);
-        return mcmc_chain_k2<2, true, 1>(km, n, D, cov, &rng, lane);
+        if (n <= 63) {
+            if (D == 1) return mcmc_chain_k2<1, true, 1>(km, n, D, cov, &rng, lane);
+            return mcmc_chain_k2<2, true, 1>(km, n, D, cov, &rng, lane);
+        }
+        if (D == 1) return mcmc_chain_k2<1, true, 2>(km, n, D, cov, &rng, lane);  // 64 .. 127 reads: two table registers
+        return mcmc_chain_k2<2, true, 2>(km, n, D, cov, &rng, lane);
     }
     if (K == 2 && n <= 127 && D >= 1 && D <= 8) {
         rng_set_parse_mode(rng, PM_K2, lane);
@@ -2787,7 +2793,9 @@ int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, Chunk
     }
     chain_split_kernel<<<1, 64, 0, s>>>(n_chunks, order, chunks, state, split);
     hipStream_t hs = s;
-    if (side && ev_fork && ev_join && hipEventRecord(ev_fork, s) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess)
+    static const bool no_side = getenv("JTK_MCMC_SIDE") && atoi(getenv("JTK_MCMC_SIDE")) == 0;  // experiments: one stream
+    if (!no_side && side && ev_fork && ev_join && hipEventRecord(ev_fork, s) == hipSuccess &&
+        hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess)
         hs = side;
     mcmc_kernel<<<n_chunks, 128, lds, hs>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post, post_stride,
                                            lg, lg_off, lds_n, lds_d, lds_k, mcmc_jump_in_lds(lds_n, lds_d, lds_k) ? 1u : 0u, 0u,

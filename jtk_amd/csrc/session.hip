@@ -128,6 +128,13 @@ struct BlockPool {
 };
 BlockPool g_pool;
 
+// A batch in flight uses up to four slices x two streams (the chain's general kernel runs beside its light one).  ROCm maps
+// streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue run in order: a slice's 300 ms
+// chain kernel would then hold up another slice's pair-HMM launches.  The variable is read when the HIP runtime initialises, so
+// it is set -- unless the host has set it -- when this library is loaded; a host that has initialised HIP earlier sets it
+// itself.
+__attribute__((constructor)) void jtk_lc_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 struct DevPtr {
     void *p = nullptr;
     size_t cap = 0;
@@ -587,9 +594,14 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
     HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 4 * sizeof(uint32_t), s->stream));  // once: the ticket counters are never reset
     if ((rc = dev_alloc<uint32_t>(s->d_nactive, JTK_NACTIVE_SLOTS))) return rc;
     if ((rc = dev_alloc<uint32_t>(s->d_chain_split, 2 * n_chunks + 8))) return rc;
-    HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&s->ev_chain[0], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&s->ev_chain[1], hipEventDisableTiming));
+    {   // the second stream only where the hardware queues are there for it (see jtk_lc_default_hw_queues)
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        if (!q || atoi(q) >= 8) {
+            HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&s->ev_chain[0], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&s->ev_chain[1], hipEventDisableTiming));
+        }
+    }
     if (!polish_only) {  // the filter's and the chain's workspaces
     if ((rc = dev_alloc<uint16_t>(s->d_homop, tmpl_off))) return rc;
     if ((rc = dev_upload(s, s->d_homop_off, h_homop_off))) return rc;
@@ -628,8 +640,10 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         // one stripe per wave the DEVICE can hold (3 per SIMD by registers = 12 per CU; 16 leaves room): the set is shared
         const uint64_t stride = (uint64_t)(s->max_tmpl + s->max_read + 8 + JTK_SCRATCH_GUARD) * 64 * 2;  // doubles
         const uint32_t n_stripes = (uint32_t)prop.multiProcessorCount * 16;
+        static const bool private_set = getenv("JTK_STRIPE_SHARED") && atoi(getenv("JTK_STRIPE_SHARED")) == 0;  // experiments
         std::lock_guard<std::mutex> lock(g_stripe_mutex);
-        std::shared_ptr<StripePool> &cur = g_stripes[device];
+        std::shared_ptr<StripePool> mine;  // JTK_STRIPE_SHARED=0: a set of this session's own, as before round 3
+        std::shared_ptr<StripePool> &cur = private_set ? mine : g_stripes[device];
         if (!cur || cur->stride < stride || cur->n < n_stripes) {
             auto p = std::make_shared<StripePool>();
             p->stride = std::max<uint64_t>(stride, cur ? cur->stride : 0);

@@ -340,6 +340,26 @@ def test_multi_device_call_matches_single_device(lib):
     assert e.value.status == -2
 
 
+def test_heterogeneous_batch_keeps_class_0_below_80_kib(lib):
+    """a deep diploid pile-up (420 reads) next to a shallow 7-copy one: each fits 80 KiB of chain work area on its own, their
+    combined maxima (420 reads x 21 columns x 7 clusters) do not -- the deep one moves to the second launch class, class 0
+    keeps two workgroups per CU (jtk_lc_timing_t.chain_lds_bytes), and both chunks match the oracle"""
+    cfg_deep = dict(synth.CONFIGS["ont_diploid"], tmpl_len=240, reads_per_hap=210)
+    cfg_wide = dict(synth.CONFIGS["ont_4copy"], tmpl_len=240, reads_per_hap=6, n_haps=7, copy_num=7, divergence=2.5e-2)
+    b = jb.pack([synth.make_pileup(7100, cfg_deep, min_variants=1), synth.make_pileup(7200, cfg_wide, min_variants=2)])
+    p = jb.default_params(haploid_coverage=30.0, band_frac=cfg_deep["band_frac"])
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, n_threads=2)
+    assert ora["rc"] == 0
+    dev = api.cluster_chunks(p, b)
+    t = api.last_timing()
+    assert 0 < t["chain_lds_bytes"][0] <= 80 * 1024 and 0 < t["chain_lds_bytes"][1] <= 160 * 1024, t["chain_lds_bytes"]
+    assert t["chain_lds_bytes"][0] < t["chain_lds_bytes"][1]      # the deep pile-up went to the second class
+    assert np.array_equal(dev["result"]["status"], np.zeros(2, np.int32))
+    assert np.array_equal(dev["label"], ora["label"])
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(ora["log_post"]))
+
+
 def test_pileup_beyond_511_reads_matches_oracle(lib):
     """a 9-copy pile-up at 60x (540 reads) next to a diploid one: the big chunk's first pass (K = 4 on 540 reads) runs in the
     chain kernel's second launch class (LDS work area above 80 KiB), the diploid chunk in the first; both bit-exact"""
