@@ -245,7 +245,7 @@ def main():
     os.environ.setdefault("JTK_LC_POOL_GB", "160")
     # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue run in order: a
     # slice's 300 ms chain kernel would hold up another slice's pair-HMM launches.  One queue per slice (+ torch's streams).
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, args.streams + 2)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(12, 2 * args.streams + 4)))   # two streams per slice + the host's own
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

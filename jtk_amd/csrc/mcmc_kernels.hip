@@ -2629,14 +2629,7 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     chunks, state, params, feat_all, vtype_all, vt_off_all, vt_stride_mode, label_all, post_all, post_stride, lg_all,       \
         lg_off, lds_n, lds_d, lds_k, jump_in_lds, flags, rng_resume, order, order_count
 __global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(MCMC_KERNEL_PARAMS) { mcmc_body<false>(MCMC_KERNEL_ARGS); }
-__global__ __launch_bounds__(128, 3) void mcmc_kernel_light(MCMC_KERNEL_PARAMS) {
-#ifdef JTK_LIGHT_176
-    // experiment: 176 registers instead of 168 -- at most two light waves per SIMD (the general kernel's packing), still room
-    // for two pair-HMM waves beside one (176 + 2 x 168 = 512)
-    asm volatile("; register v175 named so that the allocation is 176" ::: "v175");
-#endif
-    mcmc_body<true>(MCMC_KERNEL_ARGS);
-}
+__global__ __launch_bounds__(128, 3) void mcmc_kernel_light(MCMC_KERNEL_PARAMS) { mcmc_body<true>(MCMC_KERNEL_ARGS); }
 
 // One wave splits a launch's chunk list (order[] or 0 .. count-1) into the chunks the light kernel can run and the rest,
 // keeping the order (longest chain first) in both: out = counts[2] | light[count] | heavy[count].  Chunks with a trivial

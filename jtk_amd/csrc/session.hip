@@ -130,10 +130,11 @@ BlockPool g_pool;
 
 // A batch in flight uses up to four slices x two streams (the chain's general kernel runs beside its light one).  ROCm maps
 // streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue run in order: a slice's 300 ms
-// chain kernel would then hold up another slice's pair-HMM launches.  The variable is read when the HIP runtime initialises, so
-// it is set -- unless the host has set it -- when this library is loaded; a host that has initialised HIP earlier sets it
-// itself.
-__attribute__((constructor)) void jtk_lc_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// chain kernel would then hold up another slice's pair-HMM launches.  Eight streams need eight queues, and the host's own
+// streams (the null stream as soon as anything uses it) take theirs: 12.  The variable is read when the HIP runtime
+// initialises, so it is set -- unless the host has set it -- when this library is loaded; a host that has initialised HIP
+// earlier sets it itself.
+__attribute__((constructor)) void jtk_lc_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
 
 struct DevPtr {
     void *p = nullptr;
@@ -651,7 +652,12 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
             cur.reset();  // its blocks go back to the block cache first (if no session holds it any more)
             if ((rc = dev_alloc<double>(p->mem, p->stride * p->n))) return rc;
             if ((rc = dev_alloc<uint32_t>(p->owner, p->n))) return rc;
-            HIP_TRY(hipMemset(p->owner.p, 0, (size_t)p->n * sizeof(uint32_t)));  // every stripe free; blocking, under the lock
+            // every stripe free.  On the session's own stream, waited for under the lock -- NOT hipMemset: that is an operation of
+            // the null stream, which then holds a hardware queue of its own for the life of the process; with four slices x two
+            // streams on eight queues one slice's second stream then shared a queue with its first, and that slice's two chain
+            // kernels ran one after the other (serial chain time 1,340 -> 1,490 ms per pass until this was found)
+            HIP_TRY(hipMemsetAsync(p->owner.p, 0, (size_t)p->n * sizeof(uint32_t), s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
             cur = p;
         }
         s->stripes = cur;

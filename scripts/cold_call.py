@@ -7,7 +7,7 @@ import sys
 import time
 
 os.environ.setdefault("JTK_LC_POOL_GB", "160")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
