@@ -644,7 +644,7 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         static const bool private_set = getenv("JTK_STRIPE_SHARED") && atoi(getenv("JTK_STRIPE_SHARED")) == 0;  // experiments
         std::lock_guard<std::mutex> lock(g_stripe_mutex);
         std::shared_ptr<StripePool> mine;  // JTK_STRIPE_SHARED=0: a set of this session's own, as before round 3
-        std::shared_ptr<StripePool> &cur = private_set ? mine : g_stripes[device];
+        std::shared_ptr<StripePool> &cur = (private_set || device >= JTK_POOL_DEVICES) ? mine : g_stripes[device];
         if (!cur || cur->stride < stride || cur->n < n_stripes) {
             auto p = std::make_shared<StripePool>();
             p->stride = std::max<uint64_t>(stride, cur ? cur->stride : 0);
