@@ -83,7 +83,7 @@ HmmDev to_dev(const jtk_hmm_t &h) {
 
 // Device blocks of destroyed sessions are kept for the next session on the same device: a stage call is one-shot
 // (create, run, fetch, destroy) and is entered several times per pipeline with batches of similar shape, and mapping
-// ~95 GB of workspaces for 2500 chunks costs 1.3 s on a fresh device and up to 3.8 s once the same memory has been
+// the ~88 GB of workspaces of 2500 chunks costs ~0.2 s on a fresh device and ~2.4 s once the same memory has been
 // freed before (the driver scrubs it) -- more than the kernels take.  Nothing relies on the contents of a fresh
 // block.  jtk_lc_trim_cache() returns everything to the driver.
 struct BlockPool {
@@ -1301,8 +1301,8 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
     size_t per_dev = std::min<size_t>(4, n_chunks / n_devices / 500);  // 2500 chunks: 2.08 / 1.80 / 2.08 / 2.17 s in 3 / 4 / 5 / 6 slices
     if (const char *e = getenv("JTK_LC_SLICES")) per_dev = (size_t)atoi(e);
     if (per_dev < 1) per_dev = 1;
-    // per_dev slices of a device run side by side.  A batch whose workspaces do not fit beside each other that way (4-copy
-    // pile-ups: 160 reads x 555 KB of row sums + tables per chunk) is cut into MORE slices, which the per_dev worker threads
+    // per_dev slices of a device run side by side.  A batch whose workspaces do not fit beside each other that way (deep
+    // pile-ups: 296 KB of row sums / tables per read of a 2 kbp chunk) is cut into MORE slices, which the per_dev worker threads
     // of the device take one after the other: the workspace in use stays bounded by what per_dev slices need, and the
     // blocks a finished slice returns to the pool are what the next one takes.
     size_t slices_per_dev = per_dev;
@@ -1321,8 +1321,8 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
         int cur = 0;
         (void)hipGetDevice(&cur);
         if (hipSetDevice(devices[0]) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
-            const uint64_t scratch = 3072ull * (max_len + max_rd + 32) * 64 * 16;       // the pair-HMM stripes of one slice
-            const double budget = 0.80 * (double)total_b / (double)per_dev - (double)scratch;  // pooled blocks count as free
+            const uint64_t stripes = 4096ull * (max_len + max_rd + 32) * 64 * 16;   // the device's shared pair-HMM stripe set
+            const double budget = (0.80 * (double)total_b - (double)stripes) / (double)per_dev;  // pooled blocks count as free
             if (budget > 0) {
                 const size_t need = (size_t)std::ceil((double)est / (double)n_devices / budget);
                 if (need > slices_per_dev) slices_per_dev = need;
