@@ -335,13 +335,73 @@ def correct_clustering_selected(ds, selection, device=0, min_gain=None):
             e += 1
 
 
+_COMPLEMENT = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def recover_raw_read(read):
+    """EncodedRead::recover_raw_read (definitions/src/lib.rs:604-619): leading gap, then every node's original sequence
+    (Node::original_seq :737-753: reverse complement of a reverse node; anything but ACGT panics) with the overlap of a
+    negative edge offset popped and the edge label appended, the last node, the trailing gap."""
+    def original(node):
+        if node["is_forward"]:
+            return node["seq"]
+        try:
+            return "".join(_COMPLEMENT[b] for b in reversed(node["seq"].upper()))
+        except KeyError:
+            raise ValueError("sanity_check: a reverse node holds a base outside ACGT (Node::original_seq panics)") from None
+    out = list(read["leading_gap"])
+    for node, edge in zip(read["nodes"], read["edges"]):
+        if node["chunk"] != edge["from"]:
+            raise ValueError(f"sanity_check: read {read['id']}: edge.from {edge['from']} after node of chunk {node['chunk']}")
+        out.extend(original(node))
+        drop = max(-int(edge["offset"]), 0)
+        if drop:
+            del out[max(len(out) - drop, 0):]
+        out.extend(edge["label"])
+    if read["nodes"]:
+        out.extend(original(read["nodes"][-1]))
+    out.extend(read["trailing_gap"])
+    return "".join(out)
+
+
+def sanity_check(ds):
+    """DataSet::sanity_check (definitions/src/lib.rs:296-327 + encoded_reads_can_be_recovered :328-358), which
+    correct_clustering ends with (phmm_likelihood_correction.rs:29).  Where the reference panics this raises ValueError."""
+    ids = [c["id"] for c in ds["selected_chunks"]]
+    chunks = set(ids)
+    for read in ds["encoded_reads"]:
+        for node in read["nodes"]:
+            if node["chunk"] not in chunks:
+                raise ValueError(f"sanity_check: read {read['id']} has a node on chunk {node['chunk']}, which is not selected")
+    raw = {r["id"]: r["seq"] for r in ds["raw_reads"]}
+    for read in ds["encoded_reads"]:
+        if read["id"] not in raw:
+            raise ValueError(f"sanity_check: encoded read {read['id']} has no raw read")
+        orig, rec = raw[read["id"]].upper(), recover_raw_read(read).upper()
+        if len(orig) != len(rec) or len(orig) != read["original_length"] or orig != rec:
+            raise ValueError(f"sanity_check: encoded read {read['id']} does not recover its raw read "
+                             f"({len(rec)} bases recovered, {len(orig)} raw, original_length {read['original_length']})")
+    if len(chunks) != len(ids):
+        raise ValueError("sanity_check: a chunk id occurs twice in selected_chunks")
+    for c in ds["selected_chunks"]:
+        if not c["cluster_num"] <= c["copy_num"]:
+            raise ValueError(f"sanity_check: chunk {c['id']}: cluster_num {c['cluster_num']} > copy_num {c['copy_num']}")
+    max_cl = {c["id"]: c["cluster_num"] for c in ds["selected_chunks"]}
+    for read in ds["encoded_reads"]:
+        for node in read["nodes"]:
+            if not node["cluster"] <= max_cl[node["chunk"]]:
+                raise ValueError(f"sanity_check: a node of chunk {node['chunk']} carries cluster {node['cluster']} of "
+                                 f"{max_cl[node['chunk']]}")
+
+
 def correct_clustering(ds, device=0, min_gain=None):
     """AlignmentCorrection::correct_clustering (phmm_likelihood_correction.rs:14-30): chunks no read visits are dropped,
-    every chunk with more than one cluster is corrected."""
+    every chunk with more than one cluster is corrected, and the data set has to pass DataSet::sanity_check afterwards."""
     present = {n["chunk"] for r in ds["encoded_reads"] for n in r["nodes"]}
     ds["selected_chunks"] = [c for c in ds["selected_chunks"] if c["id"] in present]
     correct_clustering_selected(ds, [c["id"] for c in ds["selected_chunks"] if 1 < c["cluster_num"]], device=device,
                                 min_gain=min_gain)
+    sanity_check(ds)
 
 
 def main(argv=None):

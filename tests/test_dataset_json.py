@@ -63,12 +63,52 @@ def synthetic_dataset(n_chunks, tmpl_len, rph):
             reads[r]["nodes"].append({"position_from_start": 0, "chunk": c, "cluster": 0, "seq": bytes(rs[r]).decode(),
                                       "is_forward": bool(strands[r]), "cigar": D.ops_to_cigar(ops[r]),
                                       "posterior": [math.log(0.5)] * 2})
+    # a complete DataSet (DataSet::sanity_check, definitions/src/lib.rs:296-358): consecutive nodes joined by edges, one of them
+    # overlapping its successor by two bases, gaps at both ends, and the raw reads the encoded reads recover
+    raw = []
+    for r, read in enumerate(reads):
+        read["leading_gap"], read["trailing_gap"] = "ac" * (r % 3), "G" * (r % 2)
+        for a, b in zip(read["nodes"], read["nodes"][1:]):
+            read["edges"].append({"from": a["chunk"], "to": b["chunk"], "offset": 3, "label": "TTg"})
+        if read["edges"]:
+            read["edges"][0].update(offset=-2, label="")
+        seq = D.recover_raw_read(read)
+        read["original_length"] = len(seq)
+        raw.append({"name": f"read{r}", "desc": "", "id": r, "seq": seq})
     return {"input_file": "synthetic", "masked_kmers": {"k": 0, "thr": 0}, "coverage": {"Protected": float(rph)},
-            "raw_reads": [], "hic_pairs": [], "selected_chunks": chunks, "encoded_reads": reads, "hic_edges": [],
+            "raw_reads": raw, "hic_pairs": [], "selected_chunks": chunks, "encoded_reads": reads, "hic_edges": [],
             "read_type": "ONT", "model_param": {"forward": hmm, "reverse": copy.deepcopy(hmm)},
             "error_rate": {"del": 0.01, "del_sd": 0.0, "ins": 0.01, "ins_sd": 0.0, "mismatch": 0.01, "mism_sd": 0.0,
                            "total": 0.03, "total_sd": 0.0},
             "processed_stages": [{"stage_name": "encode", "arg": []}]}
+
+
+def test_sanity_check_accepts_a_complete_dataset_and_names_every_violation():
+    """DataSet::sanity_check (definitions/src/lib.rs:296-358), which correct_clustering ends with
+    (phmm_likelihood_correction.rs:29): every assert of the reference is a ValueError here"""
+    ds = synthetic_dataset(3, 120, 3)
+    D.sanity_check(ds)
+    rev = next(n for r in ds["encoded_reads"] for n in r["nodes"] if not n["is_forward"])
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    assert D.recover_raw_read({"leading_gap": "", "trailing_gap": "", "edges": [], "nodes": [rev]}) == \
+        "".join(comp[b] for b in reversed(rev["seq"]))
+
+    def broken(change):
+        bad = copy.deepcopy(ds)
+        change(bad)
+        with pytest.raises(ValueError, match="sanity_check"):
+            D.sanity_check(bad)
+    broken(lambda d: d["encoded_reads"][0]["nodes"][0].update(chunk=99))                  # node on an unselected chunk
+    broken(lambda d: d["raw_reads"].pop(1))                                               # encoded read without raw read
+    broken(lambda d: d["raw_reads"][2].update(seq=d["raw_reads"][2]["seq"][:-1] + "N"))   # not recovered
+    broken(lambda d: d["encoded_reads"][3].update(original_length=1))
+    broken(lambda d: d["encoded_reads"][0]["edges"][1].update(**{"from": 77}))            # edge does not follow its node
+    broken(lambda d: d["selected_chunks"].append(copy.deepcopy(d["selected_chunks"][0])))  # duplicate chunk id
+    broken(lambda d: d["selected_chunks"][1].update(cluster_num=3))                       # cluster_num > copy_num
+    broken(lambda d: d["encoded_reads"][4]["nodes"][2].update(cluster=3))                 # cluster beyond cluster_num
+    lower = copy.deepcopy(ds)
+    lower["raw_reads"][0]["seq"] = lower["raw_reads"][0]["seq"].lower()                   # case is not compared (:333,:340)
+    D.sanity_check(lower)
 
 
 def test_training_pileups_are_truncated_before_unknown_chunks_are_dropped():
