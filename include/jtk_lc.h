@@ -299,7 +299,8 @@ int jtk_lc_normalize_pileup(uint32_t n_reads, uint32_t cluster_num, uint32_t *la
 int jtk_lc_trim_cache(int device);
 
 const char *jtk_lc_strerror(int status);
-/* Thread-local text of the last failure on this thread (HIP error strings etc.); "" if none. */
+/* Thread-local text of the last failure on this thread (HIP error strings etc.); "" if none.  The pointer is valid until
+ * this thread's next call into the library: copy the text before calling anything else. */
 const char *jtk_lc_last_error(void);
 int jtk_lc_version(void);
 /* 1 if a gfx950 device `device` is present and the kernels for it are loaded. */
