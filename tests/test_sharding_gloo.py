@@ -106,3 +106,40 @@ def test_result_gather_is_one_collective_of_labels_posteriors_k_and_score(tmp_pa
     world = 2
     mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(np.load(tmp_path / f"gather{r}.npy")[0] == 1 for r in range(world))
+
+
+def _gather8_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jtk_amd import sharding
+    # the headline data set's partition (2,500 chunks x 60 reads x 2 kbp, copy number 2) as bench.py --gpus 8 deals it
+    n_chunks, n_reads, stride = 2500, 60, 2
+    parts = sharding.strong_shards(n_chunks, n_reads, 2000, 2, world)
+    sizes = [(n_reads * len(p), len(p)) for p in parts]
+    g = sharding.ResultGather(dist, sizes, stride)
+
+    def payload(r):
+        n, c = sizes[r]
+        rng = np.random.default_rng(r)
+        return (rng.integers(0, 2, n).astype(np.uint32), rng.normal(size=(n, stride)), rng.integers(1, 3, c).astype(np.uint32),
+                rng.normal(size=c))
+    ok = sorted(int(c) for p in parts for c in p) == list(range(n_chunks))
+    ok = ok and max(len(p) for p in parts) - min(len(p) for p in parts) <= 1      # uniform chunks: LPT deals them evenly
+    for step in range(2):
+        got = g.gather(*payload(rank))
+        for r in range(world):
+            lab, post, k, sc = payload(r)
+            ok = ok and np.array_equal(got[r]["label"], lab) and np.array_equal(got[r]["log_post"], post)
+            ok = ok and np.array_equal(got[r]["cluster_num"], k) and np.array_equal(got[r]["score"], sc)
+    np.save(os.path.join(outdir, f"gather8_{rank}.npy"), np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_result_gather_at_eight_ranks_on_the_headline_partition(tmp_path):
+    """the exchange step of `bench.py --gpus 8` at its real sizes (312 / 313 chunks x 60 reads per rank, ~3 MB per step) on
+    eight gloo ranks: every rank receives every rank's labels, posteriors, cluster numbers and scores; no GPU involved"""
+    world = 8
+    mp.spawn(_gather8_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(np.load(tmp_path / f"gather8_{r}.npy")[0] == 1 for r in range(world))
