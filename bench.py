@@ -255,8 +255,22 @@ def main():
     if backend != "nccl":
         local_rank = 0
     if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run "
-                         f"--nproc-per-node {args.gpus} (one rank per GPU)")
+        if "WORLD_SIZE" in os.environ:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus disagree")
+        # `python3 bench.py --gpus N` as typed, without a launcher: start one rank per GPU as CHILD processes (nothing here has
+        # touched the GPU yet; a process that has must never be replaced by another), relay their output -- rank 0 prints the
+        # JSON line -- and return their exit code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stderr.write("bench.py: launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+        raise SystemExit(subprocess.call(cmd, env=env))
     # The library is built by __graft_entry__.build() BEFORE the bench (never inside a timed or profiled process, never
     # by N ranks at once).  Only a missing library is built here, by local rank 0.
     if not os.path.exists(ffi.LIB_PATH) or not os.path.exists(ffi.SYNTH_LIB_PATH):

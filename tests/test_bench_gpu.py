@@ -56,9 +56,12 @@ def test_one_rank_line_has_the_contract_fields(jtk_lib):
 
 
 def test_two_rank_strong_scaling_path(jtk_lib):
+    """`python3 bench.py --gpus 2` AS TYPED -- no launcher around it (the driver's N > 1 command has none either): bench.py
+    starts its own ranks as child processes and relays rank 0's line and the exit code."""
     env = dict(os.environ, JTK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--chunks", "24", "--steps", "2", "--warmup", "1", "--streams", "2", "--no-e2e"],
                        capture_output=True, text=True, cwd=ROOT, env=env, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -96,6 +99,8 @@ def test_eight_rank_run_of_the_full_dataset_matches_the_one_rank_run(jtk_lib, tm
 
 
 def test_gpus_flag_must_match_the_launch():
+    """under a launcher (WORLD_SIZE set) a --gpus that disagrees with it is an error, not a second launch"""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True,
-                       cwd=ROOT, timeout=300)
+                       cwd=ROOT, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
