@@ -25,13 +25,6 @@
 //    registers instead).
 #include "device_common.h"
 
-#ifdef JTK_PHMM_WITH_R2
-#include <stdlib.h>
-void launch_phmm_r2(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks, const ChunkState *state,
-                    DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2, double *scratch,
-                    uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, double *raw, int *rawG, double *lk,
-                    uint32_t max_tmpl, uint32_t max_read, int only_active, uint32_t skip_le_radius);
-#endif
 
 namespace {
 
@@ -769,14 +762,6 @@ void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const C
                  uint32_t *work_counter, uint32_t *ticket_base, double *raw, int *rawG, double *lk, uint32_t max_tmpl,
                  uint32_t max_read, int only_active, uint32_t skip_le_radius) {
     if (n_reads == 0) return;
-#ifdef JTK_PHMM_WITH_R2
-    if (getenv("JTK_PHMM_R2")) {
-        // the round-2 kernel resets its counter: give it the spare slot behind the ticket counters
-        launch_phmm_r2(s, n_reads, reads, chunks, state, bufs, ey, delta, hmm2, stripes.mem, stripes.stride, n_waves, work_counter + 3, raw,
-                       rawG, lk, max_tmpl, max_read, only_active, skip_le_radius);
-        return;
-    }
-#endif
     const size_t lds = phmm_lds_bytes(max_tmpl, max_read);
     const uint32_t base = *ticket_base;
     *ticket_base = base + n_reads + n_waves;  // every wave takes exactly one ticket past the end

@@ -633,6 +633,9 @@ __device__ __forceinline__ void xo_jump(Xo &x, const ulonglong2 *lds_tab) {
 // with probability 2^-14).  R rounds are written stage by stage so that their instruction streams interleave:
 // a lone wave pays ~8 cycles for a dependent instruction and ~4 for an independent one.
 #define PKEEP 48
+#ifndef JTK_K2_RANGE
+#define JTK_K2_RANGE 6u  // sizes around c_ref the conservative thresholds of mcmc_chain_k2 hold for
+#endif
 template <int R>
 __device__ __forceinline__ void producer_parse(const uint64_t *ring, uint32_t *rec, uint32_t base, uint32_t n, uint32_t lane) {
     const uint64_t zone = ((uint64_t)n << __clzll((long long)n)) - 1;
@@ -1605,7 +1608,8 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
         return S;
     };
     double lk = exact_eval(tg0, tg1, pk0, pk1, pair_at(c0));
-    double pair_up = pair_at(c0 + 1), pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
+    auto pair_up = [&]() -> double { return pair_at(c0 + 1); };
+    auto pair_dn = [&]() -> double { return pair_at(c0 > 0 ? c0 - 1 : 0); };
     // ---- the table: for "flip read `lane`" in the current state, the order-free sum of its column terms and
     //      whether flip + flip-back would leave a rounding residue; thresholds follow from those and the size terms
     double sum_l[NR];
@@ -1635,19 +1639,53 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
             pert_l[r] = pert;
         }
     };
-    float thr_tab[NR];
-    auto thresholds = [&]() {
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const bool a = bit128(lab, ri[r]);
-            thr_tab[r] = reject_threshold(((a ? pair_up : pair_dn) + sum_l[r]) - lk, pert_l[r]);
-        }
-    };
+    double max = lk;
     // ---- size-only moves (a read with an all-zero row): with the column sums fixed, get_lk is a function of the
     //      cluster-0 size alone.  Lane c holds G[c] = get_lk at size c (the same left-to-right sum), and for the
-    //      move to size c' the new likelihood is G[c'] exactly.  Built on demand, stale once a column sum moves.
+    //      move to size c' the new likelihood is G[c'] exactly.  Rebuilt with the column sums (only for pile-ups that have
+    //      such reads).  While lk == G[c0] bit for bit -- it is after every accepted move -- an accepted size-only move is
+    //      settled from tables over sizes too (round 3 spent ~1,200 cycles on each of up to 2.7e5 of them per chunk: f64
+    //      difference, two exp, five scalar crossings, every read's threshold and the window's hop words again):
+    //        HS[c]        max(pair(c+1), pair(c-1)) - G[c]: the size part of proposed - lk, the larger of the two directions;
+    //        AU / AD[c]   the quick ACCEPT test of the exact step for the move to c + 1 / c - 1: u + 2^-19 < AU / AD[c];
+    //        RU / RD[c]   its quick REJECT test: u > RU / RD[c];   ndu / ndd: exp(diff) == 1.0, no draw is taken;
+    //        gmax         the sizes whose G exceeds the best likelihood seen.
+    //      and the rejection thresholds of ALL reads are evaluated against hs_bound = max HS over the sizes within JTK_K2_RANGE
+    //      of c_ref (both directions): conservative, so they -- and the hop words -- survive an accepted size-only move.  A
+    //      proposal the conservative threshold lets through is an event like any other and is decided exactly.
     double Gtab[NR];
-    bool gtab_ok = false;
+    float HS[NR], AU[NR], AD[NR], RU[NR], RD[NR];
+    unsigned long long ndu[NR], ndd[NR], gmax[NR];
+    const bool has_null = ubool(NR == 2 ? (nullm[0] | nullm[NR - 1]) != 0ull : nullm[0] != 0ull);
+    bool lk_tab = false;   // the tables are current and lk == G[c0]
+    bool lk_lazy = false;  // lk has not been fetched from G[c0] since the last fast size-only move
+    float hs_bound = 0.0f;
+    uint32_t c_ref = 0;
+    auto next_size = [&](const double *v, int r) -> double {  // lane c of register r <- entry 64 r + c + 1
+        const double a = from_next_lane(v[r]);
+        if (NR == 2) {
+            const double b = from_next_lane(v[NR - 1 - r]);
+            return lane == 63u ? b : a;
+        }
+        return a;
+    };
+    auto prev_size = [&](const double *v, int r) -> double {  // lane c of register r <- entry 64 r + c - 1
+        const double a = from_prev_lane(v[r]);
+        if (NR == 2) {
+            const double b = from_prev_lane(v[NR - 1 - r]);
+            return lane == 0u ? b : a;
+        }
+        return a;
+    };
+    auto tab32 = [&](const float *tab, uint32_t i) -> float {
+        const int v = NR == 2 && i >= 64 ? __builtin_amdgcn_readlane(__float_as_int(tab[NR - 1]), (int)(i & 63u))
+                                         : __builtin_amdgcn_readlane(__float_as_int(tab[0]), (int)(i & 63u));
+        return __int_as_float(v);
+    };
+    auto refresh_gmax = [&]() {
+#pragma unroll
+        for (int r = 0; r < NR; r++) gmax[r] = __ballot(max < Gtab[r]);
+    };
     auto build_gtab = [&]() {
         double t0[NS], t1[NS];
         column_terms(tg0, tg1, pk0, pk1, t0, t1);
@@ -1667,14 +1705,71 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
             }
             Gtab[r] = G;
         }
-        gtab_ok = true;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const double G = Gtab[r];
+            const double du = next_size(Gtab, r) - G, dd = prev_size(Gtab, r) - G;  // proposed - lk of the two moves
+            const double pu = next_size(pair_v, r), pd = prev_size(pair_v, r);
+            HS[r] = (float)((pu < pd ? pd : pu) - G);
+            ndu[r] = __ballot(du >= -0x1p-54);  // gen_bool(1.0) draws nothing
+            ndd[r] = __ballot(dd >= -0x1p-54);
+            // the guard bands of the exact step: exp in f32 is good to ~1e-5 relative
+            const bool iu = du < -1e-3 && du > -44.4, id = dd < -1e-3 && dd > -44.4;
+            const float eu = __expf((float)du), ed = __expf((float)dd);
+            AU[r] = iu ? eu * 0.999f - 3e-7f : -1.0f;
+            AD[r] = id ? ed * 0.999f - 3e-7f : -1.0f;
+            RU[r] = du <= -44.4 ? -1.0f : (iu ? eu * 1.001f + 1.3e-6f : 2.0f);
+            RD[r] = dd <= -44.4 ? -1.0f : (id ? ed * 1.001f + 1.3e-6f : 2.0f);
+        }
+        refresh_gmax();
     };
-    double max = lk;
+    auto refresh_bound = [&]() {  // hs_bound over the sizes within JTK_K2_RANGE of the current one (tables current)
+        c_ref = c0;
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const uint32_t c = lane + 64u * r;
+            const bool in = c + JTK_K2_RANGE >= c0 && c <= c0 + JTK_K2_RANGE && c <= n;
+            m = fmaxf(m, in ? HS[r] : -__builtin_inff());
+        }
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xF, 0xF, false)));   // quad_perm [1,0,3,2]
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xF, 0xF, false)));  // row_half_mirror
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x140, 0xF, 0xF, false)));  // row_mirror
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0));
+        const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 16));
+        const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 32));
+        const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 48));
+        hs_bound = fmaxf(fmaxf(a, b), fmaxf(c, d));
+    };
+    float thr_tab[NR];
+    auto thresholds = [&]() {
+        if (lk_tab) {  // conservative over the sizes near c_ref and both directions: (pair + sum) - G[c] <= sum + hs_bound
+#pragma unroll
+            for (int r = 0; r < NR; r++) thr_tab[r] = reject_threshold(sum_l[r] + (double)hs_bound, pert_l[r]);
+            return;
+        }
+        const double pu = pair_up(), pd = pair_dn();
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const bool a = bit128(lab, ri[r]);
+            thr_tab[r] = reject_threshold(((a ? pu : pd) + sum_l[r]) - lk, pert_l[r]);
+        }
+    };
+    auto after_sums_moved = [&]() {  // the column sums changed: every read's sum, the size tables, every threshold
+        rebuild_sums();
+        lk_tab = false;
+        if (has_null) {
+            build_gtab();
+            lk_tab = ubool(lk == tab64(Gtab, c0));  // (false after a flip-back residue: lk is not a table entry then)
+            if (lk_tab) refresh_bound();
+        }
+        thresholds();
+    };
     unsigned long long argmax[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) argmax[r] = lab[r];
-    rebuild_sums();
-    thresholds();
+    after_sums_moved();
     const uint32_t total = 2000u * n;
     uint32_t t = 0, p = 0;
     Window wd;
@@ -1718,38 +1813,74 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
 #ifdef JTK_MCMC_STATS
             const unsigned long long n0c = __builtin_readcyclecounter();
 #endif
-            if (!gtab_ok) build_gtab();
-            // proposed - lk with the lk the chain carries (flip-back residues move the sums, not lk: :746), so this
-            // is NOT a difference of two table entries
-            const double diff = tab64(Gtab, old ? c0 + 1 : c0 - 1) - lk;
-            const bool nd = ubool(diff >= -0x1p-54);  // gen_bool(1.0) draws nothing
-            bool acc = true;
-            if (!nd) {
-                // u: the Bernoulli draw / 2^64 truncated to 19 bits (true value < u + 2^-19); pe within ~1e-5 relative
-                const float pe = __expf((float)diff);
-                const float u = reload ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd.u), (int)p));
-                const bool in_range = u >= 0.0f && diff < -1e-3 && diff > -44.4;
-                if (ubool(diff <= -44.4 || (in_range && u > pe * 1.001f + 1.3e-6f))) {
-                    acc = false;
-                } else if (!ubool(in_range && u + 0x1p-19f < pe * 0.999f - 3e-7f)) {
-                    rng_wait(rng, pos_v + 1);
-                    acc = ubool(bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff));  // (an out-of-line call returns in a vector register)
+            // u: the Bernoulli draw / 2^64 truncated to 19 bits (true value < u + 2^-19)
+            const float u = reload ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd.u), (int)p));
+            bool nd, acc, settled = false, moved = false;  // moved: the thresholds were re-made (the hop words are stale)
+            if (lk_tab && !reload) {
+                // the quick tests of the exact step below, from the tables: no f64, no exp, one scalar crossing each
+                nd = old ? bit128(ndu, c0) : bit128(ndd, c0);
+                acc = nd || ubool(u + 0x1p-19f < (old ? tab32(AU, c0) : tab32(AD, c0)));
+                settled = acc || ubool(u > (old ? tab32(RU, c0) : tab32(RD, c0)));
+                if (acc) {
+                    c0 = old ? c0 + 1 : c0 - 1;
+                    flip_label();
+                    lk_lazy = true;  // lk = G[c0], fetched when an exact step needs it
+                    if (bit128(gmax, c0)) {  // max < lk
+                        max = tab64(Gtab, c0);
+#pragma unroll
+                        for (int r = 0; r < NR; r++) argmax[r] = lab[r];
+                        refresh_gmax();
+                    }
                 }
             }
-            if (acc) {
-                c0 = old ? c0 + 1 : c0 - 1;
-                flip_label();
-                lk = tab64(Gtab, c0);
-                pair_up = pair_at(c0 + 1);
-                pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
-                if (ubool(max < lk)) new_max(lk);
+            if (!settled) {
+                if (lk_lazy) {
+                    lk = tab64(Gtab, c0);
+                    lk_lazy = false;
+                }
+                // proposed - lk with the lk the chain carries (flip-back residues move the sums, not lk: :746), so this
+                // is NOT a difference of two table entries
+                const double diff = tab64(Gtab, old ? c0 + 1 : c0 - 1) - lk;
+                nd = ubool(diff >= -0x1p-54);  // gen_bool(1.0) draws nothing
+                acc = true;
+                if (!nd) {
+                    // pe within ~1e-5 relative
+                    const float pe = __expf((float)diff);
+                    const bool in_range = u >= 0.0f && diff < -1e-3 && diff > -44.4;
+                    if (ubool(diff <= -44.4 || (in_range && u > pe * 1.001f + 1.3e-6f))) {
+                        acc = false;
+                    } else if (!ubool(in_range && u + 0x1p-19f < pe * 0.999f - 3e-7f)) {
+                        rng_wait(rng, pos_v + 1);
+                        acc = ubool(bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff));  // (an out-of-line call returns in a vector register)
+                    }
+                }
+                if (acc) {
+                    c0 = old ? c0 + 1 : c0 - 1;
+                    flip_label();
+                    lk = tab64(Gtab, c0);
+                    if (ubool(max < lk)) {
+                        new_max(lk);
+                        refresh_gmax();
+                    }
+                    if (!lk_tab) {  // lk is a table entry again: from here on the conservative thresholds
+                        lk_tab = true;
+                        refresh_bound();
+                        thresholds();
+                        moved = true;
+                    }
+                }
+            }
+            if (acc && (c0 + JTK_K2_RANGE < c_ref || c0 > c_ref + JTK_K2_RANGE)) {  // left the sizes the thresholds hold for
+                refresh_bound();
                 thresholds();
+                moved = true;
             }
             t++;
             const uint32_t pos_next = nd ? pos_v : pos_v + 1;
             ST_CNT(7, 1);
             ST_CNT(8, acc ? 1 : 0);
             ST_CNT(2, 1);
+            ST_CNT(1, settled ? 1 : 0);
             if (reload || pos_next - wd.base >= 64) {
                 window_load(wd, rng, pos_next, lane);
                 p = 0;
@@ -1757,12 +1888,16 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
                 ST_CNT(6, 1);
             } else {
                 p = pos_next - wd.base;
-                if (acc) hopw = hop_words<NR>(wd, thr_tab);
+                if (moved) hopw = hop_words<NR>(wd, thr_tab);
             }
 #ifdef JTK_MCMC_STATS
             ST_CNT(3, __builtin_readcyclecounter() - n0c);
 #endif
             continue;
+        }
+        if (lk_lazy) {
+            lk = tab64(Gtab, c0);
+            lk_lazy = false;
         }
         // ---- the event: one exact step
 #ifdef JTK_MCMC_STATS
@@ -1788,7 +1923,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
             K0[d] = pk0[d] + k0;
             K1[d] = pk1[d] - k0;
         }
-        const double proposed = exact_eval(T0, T1, K0, K1, old ? pair_up : pair_dn);
+        const double proposed = exact_eval(T0, T1, K0, K1, old ? pair_up() : pair_dn());
         const double diff = proposed - lk;
         // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
         // exactly when diff >= -2^-54
@@ -1816,8 +1951,6 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
                 pk1[d] = K1[d];
             }
             c0 = old ? c0 + 1 : c0 - 1;
-            pair_up = pair_at(c0 + 1);
-            pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
             flip_label();
             lk = proposed;
             if (ubool(max < lk)) new_max(proposed);
@@ -1846,11 +1979,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
         ST_CNT(7, 1);
         ST_CNT(8, accept ? 1 : 0);
         ST_CNT(9, changed == 2 ? 1 : 0);
-        if (changed) {
-            gtab_ok = false;
-            rebuild_sums();
-            thresholds();
-        }
+        if (changed) after_sums_moved();
         if (reload || pos_next - wd.base >= 64) {
             window_load(wd, rng, pos_next, lane);
             p = 0;
@@ -2488,7 +2617,7 @@ int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, Chunk
     lds_k = clamp_k(lds_k);
     const size_t lds = mcmc_lds_bytes(lds_n, lds_d, lds_k);
     if (mcmc_upload_jump_table(s) != 0) return -1;  // the caller fails the call: nothing was launched
-    const uint32_t flags = 0u;  // (reserved)
+    static const uint32_t flags = getenv("JTK_MCMC_LEGACY") ? 1u : 0u;  // differential testing only
     static const bool no_split = getenv("JTK_MCMC_SPLIT") && atoi(getenv("JTK_MCMC_SPLIT")) == 0;
     if (!split || no_split || flags || rng_resume) {
         mcmc_kernel<<<n_chunks, 128, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,

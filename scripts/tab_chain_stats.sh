@@ -1,6 +1,6 @@
 #!/bin/bash
 # Diagnostic (GPU box): where the table-driven chain (mcmc_chain_tab) spends its cycles, on full-size 4-copy pile-ups,
-# and its kernel time next to the one-proposal-per-iteration chain (JTK_MCMC_LEGACY=1).
+# (the one-proposal-per-iteration chain it used to be timed against left the product sources in round 4: git history).
 set -u
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 cat > /tmp/tabrun.py <<'PY'
@@ -17,9 +17,6 @@ with api.Session(p, b) as s:
 print("MCMCMS", t["kernel_ms"]["mcmc"], "k", r["result"]["cluster_num"].tolist(), "D", r["result"]["n_variants"].tolist())
 PY
 python3 /tmp/tabrun.py 8 2>&1 | grep MCMCMS
-# the legacy chain is not in the product build: build it in (one register-hungry wave per SIMD), run, rebuild
-export JTK_LC_LIB=$(python3 -c "import jtk_amd.build as b; print(b.build_experiment('probe1', '''-DJTK_MCMC_WITH_LEGACY -DJTK_MCMC_WAVES=1'''))") || exit 1
-JTK_MCMC_LEGACY=1 python3 /tmp/tabrun.py 8 2>&1 | grep MCMCMS
 export JTK_LC_LIB=$(python3 -c "import jtk_amd.build as b; print(b.build_experiment('probe2', '''-DJTK_MCMC_STATS'''))") || exit 1
 python3 /tmp/tabrun.py 2 > gpurun_out/tabstat_raw.txt 2>&1
 python3 - <<'PY'

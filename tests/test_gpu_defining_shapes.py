@@ -86,3 +86,63 @@ def test_one_call_mixing_the_pair_hmm_kernels_matches_the_oracle(jtk_lib, oracle
     ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
     assert ora["rc"] == 0
     check_equal(dev, ora, b)
+
+
+# ---- BASELINE cfg 4 (4 copies x 40 reads x 2 kbp): the configuration where the K-way table chain (mcmc_chain_tab<K>) is the
+#      whole cost.  Round 3 covered it with two chunks.
+
+def test_cfg4_golden_16_chunks(jtk_lib):
+    """tests/golden/cfg4_16.npz (made by the oracle, tests/golden/make_cfg4_16.py): sixteen 160-read pile-ups through K = 2, 3, 4
+    with no oracle in the loop"""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_cfg3_64
+    import make_cfg4_16
+    g = np.load(os.path.join(HERE, "golden", "cfg4_16.npz"))
+    b, cfg, p = make_cfg4_16.make_inputs()
+    assert make_cfg3_64.inputs_digest(b) == str(g["inputs_sha256"][0]), "the generator no longer produces the golden's inputs"
+    assert int(b.chunks["n_reads"].min()) == 160 and int(b.chunks["copy_num"][0]) == 4
+    dev = api.cluster_chunks(p, b)
+    check_equal(dev, dict(result=g["result"], label=g["label"], log_post=g["log_post"], cons=g["cons"], cons_off=g["cons_off"]), b)
+    assert g["result"]["cluster_num"].max() >= 3
+
+
+def test_16_chunks_of_cfg4_match_the_oracle(jtk_lib, oracle):
+    """sixteen more (chunk ids 4300 .. 4315: other RNG streams than the golden's) against the oracle run on the box's CPUs"""
+    b, cfg = synth.make_batch("ont_4copy", 16, first_chunk_id=4300, min_variants=2)
+    p = jb.default_params(cfg["coverage"], cfg["band_frac"])
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
+    assert ora["rc"] == 0
+    check_equal(dev, ora, b)
+
+
+def test_copy_numbers_3_5_6_7_at_40_reads_per_copy_match_the_oracle(jtk_lib, oracle):
+    """every K the chain kernel is instantiated for beyond the diploid one, at 40 reads per copy (120 .. 280 reads: the
+    register tables, and from 256 reads the LDS tables of mcmc_chain_tab), one pile-up each in ONE call"""
+    base = dict(synth.CONFIGS["ont_4copy"])
+    piles = []
+    for i, k in enumerate((3, 5, 6, 7)):
+        cfg = dict(base, n_haps=k, copy_num=k, tmpl_len=900, divergence=4e-3)
+        piles.append(synth.make_pileup(8800 + 7 * i, cfg, synth.SEED0, 2))
+    b = jb.pack(piles)
+    assert b.chunks["n_reads"].tolist() == [120, 200, 240, 280]
+    p = jb.default_params(base["coverage"], base["band_frac"])
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
+    assert ora["rc"] == 0
+    check_equal(dev, ora, b)
+    assert ora["result"]["cluster_num"].max() >= 3
+
+
+def test_parity_campaign_seed_31_four_copy_slice(jtk_lib, oracle):
+    """scripts/parity_campaign.sh, seed 31, its four-copy leg (scripts/parity_headline.py 12 33 ont_4copy) cut to six random
+    chunk ids: promoted from a builder-run log to a test"""
+    rng = np.random.default_rng(33)
+    ids = [int(x) for x in rng.integers(0, 1 << 40, 6)]
+    base = dict(synth.CONFIGS["ont_4copy"])
+    b = jb.pack([synth.make_pileup(i, base, synth.SEED0, 1) for i in ids])
+    p = jb.default_params(base["coverage"], base["band_frac"])
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
+    assert ora["rc"] == 0
+    check_equal(dev, ora, b)
