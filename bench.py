@@ -173,19 +173,10 @@ def stage_e2e(params0, batch, cfg, device, record_path=None):
     # batches, so a chunk's time is its share of the batch's kernel time per family -- pair-HMM and polish by band cells x
     # passes, the chain by proposals
     res = out["result"]
-    passes = np.minimum(res["polish_rounds"].astype(np.float64) + 1.0, 21.0)
-    diag = np.array([int(batch.chunks[c]["n_reads"]) * int(batch.chunks[c]["tmpl_len"])
-                     + int(batch.read_off[batch.chunk_reads(c).stop] - batch.read_off[batch.chunk_reads(c).start])
-                     for c in range(batch.n_chunks)], dtype=np.float64)
-    w_dp = passes * diag
-    k_tried = np.maximum(1, np.minimum(int(cfg["copy_num"]), 1 + 2 * res["n_variants"].astype(np.int64)) - 1)
-    w_mc = n * k_tried * (res["n_variants"] > 0)
-    km = tm["kernel_ms"]
-    polish_ms = (km["phmm"] + km["polish"]) * w_dp / max(w_dp.sum(), 1.0)
-    elapsed = polish_ms + km["filter"] / batch.n_chunks + km["mcmc"] * w_mc / max(float(w_mc.sum()), 1.0)
-    clen = np.diff(out["cons_off"]).astype(np.int64)
-    rows = [f"RECORD\t{int(batch.chunks[c]['chunk_id'])}\t{elapsed[c]:.3f}\t{polish_ms[c]:.3f}\t{int(clen[c])}\t"
-            f"{float(res['score'][c]):.3f}\t{int(n[c])}" for c in range(batch.n_chunks)]
+    rows = api.record_rows(batch.chunks["chunk_id"], batch.chunks["n_reads"], batch.chunks["tmpl_len"],
+                           [int(batch.read_off[batch.chunk_reads(c).stop] - batch.read_off[batch.chunk_reads(c).start])
+                            for c in range(batch.n_chunks)], batch.chunks["copy_num"], res,
+                           np.diff(out["cons_off"]).astype(np.int64), tm)
     if record_path:
         with open(record_path, "w") as fh:
             fh.write("\n".join(rows) + "\n")
@@ -194,30 +185,29 @@ def stage_e2e(params0, batch, cfg, device, record_path=None):
     return ph, out
 
 
+PMC_PROFILE = "r04_pmc_traffic.json"
+
+
 def pmc_traffic(workload, sha):
-    """HBM bytes per launch per kernel family from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
-    doubled per the gfx950 correction), but only when they were taken on THIS build of the library (same kernel sources and flags, or the same .so) and this workload;
-    otherwise None: a stale profile says nothing about the kernels being timed."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    """HBM bytes per PASS of the workload per kernel family from the rocprofv3 PMC passes committed under profiles/ --
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the profile / the passes in it (FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md) -- but only when they were taken on THIS build of the library (same kernel sources and
+    flags, or the same .so), on this workload, and with nothing but full-workload launches in the profile; otherwise None: a
+    stale profile says nothing about the kernels being timed."""
+    path = os.path.join(ROOT, "profiles", PMC_PROFILE)
     try:
         prof = json.load(open(path))
     except (OSError, ValueError):
-        return None, "no profiles/r03_pmc_traffic.json"
+        return None, "no profiles/" + PMC_PROFILE
     src = jbuild.source_sha16()
     if prof.get("src_sha16") != src and prof.get("lib_sha16") != sha:
-        return None, (f"profiles/r03_pmc_traffic.json was taken on kernel sources {prof.get('src_sha16')} "
+        return None, (f"profiles/{PMC_PROFILE} was taken on kernel sources {prof.get('src_sha16')} "
                       f"(library {prof.get('lib_sha16')}), this is {src} ({sha})")
     if prof.get("workload") != workload:
-        return None, f"profiles/r03_pmc_traffic.json is for workload {prof.get('workload')}"
-    out = {}
-    for fam, kernels in prof["kernel_family"].items():
-        tot = 0.0
-        for k in kernels:
-            e = prof["kernels"].get(k)
-            if e:
-                tot += (2.0 * e.get("FETCH_SIZE_KiB_per_launch", 0.0) + e.get("WRITE_SIZE_KiB_per_launch", 0.0)) * 1024.0
-        out[fam] = tot
-    return out, None
+        return None, f"profiles/{PMC_PROFILE} is for workload {prof.get('workload')}"
+    if not prof.get("full_workload_launches_only") or "family_bytes_per_pass" not in prof:
+        return None, f"profiles/{PMC_PROFILE} mixes launches of other batch sizes"
+    return dict(prof["family_bytes_per_pass"]), None
 
 
 def main():
@@ -250,6 +240,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # What the FIRST stage call of a fresh process costs (device workspaces are mapped for the first time: the pipeline's
+    # situation), measured where the driver can see it: a child process, run to completion before this one touches the GPU.
+    fresh = None
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_e2e and os.path.exists(ffi.LIB_PATH):
+        import subprocess
+        wl0 = WORKLOADS[args.workload]
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cold_call.py"), str(args.chunks or wl0["chunks"]),
+                                wl0["config"], "1"], capture_output=True, text=True, timeout=600)
+            rows = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and rows:
+                c0 = json.loads(rows[-1])["calls"][0]
+                fresh = dict(first_call_seconds=c0["seconds"], held_gb=c0["held_gb"], h2d_ms=c0["h2d_ms"], d2h_ms=c0["d2h_ms"],
+                             note="scripts/cold_call.py as a child process before this one touched the GPU: one "
+                                  "jtk_lc_cluster_chunks on the whole workload from host buffers, the process's first call")
+            else:
+                fresh = dict(error=(r.stderr or r.stdout)[-300:])
+        except Exception as e:  # the bench line must not depend on it
+            fresh = dict(error=repr(e))
     # diagnostic / CPU-box tests: JTK_BENCH_BACKEND=gloo runs the multi-rank path with every rank on GPU 0
     backend = os.environ.get("JTK_BENCH_BACKEND", "nccl")
     if backend != "nccl":
@@ -490,9 +499,35 @@ def main():
              "serial pass's pair-HMM device time, vs the 78.6 TFLOP/s vector f64 peak; chain_cycles_per_proposal: the "
              "chain kernel's launch duration (set by its slowest chunk) x 2.4 GHz / that chunk's 20 x 2000 x n x "
              "(#k tried) proposals")
+    # the pair-HMM family's forward state: (toM, toD) of every anti-diagonal, 1 KiB, written by the forward and read by the
+    # backward sweep of every read and pass -- what the kernel moves BY CONSTRUCTION, next to what the counters saw
+    stripe_bytes = 0.0
+    for c in range(batch.n_chunks):
+        ch = batch.chunks[c]
+        r0, r1 = int(ch["read_first"]), int(ch["read_first"]) + int(ch["n_reads"])
+        diags = int(ch["n_reads"]) * (int(ch["tmpl_len"]) + 24) + int(batch.read_off[r1] - batch.read_off[r0])
+        stripe_bytes += float(passes[c]) * diags * 1024.0 * 2.0
+    launches_dom = max(1, serial_launch[dom])
+    fam_pass = (traffic or {}).get("phmm")
+    stream = dict(
+        family="phmm", kernels=KERNELS_OF_FAMILY.get("phmm"), serial_ms_per_pass=serial_k["phmm"],
+        stripe_bytes_per_pass_by_construction=stripe_bytes,
+        by_construction=dict(GBps=stripe_bytes / 1e9 / phmm_s if phmm_s > 0 else None,
+                             frac_of_8TBps=stripe_bytes / 1e9 / phmm_s / HBM_PEAK_GBPS if phmm_s > 0 else None,
+                             frac_of_achievable_6p3TBps=stripe_bytes / 1e9 / phmm_s / 6300.0 if phmm_s > 0 else None),
+        pmc_bytes_per_pass=fam_pass,
+        pmc=None if not fam_pass else dict(GBps=fam_pass / 1e9 / phmm_s, frac_of_8TBps=fam_pass / 1e9 / phmm_s / HBM_PEAK_GBPS,
+                                           frac_of_achievable_6p3TBps=fam_pass / 1e9 / phmm_s / 6300.0),
+        note="the pair-HMM family is bound by this stream, not by the 124 KB per chunk of the algorithmic figure: bytes per pass "
+             "of the workload over the serial pass's pair-HMM device time.  by_construction = sum over chunks of passes x "
+             "(anti-diagonals of its reads) x 1 KiB x (write + read back); pmc = (2 x FETCH_SIZE + WRITE_SIZE) of the family's "
+             "kernels from the committed profile of this build (tables and row sums included); 6.3 TB/s = the float4-copy rate "
+             "of MI355X_MICROARCH.md")
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS * world, unit="GB/s",
                     frac=achieved / (HBM_PEAK_GBPS * world),
-                    traffic=(traffic or {}).get(dom) if traffic else None, traffic_note=traffic_note,
+                    traffic=(traffic[dom] / launches_dom) if traffic and dom in traffic else None, traffic_note=traffic_note,
+                    traffic_unit="HBM bytes per launch of the dominant family = its bytes per pass / its launches per pass",
+                    stream=stream,
                     algorithmic_bytes_per_chunk=alg_bytes_per_chunk,
                     dominant_kernel=dict(
                         name=dom, kernels=KERNELS_OF_FAMILY.get(dom), launches_per_pass=serial_launch[dom], ms_per_pass=serial_k[dom],
@@ -504,7 +539,7 @@ def main():
                                      kernel_ms_sum=sum(serial_k.values()),
                                      note="slices run one after another: the kernel times add up to <= wall_ms"),
                     overlapped_kernel_ms_per_step=overl_k,
-                    hbm_traffic_by_kernel=traffic, secondary=secondary,
+                    hbm_traffic_per_pass_by_family=traffic, secondary=secondary,
                     note="achieved = value x algorithmic bytes per chunk (SURVEY.md 8d: packed 4-bit bases, 2-bit ops, u32 "
                          "labels, f64 posteriors), frac = achieved / (8 TB/s x n_gpus).  Byte/integer + f64 scan work: the "
                          "compulsory HBM traffic is ~126 KB/chunk, so the HBM fraction is tiny by construction; the binding "
@@ -548,38 +583,46 @@ def main():
     #      0 of the 8-way LPT partition of the same dataset, as slices on this GPU, same step definition.  A measured per-GPU
     #      rate, not a scaling curve: no RCCL, no second device.
     if world == 1 and args.scaling == "strong" and not args.no_shard8 and n_total >= 64:
-        ids8 = sharding.strong_shards(n_total, reads_per_chunk, cfg0["tmpl_len"], cfg0["copy_num"], 8)[0]
-        pos = np.searchsorted(np.asarray(my_ids), ids8)        # world == 1: my_ids is 0..n_total-1
-        sh = batch.subset(pos)
-        nb = max(1, min(args.streams, sh.n_chunks))
-        bd = [round(i * sh.n_chunks / nb) for i in range(nb + 1)]
-        sess8 = [api.Session(params, sh.subset(range(bd[i], bd[i + 1])), device=local_rank) for i in range(nb)]
+        parts8 = sharding.strong_shards(n_total, reads_per_chunk, cfg0["tmpl_len"], cfg0["copy_num"], 8)
+        steps8 = max(1, min(args.steps, 2))
+        per_rank = []
+        for r8 in range(8):    # every rank's shard, one after the other on THIS GPU: the job's step is the slowest rank's
+            pos = np.searchsorted(np.asarray(my_ids), parts8[r8])        # world == 1: my_ids is 0..n_total-1
+            sh = batch.subset(pos)
+            nb = max(1, min(args.streams, sh.n_chunks))
+            bd = [round(i * sh.n_chunks / nb) for i in range(nb + 1)]
+            sess8 = [api.Session(params, sh.subset(range(bd[i], bd[i + 1])), device=local_rank) for i in range(nb)]
 
-        def run8(k):
-            def w(i):
-                for _ in range(k):
-                    sess8[i].run(skip_polish=False)
-                    sess8[i].fetch_results()
-            ths = [threading.Thread(target=w, args=(i,)) for i in range(nb)]
-            for th in ths:
-                th.start()
-            for th in ths:
-                th.join()
+            def run8(k):
+                def w(i):
+                    for _ in range(k):
+                        sess8[i].run(skip_polish=False)
+                        sess8[i].fetch_results()
+                ths = [threading.Thread(target=w, args=(i,)) for i in range(nb)]
+                for th in ths:
+                    th.start()
+                for th in ths:
+                    th.join()
 
-        run8(1)
-        torch.cuda.synchronize()
-        t8 = time.perf_counter()
-        run8(args.steps)
-        torch.cuda.synchronize()
-        dt8 = (time.perf_counter() - t8) / args.steps
-        for s8 in sess8:
-            s8.close()
+            run8(1)
+            torch.cuda.synchronize()
+            t8 = time.perf_counter()
+            run8(steps8)
+            torch.cuda.synchronize()
+            per_rank.append(dict(rank=r8, chunks=int(sh.n_chunks), ms_per_step=(time.perf_counter() - t8) / steps8 * 1e3))
+            for s8 in sess8:
+                s8.close()
+        worst = max(per_rank, key=lambda x: x["ms_per_step"])
+        dt8 = worst["ms_per_step"] / 1e3
         line["shard8_projection"] = dict(
-            chunks=int(sh.n_chunks), slices=nb, ms_per_step=dt8 * 1e3, chunks_per_s_one_gpu=sh.n_chunks / dt8,
-            projected_8gpu_chunks_per_s=8 * sh.n_chunks / dt8, projected_efficiency_vs_8x=(8 * sh.n_chunks / dt8) / (8 * value),
-            note="rank 0's share of the 8-way LPT partition run on THIS GPU (same step, incl. fetch); the 8-GPU figure is 8 x "
-                 "that rate and leaves out the one all-gather per step (~3 MB).  NOT a measured scaling curve: no run of this "
-                 "code on more than one GPU exists")
+            chunks=worst["chunks"], slices=min(args.streams, worst["chunks"]), ms_per_step=worst["ms_per_step"],
+            ms_per_step_by_rank=[round(x["ms_per_step"], 1) for x in per_rank], chunks_by_rank=[x["chunks"] for x in per_rank],
+            chunks_per_s_one_gpu=worst["chunks"] / dt8, projected_8gpu_chunks_per_s=n_total / dt8,
+            projected_efficiency_vs_8x=(n_total / dt8) / (8 * value), steps=steps8,
+            note="each rank's share of the 8-way LPT partition run on THIS GPU, one after the other (same step, incl. fetch); the "
+                 "job's step is the SLOWEST rank's (max over ranks, as bench.py times N > 1), so the 8-GPU figure is n_chunks / "
+                 "that; the one all-gather per step (~3 MB) is left out.  NOT a measured scaling curve: no run of this code on "
+                 "more than one GPU exists")
     # ---- end to end: what one stage call costs a host that hands over HOST buffers (encode + allocate + H2D + run +
     #      fetch + free): jtk_lc_cluster_chunks on this rank's shard.  PCIe-inclusive; never `value`.
     if not args.no_e2e:
@@ -591,7 +634,7 @@ def main():
         one = api.cluster_chunks(params, batch, device=local_rank)
         warm = time.perf_counter() - t2
         tm = api.last_timing()
-        line["e2e"] = dict(chunks_per_s=batch.n_chunks / warm, seconds=warm, first_call_seconds=cold,
+        line["e2e"] = dict(chunks_per_s=batch.n_chunks / warm, seconds=warm, first_call_seconds=cold, fresh_process=fresh,
                            h2d_ms=tm["h2d_ms"], d2h_ms=tm["d2h_ms"], pool_gb=float(os.environ["JTK_LC_POOL_GB"]), matches_resident=bool(np.array_equal(one["label"], out["label"])),
                            note="jtk_lc_cluster_chunks on this rank's shard from host buffers to host buffers; the first call "
                                 "also maps the device workspaces, the second reuses the pooled blocks")

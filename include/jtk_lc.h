@@ -22,7 +22,10 @@
 extern "C" {
 #endif
 
-#define JTK_LC_ABI_VERSION 1
+/* Bumped whenever a public struct changes size or an entry point gains a precondition; a host compares it with
+ * jtk_lc_version() before the first call.  2: jtk_lc_timing_t grew by chain_lds_bytes[2] (round 3) and
+ * jtk_lc_cluster_chunks_multi checks the contiguous read_first layout itself (see there). */
+#define JTK_LC_ABI_VERSION 2
 
 /* kiley::hmm::NUM_ROW = 8 + COPY_SIZE + DEL_SIZE (pseudo_mcmc.rs:7,172,447): rows 0-3 substitute to
  * ACGT, 4-7 insert ACGT before the position, 8-10 copy 1-3 bp, 11-13 delete 1-3 bp. */
@@ -133,7 +136,10 @@ int jtk_lc_cluster_chunks(const jtk_lc_params_t *params, size_t n_chunks, const 
  * dealt to `devices` by longest-processing-time-first over a cost model (pair-HMM cells + Metropolis steps per candidate k;
  * the partition bench.py / jtk_amd.sharding use between ranks), each share is gathered into its own batch and runs as on a
  * single device (sliced, overlapped), and the outputs are scattered back into the caller's order, laid out as above.  Chunks are independent (one RNG stream per chunk id), so results do not depend on
- * the device list; the path has no exchange step and no collective runs.  A device may be listed more than once. */
+ * the device list; the path has no exchange step and no collective runs.  A device may be listed more than once.
+ * Precondition (checked here since ABI 2, as the single-device call always did when it built its session): the chunks' reads
+ * are laid out back to back in chunk order (chunks[0].read_first == 0, chunks[c + 1].read_first == chunks[c].read_first +
+ * chunks[c].n_reads) -- JTK_ERR_INVALID_ARG otherwise. */
 int jtk_lc_cluster_chunks_multi(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
                                 const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
                                 const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,

@@ -231,3 +231,19 @@ def normalize_pileup(label, log_post, cluster_num):
     check(ffi.lib().jtk_lc_normalize_pileup(len(label), int(cluster_num), u32p(label), f64p(log_post),
                                             log_post.shape[1]))
     return label, log_post
+
+
+def record_rows(chunk_ids, n_reads, tmpl_len, read_bases_per_chunk, copy_num, result, cons_len, timing):
+    """The reference's per-chunk `RECORD` lines (local_clustering/mod.rs:121: chunk id, elapsed ms, polish ms, consensus
+    length, score, coverage).  The device runs the chunks of a call together, so a chunk's time is its SHARE of the call's
+    kernel time per family: pair-HMM and polishing by band cells x passes, the chain by proposals x candidate k."""
+    n = np.asarray(n_reads, dtype=np.float64)
+    passes = np.minimum(result["polish_rounds"].astype(np.float64) + 1.0, 21.0)
+    w_dp = passes * (n * np.asarray(tmpl_len, dtype=np.float64) + np.asarray(read_bases_per_chunk, dtype=np.float64))
+    k_tried = np.maximum(1, np.minimum(np.asarray(copy_num, dtype=np.int64), 1 + 2 * result["n_variants"].astype(np.int64)) - 1)
+    w_mc = n * k_tried * (result["n_variants"] > 0)
+    km = timing["kernel_ms"]
+    polish_ms = (km["phmm"] + km["polish"]) * w_dp / max(float(w_dp.sum()), 1.0)
+    elapsed = polish_ms + km["filter"] / max(1, len(n)) + km["mcmc"] * w_mc / max(float(w_mc.sum()), 1.0)
+    return ["RECORD\t%d\t%.3f\t%.3f\t%d\t%.3f\t%d" % (int(chunk_ids[c]), elapsed[c], polish_ms[c], int(cons_len[c]),
+                                                      float(result["score"][c]), int(n[c])) for c in range(len(n))]

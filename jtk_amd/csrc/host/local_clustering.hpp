@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -97,6 +98,11 @@ struct LocalClusteringOptions {
     // is written back.
     std::vector<std::pair<uint64_t, int>> *failed = nullptr;
     bool refit_model = true;  // run update_models_on_both_strands (mod.rs:58) before clustering, as the reference does
+    // The reference's per-chunk `debug!("RECORD\t{chunk_id}\t{elapsed}\t{polished_time}\t{len}\t{score:.3}\t{cov}")`
+    // (mod.rs:121), one line per chunk that was written back.  The device runs the chunks of a call together, so a chunk's
+    // milliseconds are its share of the call's kernel time (jtk_lc_last_timing): pair-HMM + polishing by band cells x passes,
+    // the chain by proposals x candidate k.  nullptr: no lines.
+    std::ostream *record = nullptr;
 };
 
 inline double band_frac(ReadType t) {  // definitions/src/lib.rs:173-175, 201-210
@@ -352,6 +358,33 @@ inline void local_clustering_selected(DataSet &ds, const std::unordered_set<uint
         chunk.seq.assign((const char *)cons.data() + cons_off[c], cons_off[c + 1] - cons_off[c]);
         chunk.score = result[c].score;
         chunk.cluster_num = result[c].cluster_num;
+    }
+    if (opt.record) {  // mod.rs:121
+        jtk_lc_timing_t tm;
+        if (jtk_lc_last_timing(&tm) == 0) {
+            std::vector<double> w_dp(chunks.size()), w_mc(chunks.size());
+            double s_dp = 0.0, s_mc = 0.0;
+            for (size_t c = 0; c < chunks.size(); c++) {
+                const double nr = chunks[c].n_reads;
+                const double bases = (double)(read_off[chunks[c].read_first + chunks[c].n_reads] - read_off[chunks[c].read_first]);
+                const double passes = std::min<double>(result[c].polish_rounds + 1.0, 21.0);
+                w_dp[c] = passes * (nr * chunks[c].tmpl_len + bases);
+                const int64_t kt = std::max<int64_t>(1, std::min<int64_t>(chunks[c].copy_num, 1 + 2 * (int64_t)result[c].n_variants) - 1);
+                w_mc[c] = result[c].n_variants > 0 ? nr * (double)kt : 0.0;
+                s_dp += w_dp[c];
+                s_mc += w_mc[c];
+            }
+            for (size_t c = 0; c < chunks.size(); c++) {
+                if (result[c].status != 0) continue;
+                const double polish_ms = (tm.kernel_ms[JTK_K_PHMM] + tm.kernel_ms[JTK_K_POLISH]) * w_dp[c] / std::max(s_dp, 1.0);
+                const double elapsed = polish_ms + tm.kernel_ms[JTK_K_FILTER] / (double)chunks.size() +
+                                       tm.kernel_ms[JTK_K_MCMC] * w_mc[c] / std::max(s_mc, 1.0);
+                char line[256];
+                snprintf(line, sizeof line, "RECORD\t%llu\t%.3f\t%.3f\t%llu\t%.3f\t%u\n", (unsigned long long)order[c], elapsed,
+                         polish_ms, (unsigned long long)(cons_off[c + 1] - cons_off[c]), result[c].score, chunks[c].n_reads);
+                *opt.record << line;
+            }
+        }
     }
     normalize_local_clustering(ds);  // mod.rs:82
 }

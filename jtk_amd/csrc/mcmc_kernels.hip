@@ -217,7 +217,10 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // registers" when a kernel body has to spill a 64-bit value across a call).
 struct LdsShape {
     uint32_t n, d, k, jump;  // capacity in reads / columns / clusters; the producer's jump table has a copy in LDS
+    uint64_t gws;            // 0, or the address of a global-memory workspace (mcmc_kernel_huge): whatever of the arrays sized
+                             // by n / d / k does not fit the JTK_HUGE_LDS bytes of LDS behind the ring goes there, in carve order
 };
+#define JTK_HUGE_LDS (128u * 1024u)  // dynamic LDS of mcmc_kernel_huge behind the ring and its control block
 struct Lds {
     RCtl *ctl;
     uint64_t *ring;      // RN raw draws
@@ -257,18 +260,39 @@ struct SzEnt {     // 32 bytes, read as two 16-byte vectors
 };
 
 // The carve (host twin: mcmc_lds_core).  `base` passes through an empty asm so that two carves are not merged across a call.
+template <bool HUGE = false>
 __device__ __forceinline__ Lds lds_carve(LdsShape sh_in) {
     LdsShape sh;
     sh.n = uni(sh_in.n);
     sh.d = uni(sh_in.d);
     sh.k = uni(sh_in.k);
     sh.jump = uni(sh_in.jump);
+    sh.gws = uni64(sh_in.gws);
     uint32_t base = 0;
     asm volatile("" : "+s"(base));
     unsigned char *p = jtk_mcmc_smem + base;
-    auto take = [&](size_t bytes) {
+    // mcmc_kernel_huge only: an array that does not fit what is left of JTK_HUGE_LDS lives in the chunk's global workspace.
+    // There every pointer is made from an integer that went through an empty asm: the optimizer must not try to prove an address
+    // space for a pointer that is LDS on one path and global on the other (hipcc 7.2 crashes in simplifycfg when it does).
+    uint64_t pl = 0, gl = sh.gws;
+    size_t lds_left = ~(size_t)0;
+    if (HUGE) {
+        pl = (uint64_t)(uintptr_t)p;
+        asm volatile("" : "+s"(pl));
+    }
+    auto take = [&](size_t bytes) -> unsigned char * {
+        bytes = (bytes + 15) & ~(size_t)15;
+        if (HUGE) {
+            const bool in_lds = bytes <= lds_left;
+            uint64_t q = in_lds ? pl : gl;
+            pl += in_lds ? bytes : 0;
+            gl += in_lds ? 0 : bytes;
+            lds_left -= in_lds ? bytes : 0;
+            asm volatile("" : "+s"(q));
+            return reinterpret_cast<unsigned char *>((uintptr_t)q);
+        }
         unsigned char *q = p;
-        p += (bytes + 15) & ~(size_t)15;
+        p += bytes;
         return q;
     };
     const uint32_t lds_n = sh.n, lds_d = sh.d, lds_k = sh.k;
@@ -278,6 +302,7 @@ __device__ __forceinline__ Lds lds_carve(LdsShape sh_in) {
     m.rec = (uint32_t *)take(sizeof(uint32_t) * RN);
     m.jump = sh.jump ? (ulonglong2 *)take(JUMP_TAB_BYTES) : nullptr;
     m.k2_stats = (unsigned long long *)take(16 * 8);
+    if (HUGE) lds_left = JTK_HUGE_LDS;  // from here on an array that does not fit goes to the workspace (host twin: mcmc_ws_bytes)
     m.data = (double *)take((size_t)lds_n * lds_d * 8);
     m.size_to_lk = (double *)take((size_t)(lds_n + 1) * 8);
     m.lfact = (double *)take((size_t)(lds_n + 1) * 8);
@@ -835,6 +860,323 @@ __device__ __forceinline__ double wave_sum_f64(double v) {  // order-free: for e
     v += dpp_f64<0x141>(v);  // row_half_mirror
     v += dpp_f64<0x140>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
     return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+// mcmc_with_filter (:704-762), generic in K, one proposal per iteration.  m.assign holds the k-means labels on entry, the
+// best-seen labels on exit.  This is the chain of mcmc_kernel_huge: pile-ups of more than JTK_MAX_PILEUP reads, or whose work
+// area exceeds a CU's LDS -- there the per-read arrays of `m` point into a GLOBAL-memory workspace (every access below goes
+// through generic pointers), the 10-bit read indices of the table-driven chains do not apply, and speed is not the point:
+// clustering_on_pileup (local_clustering/mod.rs:86-123) takes any depth, so this library does too.
+template <int K, bool SMALL>
+__device__ __forceinline__ double mcmc_chain(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
+    // size_to_lk[x] = max_{c=1..K} poisson_lk(x, cov*c)
+    LaneTab size_to_lk;
+#pragma unroll
+    for (int r = 0; r < (SMALL ? 1 : 4); r++) {
+        const uint32_t x = lane + 64 * r;
+        double mx = -__builtin_inf();
+        if (x <= n)
+            for (int c = 1; c <= K; c++) {
+                const double lam = cov * (double)c;
+                mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
+            }
+        size_to_lk.v[r] = mx;
+    }
+    // Pile-ups of more than 255 reads (high copy numbers: 8 copies x 40 reads) do not fit the four-register tables:
+    // sizes and labels then live in LDS (m.size_to_lk, m.assign in place, m.argmax), one extra round trip per look-up.
+    const bool big = !SMALL && n > 255u;
+    if (big) {
+        for (uint32_t x = lane; x <= n; x += 64) {
+            double mx = -__builtin_inf();
+            for (int c = 1; c <= K; c++) {
+                const double lam = cov * (double)c;
+                mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
+            }
+            m.size_to_lk[x] = mx;
+        }
+        wsync();
+    }
+    auto size_lk = [&](uint32_t x) -> double { return big ? unif64(m.size_to_lk[x]) : tab_get<SMALL>(size_to_lk, x); };
+    // ---- initial LKCounts in the reference's order (reads outer)
+    double tg[K];
+    int np[K], w[K], cl[K];
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        tg[c] = 0.0;
+        np[c] = 0;
+        w[c] = 0;
+        cl[c] = 0;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t c = uni(m.assign[i]);
+        Elem el = {0.0, 0, 0};
+        if (lane < D) el = elem_of(m.data[i * D + lane]);
+#pragma unroll
+        for (int cc = 0; cc < K; cc++)
+            if ((uint32_t)cc == c) {
+                tg[cc] += el.x;
+                np[cc] += el.dp;
+                w[cc] += el.pw;
+                cl[cc]++;
+            }
+    }
+    int totp = 0;  // reads with a positive value in this column: sum_c num_pos[c], constant along the chain
+    unsigned long long posm[K], infm[K];
+    const unsigned long long colm = D >= 64 ? ~0ull : ((1ull << D) - 1ull);
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        totp += np[c];
+        posm[c] = __ballot(0.0 < tg[c]) & colm;
+        infm[c] = __ballot(w[c] > 0);
+    }
+    LaneLabels assign, argmax;
+#pragma unroll
+    for (int r = 0; r < (SMALL ? 1 : 4); r++) {
+        const uint32_t i = lane + 64 * r;
+        assign.v[r] = i < n ? (int)m.assign[i] : 0;
+        argmax.v[r] = assign.v[r];
+    }
+    if (big) {
+        for (uint32_t i = lane; i < n; i += 64) m.argmax[i] = m.assign[i];
+        wsync();
+    }
+    // get_lk (:785-795) on a tentative state: size terms first, then clusters outer / columns inner, left to
+    // right; exactly-zero terms (unused column or total_gain <= 0) leave the f64 sum unchanged and are skipped.
+    auto get_lk = [&](const double *T, const int *P, const int *cls, const unsigned long long *pm,
+                      const unsigned long long *im) -> double {
+        double S = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; c++) S += size_lk((uint32_t)cls[c]);
+        int in_use = 0;
+        unsigned long long anym = 0;
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            in_use += (0.0 < T[c]) ? P[c] : 0;
+            anym |= pm[c] & im[c];  // some cluster is_informative (:818-822) on this column
+        }
+        // get_used_columns (:847-869): informative somewhere, and 2 * pos_in_neg < pos_in_use
+        const unsigned long long usedm = __ballot(3 * in_use > 2 * totp) & anym;
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            unsigned long long mm = usedm & pm[c];
+            while (mm) {
+                const uint32_t d = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1;
+                S += readlane_f64(T[c], d);
+            }
+        }
+        return S;
+    };
+    // The same quantity without the ordering (any order of the same terms: off by ~1e-12 at most).  The ordered sum
+    // costs a v_readlane + a dependent add per term; this costs one cross-lane reduction, and it is enough to see
+    // that a proposal is certainly rejected -- which > 96% of them are.
+    // (its size terms come from three small per-cluster tables -- the entry of the current size, of one read less and
+    // of one read more -- kept up to date on the rare accepts: no table look-up per proposal)
+    double sz0[K], szm[K], szp[K];
+    auto size_terms = [&](int c) {
+        const uint32_t x = (uint32_t)cl[c];
+        sz0[c] = size_lk(x);
+        szm[c] = x > 0 ? size_lk(x - 1) : 0.0;
+        szp[c] = x < n ? size_lk(x + 1) : 0.0;
+    };
+#pragma unroll
+    for (int c = 0; c < K; c++) size_terms(c);
+    auto approx_lk = [&](const double *T, const int *P, uint32_t from, uint32_t to, const unsigned long long *pm,
+                         const unsigned long long *im) -> double {
+        double S = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; c++) S += (uint32_t)c == from ? szm[c] : ((uint32_t)c == to ? szp[c] : sz0[c]);
+        int in_use = 0;
+        unsigned long long anym = 0;
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            in_use += (0.0 < T[c]) ? P[c] : 0;
+            anym |= pm[c] & im[c];
+        }
+        const unsigned long long usedm = __ballot(3 * in_use > 2 * totp) & anym;
+        const bool used = (usedm >> lane) & 1ull;
+        double loc = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; c++) loc += (used && 0.0 < T[c]) ? T[c] : 0.0;
+        return S + wave_sum_f64(loc);
+    };
+    double lk = get_lk(tg, np, cl, posm, infm);
+    double max = lk;
+    const uint32_t total = 2000u * n;
+#ifdef JTK_MCMC_STATS
+    unsigned long long gs[6] = {0, 0, 0, 0, 0, 0};
+#define GS_MARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); gs[k] += now_ - gs_t; gs_t = now_; }
+#else
+#define GS_MARK(k)
+#endif
+    // Proposals are parsed from the 64-draw register window, not draw by draw.  A proposal is gen_range(0..n) -- the
+    // first draw at or after its start whose widening product passes the zone test -- and then, for i = 1..K-1,
+    // gen_index(i) on the upper halves of the following draws, each with its own zone test; the pick is the last i
+    // whose index came out 0 (choose_pos).  Which draws pass which test, and which give index 0, depends on the draws
+    // only: one ballot each per window, after which a proposal is a few scalar shift / find-first-set steps instead of
+    // ~6 rejection loops on values that have to cross from the vector to the scalar side one at a time.
+    uint32_t wp_base = 0xfffffff0u, wp_hi = 0;
+    unsigned long long wp_ok0 = 0, wp_ok[K], wp_z[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) wp_ok[i] = wp_z[i] = 0;
+    const uint64_t zone_n = ((uint64_t)n << __clzll((long long)n)) - 1;
+    for (uint32_t t = 0; t < total; t++) {
+#ifdef JTK_MCMC_STATS
+        unsigned long long gs_t = __builtin_readcyclecounter();
+#endif
+        uint32_t idx = 0, pos = 0;
+        {
+            uint32_t off = rng.pos - rng.win_base;
+            if (off >= 40u) {  // keep 24 draws of look-ahead: reload the window at the current position
+                rng_refill(rng);
+                off = 0;
+            }
+            if (wp_base != rng.win_base) {
+                const uint64_t v = rng.win;
+                const uint32_t v32 = (uint32_t)(v >> 32);
+                wp_hi = (uint32_t)__umul64hi(v, (uint64_t)n);
+                wp_ok0 = __ballot(v * (uint64_t)n <= zone_n);
+#pragma unroll
+                for (int i = 1; i < K; i++) {
+                    const uint32_t zone = ((uint32_t)i << __builtin_clz((uint32_t)i)) - 1u;
+                    const uint64_t mi = (uint64_t)v32 * (uint32_t)i;
+                    wp_ok[i] = __ballot((uint32_t)mi <= zone);
+                    wp_z[i] = __ballot((uint32_t)(mi >> 32) == 0u);
+                }
+                wp_base = rng.win_base;
+            }
+            const unsigned long long m0 = wp_ok0 >> off;
+            bool good = m0 != 0ull;
+            const uint32_t p0 = off + (uint32_t)__builtin_ctzll(m0 | (1ull << 63));
+            uint32_t q = p0;
+#pragma unroll
+            for (int i = 1; i < K; i++) {
+                const unsigned long long mm = (good && q < 63u) ? wp_ok[i] >> (q + 1u) : 0ull;
+                good = good && mm != 0ull;
+                q = (q + 1u + (uint32_t)__builtin_ctzll(mm | (1ull << 63))) & 63u;
+                if ((wp_z[i] >> q) & 1ull) pos = (uint32_t)i - 1u;
+            }
+            if (good) {
+                idx = (uint32_t)__builtin_amdgcn_readlane((int)wp_hi, (int)p0);
+                rng.pos = rng.win_base + q + 1u;
+            } else {  // the proposal runs past the window: draw by draw
+                idx = (uint32_t)gen_range_usize(rng, n);
+                pos = choose_pos(rng, K);
+            }
+        }
+        const uint32_t old = big ? uni((uint32_t)m.assign[idx]) : lab_get<SMALL>(assign, idx);
+        const uint32_t nw = pos < old ? pos : pos + 1;
+        GS_MARK(0);
+        Elem el = {0.0, 0, 0};
+        if (lane < D) el = elem_of(m.data[idx * D + lane]);
+        // ---- tentative flip (:764-783): only the two touched clusters change
+        double T[K];
+        int P[K], W[K], ncl[K];
+        unsigned long long npm[K], nim[K];
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            const bool o = (uint32_t)c == old, a = (uint32_t)c == nw;
+            T[c] = tg[c];
+            P[c] = np[c];
+            W[c] = w[c];
+            ncl[c] = cl[c];
+            npm[c] = posm[c];
+            nim[c] = infm[c];
+            if (o) {
+                T[c] = tg[c] - el.x;
+                P[c] = np[c] - el.dp;
+                W[c] = w[c] - el.pw;
+                ncl[c] = cl[c] - 1;
+            }
+            if (a) {
+                T[c] = tg[c] + el.x;
+                P[c] = np[c] + el.dp;
+                W[c] = w[c] + el.pw;
+                ncl[c] = cl[c] + 1;
+            }
+            if (o || a) {
+                npm[c] = __ballot(0.0 < T[c]) & colm;
+                nim[c] = __ballot(W[c] > 0);
+            }
+        }
+        // estimate first: if proposed - lk is below -1e-3 the step certainly draws, and the draw usually settles it
+        double proposed = 0.0;
+        bool accept = false, decided = false, have_v = false;
+        uint64_t v = 0;
+        GS_MARK(1);
+        const double dA = unif64(approx_lk(T, P, old, nw, npm, nim) - lk);
+        GS_MARK(2);
+        if (ubool(dA < -1e-3)) {
+            v = next_u64(rng);
+            have_v = true;
+            const float u = (float)(uint32_t)(v >> 40) * 0x1p-24f;  // v / 2^64 within 2^-24
+            decided = ubool(dA <= -44.5 || u > __expf((float)dA) * 1.001f + 3e-7f);  // certainly rejected
+        }
+        GS_MARK(3);
+        if (!decided) {
+#ifdef JTK_MCMC_STATS
+            gs[5]++;
+#endif
+            proposed = get_lk(T, P, ncl, npm, nim);
+            const double diff = unif64(proposed - lk);
+            // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
+            // exactly when diff >= -2^-54 (never the case when the estimate was below -1e-3)
+            accept = true;
+            if (!ubool(diff >= -0x1p-54)) accept = bernoulli_exact(have_v ? v : next_u64(rng), diff);
+        }
+        if (accept) {
+#pragma unroll
+            for (int c = 0; c < K; c++) {
+                tg[c] = T[c];
+                np[c] = P[c];
+                w[c] = W[c];
+                cl[c] = ncl[c];
+                posm[c] = npm[c];
+                infm[c] = nim[c];
+                if ((uint32_t)c == old || (uint32_t)c == nw) size_terms(c);
+            }
+            if (big) {
+                if (lane == 0) m.assign[idx] = (uint8_t)nw;
+                wsync();
+            } else {
+                lab_set<SMALL>(assign, idx, nw, lane);
+            }
+            lk = proposed;
+            if (ubool(max < lk)) {
+                max = proposed;
+                argmax = assign;
+                if (big) {
+                    for (uint32_t i = lane; i < n; i += 64) m.argmax[i] = m.assign[i];
+                    wsync();
+                }
+            }
+        } else {
+            // flip back (:746): the reference re-adds / re-subtracts, which leaves rounding residue
+#pragma unroll
+            for (int c = 0; c < K; c++) {
+                if ((uint32_t)c == old) tg[c] = T[c] + el.x;
+                if ((uint32_t)c == nw) tg[c] = T[c] - el.x;
+            }
+        }
+        GS_MARK(4);
+    }
+#ifdef JTK_MCMC_STATS
+    if (lane == 0)
+        printf("GENSTAT K %d n %u D %u steps %u draws %llu flip %llu approx %llu decide %llu tail %llu exact %llu\n", K, n, D,
+               total, gs[0], gs[1], gs[2], gs[3], gs[4], gs[5]);
+#endif
+    wsync();
+    if (big) {
+        for (uint32_t i = lane; i < n; i += 64) m.assign[i] = m.argmax[i];
+    } else {
+#pragma unroll
+        for (int r = 0; r < (SMALL ? 1 : 4); r++) {
+            const uint32_t i = lane + 64 * r;
+            if (i < n) m.assign[i] = (uint8_t)argmax.v[r];
+        }
+    }
+    wsync();
+    return max;
 }
 
 // The rejection threshold from the order-free estimate dA of proposed - lk.  u is the Bernoulli draw truncated to
@@ -1878,11 +2220,11 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
 
 // get_lk (:785-795) of the labels in `assign` from freshly filled counters (reads in order, :752-758): what the
 // reference compares the tracked maximum with before returning it (`assert!((max - lk).abs() < 0.0001)`, :759-760).
-template <int K>
+template <int K, bool HUGE>
 __device__ __noinline__ double fresh_lk(LdsShape shape, uint32_t n_in, uint32_t D_in, double cov_in, uint32_t lane) {
     const uint32_t n = uni(n_in), D = uni(D_in);
     const double cov = unif64(cov_in);
-    const Lds m = lds_carve(shape);
+    const Lds m = lds_carve<HUGE>(shape);
     const uint8_t *assign = m.assign;
     Counts<K> q;
     int clusters[K];
@@ -1911,20 +2253,21 @@ __device__ __noinline__ double fresh_lk(LdsShape shape, uint32_t n_in, uint32_t 
     return S;
 }
 
-template <int K, bool LIGHT>
+template <int K, bool LIGHT, bool HUGE>
 __device__ __forceinline__ double mcmc_chain_dispatch(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane);
 
 // mcmc_with_filter (:704-762): the chain, then the reference's closing self-check.  NaN = the reference panics.
-template <int K, bool LIGHT>
+template <int K, bool LIGHT, bool HUGE>
 __device__ __forceinline__ double mcmc_with_filter(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
-    const double max = mcmc_chain_dispatch<K, LIGHT>(m, n, D, cov, rng, lane);
-    const double fresh = fresh_lk<K>(m.shape, n, D, cov, lane);
+    const double max = mcmc_chain_dispatch<K, LIGHT, HUGE>(m, n, D, cov, rng, lane);
+    const double fresh = fresh_lk<K, HUGE>(m.shape, n, D, cov, lane);
     if (!ubool(fabs(max - fresh) < 0.0001)) return __builtin_nan("");
     return max;
 }
 
-template <int K, bool LIGHT>
+template <int K, bool LIGHT, bool HUGE>
 __device__ __forceinline__ double mcmc_chain_dispatch(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
+    if (HUGE) return mcmc_chain<K, false>(m, n, D, cov, rng, lane);  // the work area is in global memory (mcmc_kernel_huge)
     if (LIGHT) {
         // the light kernel (mcmc_kernel_light) holds only the two chain variants that fit 168 registers; chain_split_kernel
         // sends it nothing else.  NaN = the chunk fails, loudly, should that ever not hold.
@@ -2000,14 +2343,14 @@ __device__ __forceinline__ void get_likelihood_gain(const Lds &m, uint32_t n, ui
 }
 
 // mcmc_clustering (:649-670): labels -> m.best, per-read gains -> m.fbuf, used columns -> m.used
-template <int K, bool LIGHT>
+template <int K, bool LIGHT, bool HUGE>
 __device__ __forceinline__ bool mcmc_clustering(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score,
                                 uint32_t lane) {
     double best = 0.0;
     bool have = false;
     for (int it = 0; it < 20; it++) {
         if (!kmeans(m, n, D, K, rng, lane)) return false;
-        const double lk = mcmc_with_filter<K, LIGHT>(m, n, D, cov, rng, lane);
+        const double lk = mcmc_with_filter<K, LIGHT, HUGE>(m, n, D, cov, rng, lane);
         if (ubool(lk != lk)) return false;  // the reference panicked inside mcmc_with_filter
 #ifdef JTK_DEBUG_LK
         if (lane == 0 && n == 65) printf("DEVLK n %u D %u it %d lk %.17g pos %u\n", n, D, it, lk, rng.pos);
@@ -2037,26 +2380,26 @@ __device__ __forceinline__ bool mcmc_clustering(const Lds &m, uint32_t n, uint32
 }
 
 // out of line: one candidate cluster count per call keeps the kernel body (k-means, model selection, posteriors) small
-template <int K, bool LIGHT>
+template <int K, bool LIGHT, bool HUGE = false>
 __device__ __attribute__((noinline)) bool run_k(LdsShape shape, uint32_t n_in, uint32_t D_in, double cov_in, Rng &rng, double *score,
                                                 uint32_t lane) {
     const uint32_t n = uni(n_in), D = uni(D_in);
     const double cov = unif64(cov_in);
-    const Lds m = lds_carve(shape);
-    return mcmc_clustering<K, LIGHT>(m, n, D, cov, rng, score, lane);
+    const Lds m = lds_carve<HUGE>(shape);
+    return mcmc_clustering<K, LIGHT, HUGE>(m, n, D, cov, rng, score, lane);
 }
 
-template <bool LIGHT>
+template <bool LIGHT, bool HUGE>
 __device__ __forceinline__ bool run_k_dyn(uint32_t k, LdsShape m, uint32_t n, uint32_t D, double cov, Rng &rng, double *score,
                           uint32_t lane) {
     if (LIGHT) return k == 2 ? run_k<2, true>(m, n, D, cov, rng, score, lane) : false;
     switch (k) {
-        case 2: return run_k<2, false>(m, n, D, cov, rng, score, lane);
-        case 3: return run_k<3, false>(m, n, D, cov, rng, score, lane);
-        case 4: return run_k<4, false>(m, n, D, cov, rng, score, lane);
-        case 5: return run_k<5, false>(m, n, D, cov, rng, score, lane);
-        case 6: return run_k<6, false>(m, n, D, cov, rng, score, lane);
-        case 7: return run_k<7, false>(m, n, D, cov, rng, score, lane);
+        case 2: return run_k<2, false, HUGE>(m, n, D, cov, rng, score, lane);
+        case 3: return run_k<3, false, HUGE>(m, n, D, cov, rng, score, lane);
+        case 4: return run_k<4, false, HUGE>(m, n, D, cov, rng, score, lane);
+        case 5: return run_k<5, false, HUGE>(m, n, D, cov, rng, score, lane);
+        case 6: return run_k<6, false, HUGE>(m, n, D, cov, rng, score, lane);
+        case 7: return run_k<7, false, HUGE>(m, n, D, cov, rng, score, lane);
         default: return false;
     }
 }
@@ -2101,7 +2444,7 @@ __device__ __forceinline__ double gains_expected(const jtk_gains_t *g, uint32_t 
 #ifndef JTK_MCMC_WAVES
 #define JTK_MCMC_WAVES 2
 #endif
-template <bool LIGHT>
+template <bool LIGHT, bool HUGE = false>
 __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *state,
                                                   const jtk_lc_params_t *params, const double *feat_all,
                                                   const uint32_t *vtype_all, const uint64_t *vt_off_all,
@@ -2109,7 +2452,8 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
                                                   uint32_t post_stride, double *lg_all, const uint64_t *lg_off,
                                                   uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, uint32_t jump_in_lds,
                                                   uint32_t flags, const uint64_t *rng_resume, const uint32_t *order,
-                                                  const uint32_t *order_count) {
+                                                  const uint32_t *order_count, unsigned char *ws_base = nullptr,
+                                                  const uint64_t *ws_off = nullptr) {
     // workgroups are dispatched in blockIdx order: `order` lists the chunks with the longest chains first (their
     // length is 20 x 2000 x n proposals per candidate k), so that on ragged batches the kernel does not end on a
     // long chain that started late.  `order_count`, if given, is the device-side length of the list (the grid is the
@@ -2138,14 +2482,16 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
         }
         return;
     }
-    if (copy_num > JTK_MAX_COPY || copy_num > lds_k || n > JTK_MAX_PILEUP || n > lds_n || D > lds_d) {
+    if (copy_num > JTK_MAX_COPY || copy_num > lds_k || (!HUGE && n > JTK_MAX_PILEUP) || n > lds_n || D > lds_d) {
         if (threadIdx.x == 0) st->status = JTK_ERR_UNSUPPORTED;
         return;
     }
     // ---- LDS carve (again after every out-of-line call: the pointers are cheaper to re-make than to keep alive across it)
     (void)flags;
-    const LdsShape shape = {lds_n, lds_d, lds_k, jump_in_lds};
-    Lds m = lds_carve(shape);
+    // (mcmc_kernel_huge: lds_n / lds_d / lds_k are this chunk's own sizes and size its slice of the global workspace)
+    const LdsShape shape = {HUGE ? n : lds_n, HUGE ? D : lds_d, HUGE ? (copy_num < 2 ? 2u : copy_num) : lds_k, jump_in_lds,
+                            HUGE ? (uint64_t)(uintptr_t)(ws_base + ws_off[blockIdx.x]) : 0ull};
+    Lds m = lds_carve<HUGE>(shape);
     if (jump_in_lds)
         for (uint32_t e = threadIdx.x; e < JUMP_TAB_BYTES / 16; e += blockDim.x) m.jump[e] = g_jump_tab[e];
     if (threadIdx.x == 0) {
@@ -2220,8 +2566,8 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     bool failed = false;
     for (uint32_t k = start; k <= end; k++) {
         double score;
-        const bool ran = run_k_dyn<LIGHT>(k, shape, n, D, coverage, rng, &score, lane);
-        m = lds_carve(shape);
+        const bool ran = run_k_dyn<LIGHT, HUGE>(k, shape, n, D, coverage, rng, &score, lane);
+        m = lds_carve<HUGE>(shape);
         if (!ran) {
             failed = true;
             break;
@@ -2327,6 +2673,12 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     chunks, state, params, feat_all, vtype_all, vt_off_all, vt_stride_mode, label_all, post_all, post_stride, lg_all,       \
         lg_off, lds_n, lds_d, lds_k, jump_in_lds, flags, rng_resume, order, order_count
 __global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(MCMC_KERNEL_PARAMS) { mcmc_body<false>(MCMC_KERNEL_ARGS); }
+// Pile-ups whose work area does not fit a CU's LDS, or of more than JTK_MAX_PILEUP reads: the per-read arrays live in a
+// global-memory workspace (ws_base + ws_off[block]), the chain is the one-proposal-per-iteration one.  One wave per SIMD: the
+// seven inlined instantiations of that chain need ~360 registers, and nothing here is built for speed.
+__global__ __launch_bounds__(128, 1) void mcmc_kernel_huge(MCMC_KERNEL_PARAMS, unsigned char *ws_base, const uint64_t *ws_off) {
+    mcmc_body<false, true>(MCMC_KERNEL_ARGS, ws_base, ws_off);
+}
 #ifndef JTK_MCMC_LIGHT_WAVES
 #ifdef JTK_MCMC_STATS
 #define JTK_MCMC_LIGHT_WAVES 2  // the statistics build prints from the kernel body: it does not fit 168 registers
@@ -2389,6 +2741,16 @@ static bool mcmc_jump_in_lds(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
     // costs the kernels that overlap with it 16 KiB of LDS per chunk: 1,823 -> 1,893 chunks/s without it.
     static const bool in_lds = getenv("JTK_MCMC_JUMP_LDS") != nullptr;
     return in_lds && mcmc_lds_core(lds_n, lds_d, lds_k) + JUMP_TAB_BYTES <= 80 * 1024;
+}
+// mcmc_kernel_huge: the LDS in front of the sized arrays (ring + control block) and the global workspace of one chunk (an upper
+// bound: everything sized by n, d, k -- lds_carve keeps what fits JTK_HUGE_LDS in LDS)
+static size_t mcmc_lds_fixed() {
+    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    return al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) + al(16 * 8);
+}
+size_t mcmc_ws_bytes(uint32_t n, uint32_t d, uint32_t k) {
+    k = clamp_k(k);
+    return ((mcmc_lds_core(n, d, k) - mcmc_lds_fixed()) + 255) & ~(size_t)255;
 }
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
     lds_k = clamp_k(lds_k);
@@ -2513,5 +2875,19 @@ int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, Chunk
     if (hs != s) {
         if (hipEventRecord(ev_join, hs) != hipSuccess || hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return -1;
     }
+    return 0;
+}
+
+// The chunks listed in `order` (one workgroup each) through mcmc_kernel_huge; ws_off[i] = offset of order[i]'s slice of `ws`
+// (mcmc_ws_bytes of ITS reads, columns and copy number).
+int launch_mcmc_huge(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state, const jtk_lc_params_t *params,
+                     const double *feat, const uint32_t *vtype, const uint64_t *vt_off, uint32_t vt_stride_mode, uint32_t *label,
+                     double *post, uint32_t post_stride, double *lg, const uint64_t *lg_off, uint32_t max_n, uint32_t max_d,
+                     uint32_t max_k, const uint64_t *rng_resume, const uint32_t *order, unsigned char *ws, const uint64_t *ws_off) {
+    if (n_chunks == 0) return 0;
+    if (mcmc_upload_jump_table(s) != 0) return -1;
+    mcmc_kernel_huge<<<n_chunks, 128, mcmc_lds_fixed() + JTK_HUGE_LDS, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
+                                                             post_stride, lg, lg_off, max_n, max_d, clamp_k(max_k), 0u, 0u,
+                                                             rng_resume, order, nullptr, ws, ws_off);
     return 0;
 }

@@ -444,8 +444,10 @@ void launch_phmm_pair(hipStream_t s, uint32_t n_items, const uint32_t *items, co
                       double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active) {
     if (n_items == 0) return;
     const uint32_t base = *ticket_base;
-    *ticket_base = base + n_items + n_waves;
     const size_t lds = phmm_pair_lds_bytes(max_tmpl, max_read);
     phmm_pair_kernel<<<n_waves, 64, lds, s>>>(n_items, items, reads, chunks, state, bufs, ey, delta, hmm2, stripes,
                                               work_counter, base, raw, rawG, lk, max_tmpl, max_read, only_active);
+    // the host mirror of the never-reset ticket counter moves only when the launch was accepted: a rejected launch (LDS, grid
+    // or an earlier sticky error) takes no tickets, and a mirror that ran ahead would make every later launch exit at once
+    if (hipPeekAtLastError() == hipSuccess) *ticket_base = base + n_items + n_waves;
 }

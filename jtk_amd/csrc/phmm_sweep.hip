@@ -715,6 +715,9 @@ __global__ __launch_bounds__(64, 3) __attribute__((amdgpu_num_vgpr(JTK_PHMM_NUM_
     uint32_t *work_counter, uint32_t ticket_base, double *raw_all, int *rawG_all, double *lk_all, uint32_t lds_tmpl,
     uint32_t lds_read, int only_active, uint32_t skip_le_radius) {
     const int lane = threadIdx.x;
+#ifdef JTK_PHMM_PRIO
+    __builtin_amdgcn_s_setprio(JTK_PHMM_PRIO);  // experiment: issue priority over the chain waves that share the SIMD
+#endif
     // this wave's stripe of the device's forward scratch, for as long as the wave lives (device_common.h: StripeSet);
     // the stripe starts with JTK_SCRATCH_GUARD rows of zeros: "the pair of a diagonal below 0" is an ordinary load
     const uint32_t stripe = jtk_stripe_acquire(stripes);
@@ -764,7 +767,9 @@ void launch_phmm(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const C
     if (n_reads == 0) return;
     const size_t lds = phmm_lds_bytes(max_tmpl, max_read);
     const uint32_t base = *ticket_base;
-    *ticket_base = base + n_reads + n_waves;  // every wave takes exactly one ticket past the end
     phmm_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, stripes, work_counter, base, raw,
                                          rawG, lk, max_tmpl, max_read, only_active, skip_le_radius);
+    // the host mirror of the never-reset ticket counter moves only when the launch was accepted: a rejected launch (LDS, grid
+    // or an earlier sticky error) takes no tickets, and a mirror that ran ahead would make every later launch exit at once
+    if (hipPeekAtLastError() == hipSuccess) *ticket_base = base + n_reads + n_waves;
 }

@@ -575,10 +575,12 @@ void launch_phmm_wide(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, co
                       double *raw, int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active) {
     if (n_reads == 0 || n_waves == 0) return;
     const uint32_t base = *ticket_base;
-    *ticket_base = base + n_reads + n_waves;
     const size_t lds = phmm_wide_lds_bytes(max_tmpl, max_read);
     phmm_wide_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch, scratch_stride,
                                               work_counter, base, raw, rawG, lk, max_tmpl, max_read, only_active);
+    // the host mirror of the never-reset ticket counter moves only when the launch was accepted: a rejected launch (LDS, grid
+    // or an earlier sticky error) takes no tickets, and a mirror that ran ahead would make every later launch exit at once
+    if (hipPeekAtLastError() == hipSuccess) *ticket_base = base + n_reads + n_waves;
 }
 
 size_t phmm_counts_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
@@ -596,8 +598,10 @@ void launch_phmm_counts(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, 
                         double *counts, double *lk, uint32_t max_tmpl, uint32_t max_read) {
     if (n_reads == 0 || n_waves == 0) return;
     const uint32_t base = *ticket_base;
-    *ticket_base = base + n_reads + n_waves;
     const size_t lds = phmm_counts_lds_bytes(max_tmpl, max_read);
     phmm_counts_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch, scratch_stride,
                                                 work_counter, base, counts, lk, max_tmpl, max_read);
+    // the host mirror of the never-reset ticket counter moves only when the launch was accepted: a rejected launch (LDS, grid
+    // or an earlier sticky error) takes no tickets, and a mirror that ran ahead would make every later launch exit at once
+    if (hipPeekAtLastError() == hipSuccess) *ticket_base = base + n_reads + n_waves;
 }

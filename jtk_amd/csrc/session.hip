@@ -38,6 +38,11 @@ void launch_filter(hipStream_t s, uint32_t n_chunks, const ReadMeta *reads, cons
                    uint16_t *homop, const uint64_t *homop_off, double *aux, const uint64_t *aux_off, double *cand,
                    uint32_t *list, uint8_t *sel, double *feat, uint32_t *vtype, uint32_t *pos, uint32_t max_tmpl);
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k);
+size_t mcmc_ws_bytes(uint32_t n, uint32_t d, uint32_t k);
+int launch_mcmc_huge(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state, const jtk_lc_params_t *params,
+                     const double *feat, const uint32_t *vtype, const uint64_t *vt_off, uint32_t vt_stride_mode, uint32_t *label,
+                     double *post, uint32_t post_stride, double *lg, const uint64_t *lg_off, uint32_t max_n, uint32_t max_d,
+                     uint32_t max_k, const uint64_t *rng_resume, const uint32_t *order, unsigned char *ws, const uint64_t *ws_off);
 int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state,
                 const jtk_lc_params_t *params, const double *feat, const uint32_t *vtype, const uint64_t *vt_off,
                 uint32_t vt_stride_mode, uint32_t *label, double *post, uint32_t post_stride, double *lg,
@@ -134,7 +139,17 @@ BlockPool g_pool;
 // streams (the null stream as soon as anything uses it) take theirs: 12.  The variable is read when the HIP runtime
 // initialises, so it is set -- unless the host has set it -- when this library is loaded; a host that has initialised HIP
 // earlier sets it itself.
-__attribute__((constructor)) void jtk_lc_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
+static bool g_queues_by_library = false;  // the variable was absent when the library was loaded
+static int g_host_queues = 0;             // the host's own setting, if any
+__attribute__((constructor)) void jtk_lc_default_hw_queues() {
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    if (q) {
+        g_host_queues = atoi(q);
+    } else {
+        g_queues_by_library = true;
+        setenv("GPU_MAX_HW_QUEUES", "12", 0);
+    }
+}
 
 struct DevPtr {
     void *p = nullptr;
@@ -194,13 +209,40 @@ struct ChainClass {
     uint32_t first = 0, count = 0, lds_n = 0, lds_d = 0, lds_k = 0, lds_bytes = 0;
 };
 
+// The mapped pinned pages the polish rounds report into (JTK_NACTIVE_SLOTS counters per session): taken from and returned to
+// a process-wide free list -- sessions are created per slice per one-shot call, and hipHostFree synchronises the device,
+// which stalls the other slices' streams.  The pages are freed with the process.
+static std::mutex g_pinned_mutex;
+static std::vector<uint32_t *> g_pinned_free;
+static uint32_t *pinned_page_take() {
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        if (!g_pinned_free.empty()) {
+            uint32_t *p = g_pinned_free.back();
+            g_pinned_free.pop_back();
+            return p;
+        }
+    }
+    uint32_t *p = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&p), JTK_NACTIVE_SLOTS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess)
+        return nullptr;
+    return p;
+}
+static void pinned_page_give(uint32_t *p) {
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    g_pinned_free.push_back(p);
+}
+
 struct jtk_lc_session {
     int device = 0;
     hipStream_t stream = nullptr;
     jtk_lc_params_t params;
     uint32_t n_chunks = 0, n_reads = 0, post_stride = 1;
     uint32_t max_tmpl = 0, max_read = 0, max_n = 0, max_copy = 0, n_waves = 0;
-    ChainClass chain_class[2];  // the chain kernel's launches (by LDS need), as ranges of d_order
+    ChainClass chain_class[3];  // the chain kernel's launches (by LDS need), as ranges of d_order; [2]: the pile-ups whose
+                                // work area lives in global memory (mcmc_kernel_huge: more than JTK_MAX_PILEUP reads, or more
+                                // than a CU's LDS)
+    DevPtr d_chain_ws, d_chain_ws_off;
     uint32_t n_pair_items = 0, n_pair_waves = 0;  // phmm_pair_kernel: chunks with band radius <= JTK_PAIR_MAX_RADIUS
     DevPtr d_pair_items;
     std::shared_ptr<StripePool> stripes;  // the device's forward scratch (shared)
@@ -255,7 +297,7 @@ struct jtk_lc_session {
             if (t.b) (void)hipEventDestroy(t.b);
         }
         if (stream) (void)hipStreamDestroy(stream);
-        if (h_nactive) (void)hipHostFree(h_nactive);
+        if (h_nactive) pinned_page_give(h_nactive);  // (hipHostFree synchronises the whole device: never on the one-shot path)
         for (auto &e : ev_round)
             if (e) (void)hipEventDestroy(e);
     }
@@ -518,12 +560,16 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
             // a chunk picks at most ROUND * max(copy_num, 2) columns (pseudo_mcmc.rs:421,527,532)
             *d = std::min<uint32_t>(JTK_MAX_DIM, 3u * std::max<uint32_t>(cm.copy_num, 2u));
         };
-        std::vector<uint32_t> cls[2];
+        std::vector<uint32_t> cls[3];
         for (uint32_t c = 0; c < s->h_chunks.size() && !polish_only; c++) {
             uint32_t n, d, k;
             dims_of(s->h_chunks[c], &n, &d, &k);
-            if (n > JTK_MAX_PILEUP || s->h_chunks[c].copy_num > JTK_MAX_COPY) {
+            if (s->h_chunks[c].copy_num > JTK_MAX_COPY) {
                 if (s->h_state0[c].status == 0) s->h_state0[c].status = JTK_ERR_UNSUPPORTED;
+                continue;
+            }
+            if (n > JTK_MAX_PILEUP) {  // the reference takes any depth (mod.rs:86-123): so does class 2, slowly
+                cls[2].push_back(c);
                 continue;
             }
             cls[mcmc_lds_bytes(n, d, k) <= 80 * 1024 ? 0 : 1].push_back(c);
@@ -551,11 +597,8 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
                 cc.lds_bytes = v.empty() ? 0 : (uint32_t)mcmc_lds_bytes(cc.lds_n, cc.lds_d, cc.lds_k);
                 if (v.empty() || cc.lds_bytes <= (q == 0 ? 80u : 160u) * 1024u) break;
                 auto worst = std::max_element(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return need(a) < need(b); });
-                if (q == 0) {
-                    cls[1].push_back(*worst);  // class 0's maxima can combine beyond one member's need: hand it over
-                } else if (s->h_state0[*worst].status == 0) {
-                    s->h_state0[*worst].status = JTK_ERR_UNSUPPORTED;
-                }
+                cls[q + 1].push_back(*worst);  // a class's maxima can combine beyond one member's need: hand it over (class 1's
+                                               // overflow -- a work area beyond 160 KiB -- goes to the global-memory class)
                 v.erase(worst);
             }
             std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) {
@@ -565,6 +608,28 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
             cc.first = (uint32_t)order.size();
             cc.count = (uint32_t)v.size();
             order.insert(order.end(), v.begin(), v.end());
+        }
+        {   // class 2: one workgroup per chunk, its own slice of a global workspace
+            ChainClass &cc = s->chain_class[2];
+            cc = ChainClass{};
+            std::vector<uint64_t> ws_off;
+            uint64_t ws = 0;
+            for (uint32_t c : cls[2]) {
+                uint32_t n, d, k;
+                dims_of(s->h_chunks[c], &n, &d, &k);
+                cc.lds_n = std::max(cc.lds_n, n);
+                cc.lds_d = std::max(cc.lds_d, d);
+                cc.lds_k = std::max(cc.lds_k, k);
+                ws_off.push_back(ws);
+                ws += mcmc_ws_bytes(n, d, k);
+            }
+            cc.first = (uint32_t)order.size();
+            cc.count = (uint32_t)cls[2].size();
+            order.insert(order.end(), cls[2].begin(), cls[2].end());
+            if (cc.count) {
+                if ((rc = dev_alloc<uint8_t>(s->d_chain_ws, ws))) return rc;
+                if ((rc = dev_upload(s, s->d_chain_ws_off, ws_off))) return rc;
+            }
         }
         if (order.empty()) order.push_back(0);
         if ((rc = dev_upload(s, s->d_order, order))) return rc;
@@ -595,9 +660,13 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
     HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 4 * sizeof(uint32_t), s->stream));  // once: the ticket counters are never reset
     if ((rc = dev_alloc<uint32_t>(s->d_nactive, JTK_NACTIVE_SLOTS))) return rc;
     if ((rc = dev_alloc<uint32_t>(s->d_chain_split, 2 * n_chunks + 8))) return rc;
-    {   // the second stream only where the hardware queues are there for it (see jtk_lc_default_hw_queues)
-        const char *q = getenv("GPU_MAX_HW_QUEUES");
-        if (!q || atoi(q) >= 8) {
+    if (!polish_only) {  // the second stream (the chain's general kernel beside its light one) only where the hardware queues
+                         // are there for it: the host asked for >= 8 queues, or the variable was absent when this library was
+                         // loaded and jtk_lc_default_hw_queues set it (a host that initialised HIP BEFORE loading the library
+                         // and never set the variable runs on 4 queues: it says so with JTK_LC_SIDE_STREAM=0)
+        const char *force = getenv("JTK_LC_SIDE_STREAM");
+        const bool on = force ? atoi(force) != 0 : (g_queues_by_library || g_host_queues >= 8);
+        if (on) {
             HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&s->ev_chain[0], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&s->ev_chain[1], hipEventDisableTiming));
@@ -644,11 +713,17 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         static const bool private_set = getenv("JTK_STRIPE_SHARED") && atoi(getenv("JTK_STRIPE_SHARED")) == 0;  // experiments
         std::lock_guard<std::mutex> lock(g_stripe_mutex);
         std::shared_ptr<StripePool> mine;  // JTK_STRIPE_SHARED=0: a set of this session's own, as before round 3
-        std::shared_ptr<StripePool> &cur = (private_set || device >= JTK_POOL_DEVICES) ? mine : g_stripes[device];
-        if (!cur || cur->stride < stride || cur->n < n_stripes) {
+        // A session that launches far fewer waves than the device holds (one pile-up's modification table, the five training
+        // pile-ups of the model refit) neither needs nor may grow the device's set: n_waves stripes of its own (a 60-read call
+        // holds 0.3 GB, not the 19 GB of 4,096 stripes).  It uses the device's set if one of sufficient stride is already there.
+        const bool small = (uint64_t)s->n_waves * 4u <= n_stripes &&
+                           !(device < JTK_POOL_DEVICES && g_stripes[device] && g_stripes[device]->stride >= stride);
+        std::shared_ptr<StripePool> &cur = (private_set || small || device >= JTK_POOL_DEVICES) ? mine : g_stripes[device];
+        const uint32_t n_want = (private_set || small) ? s->n_waves : n_stripes;
+        if (!cur || cur->stride < stride || cur->n < n_want) {
             auto p = std::make_shared<StripePool>();
             p->stride = std::max<uint64_t>(stride, cur ? cur->stride : 0);
-            p->n = std::max<uint32_t>(n_stripes, cur ? cur->n : 0);
+            p->n = std::max<uint32_t>(n_want, cur ? cur->n : 0);
             cur.reset();  // its blocks go back to the block cache first (if no session holds it any more)
             if ((rc = dev_alloc<double>(p->mem, p->stride * p->n))) return rc;
             if ((rc = dev_alloc<uint32_t>(p->owner, p->n))) return rc;
@@ -771,7 +846,8 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
     // host looks at round r's counter (a round without active chunks does nothing: every kernel of a round >= 1 skips the
     // chunks that are not active), so a pass costs at most one empty round instead of a host round trip per round.
     if (!s->h_nactive) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_nactive), JTK_NACTIVE_SLOTS * sizeof(uint32_t), hipHostMallocMapped));
+        s->h_nactive = pinned_page_take();
+        if (!s->h_nactive) return fail(JTK_ERR_ALLOC, "hipHostMalloc failed");
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->h_nactive_dev), s->h_nactive, 0));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_round[0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_round[1], hipEventDisableTiming));
@@ -834,6 +910,14 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                               s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr, s->d_order.as<uint32_t>() + cc.first,
                               s->d_chain_split.as<uint32_t>() + 2 * cc.first + 4 * j, s->side, s->ev_chain[0], s->ev_chain[1]);
     }
+    if (s->chain_class[2].count && mcmc_rc == 0) {
+        const ChainClass &cc = s->chain_class[2];
+        mcmc_rc = launch_mcmc_huge(st, cc.count, chunks, state, s->d_params.as<jtk_lc_params_t>(), s->d_feat.as<double>(),
+                                   s->d_vtype.as<uint32_t>(), nullptr, 0, s->d_label.as<uint32_t>(), s->d_post.as<double>(),
+                                   s->post_stride, s->d_lg.as<double>(), s->d_lg_off.as<uint64_t>(), cc.lds_n, cc.lds_d, cc.lds_k,
+                                   s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr, s->d_order.as<uint32_t>() + cc.first,
+                                   s->d_chain_ws.as<uint8_t>(), s->d_chain_ws_off.as<uint64_t>());
+    }
     tstop(s);
     if (mcmc_rc != 0) {
         (void)hipStreamSynchronize(st);
@@ -883,11 +967,19 @@ int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post,
     if (label) HIP_TRY(hipMemcpyAsync(label, s->d_label.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToHost, st));
     if (log_post)
         HIP_TRY(hipMemcpyAsync(log_post, s->d_post.p, (size_t)s->n_reads * s->post_stride * 8, hipMemcpyDeviceToHost, st));
-    // the three buffer sets (DevBufs): a chunk's result lives in the set its state names (0 = never edited)
+    // the three buffer sets (DevBufs): a chunk's result lives in the set its state names (0 = never edited).  Only the sets
+    // some chunk's result lives in cross the bus (the states first: 40 bytes per chunk)
     std::vector<uint8_t> tb[3], ob[3];
     std::vector<uint32_t> lb[3];
     const bool want_cons = cons_out && cons_off, want_ops = ops_out && ops_out_off;
+    bool set_used[3] = {false, false, false};
+    if (want_cons || want_ops) {
+        HIP_TRY(hipStreamSynchronize(st));
+        for (const ChunkState &cs : state)
+            if (cs.status == 0) set_used[cs.buf % 3] = true;
+    }
     for (int b = 0; b < 3; b++) {
+        if (!set_used[b]) continue;
         if (want_cons) {
             tb[b].resize(s->tmpl_bytes);
             HIP_TRY(hipMemcpyAsync(tb[b].data(), s->bufs.tmpl[b], s->tmpl_bytes, hipMemcpyDeviceToHost, st));
@@ -1763,6 +1855,10 @@ int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_l
                 cm.radius = max_bw / 2;
                 cm.take_num = 0;
             }
+            // (checked before anything is allocated or queued: an early return must not hand a block with a pending memset
+            // back to the pool)
+            const size_t lds = phmm_counts_lds_bytes(s->max_tmpl, s->max_read);
+            if (lds > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "template + read too long for the LDS staging of phmm_counts_kernel");
             DevPtr d_wide, d_counts, d_lk, d_scratch, d_counter;
             if ((rc = dev_upload(s, d_wide, wide))) return rc;
             if ((rc = dev_alloc<double>(d_counts, (size_t)n_reads * FIT_COUNTS))) return rc;
@@ -1770,8 +1866,6 @@ int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_l
             if ((rc = dev_alloc<uint32_t>(d_counter, 4))) return rc;
             HIP_TRY(hipMemsetAsync(d_counter.p, 0, 4 * sizeof(uint32_t), s->stream));  // a fresh ticket counter (once per round)
             uint32_t tk_counts = 0;
-            const size_t lds = phmm_counts_lds_bytes(s->max_tmpl, s->max_read);
-            if (lds > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "template + read too long for the LDS staging of phmm_counts_kernel");
             hipDeviceProp_t prop;
             HIP_TRY(hipGetDeviceProperties(&prop, device));
             const uint64_t stride = phmm_counts_scratch_doubles(s->max_tmpl, s->max_read, max_bw / 2);
@@ -1932,7 +2026,7 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
         cms[c].local_coverage = fc.local_coverage;
         sts[c].dim = fc.dim;
         sts[c].k = 1;
-        if (fc.dim > JTK_MAX_DIM || fc.copy_num > JTK_MAX_COPY || fc.n_reads > JTK_MAX_PILEUP) sts[c].status = JTK_ERR_UNSUPPORTED;
+        if (fc.dim > JTK_MAX_DIM || fc.copy_num > JTK_MAX_COPY) sts[c].status = JTK_ERR_UNSUPPORTED;
         else if (fc.copy_num > post_stride)  // a posterior row holds up to copy_num entries
             return fail(JTK_ERR_INVALID_ARG, "post_stride smaller than a chunk's copy_num");
         vt_off[c] = fc.vt_off;
@@ -1941,9 +2035,30 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
         n_reads += fc.n_reads;
         if (fc.var_off + (uint64_t)fc.n_reads * fc.dim > n_var) n_var = fc.var_off + (uint64_t)fc.n_reads * fc.dim;
         if (fc.vt_off + fc.dim > n_vt) n_vt = fc.vt_off + fc.dim;
-        if (sts[c].status == 0 && fc.n_reads > max_n) max_n = fc.n_reads;
-        if (sts[c].status == 0 && fc.dim > max_d) max_d = fc.dim;
     }
+    // chunks whose work area fits a CU's LDS run in the table-driven kernels (one launch sized for their maxima); the others --
+    // more than JTK_MAX_PILEUP reads, or too large a feature matrix -- in mcmc_kernel_huge with a global-memory work area
+    std::vector<uint32_t> in_lds, in_ws;
+    for (size_t c = 0; c < n_chunks; c++) {
+        if (sts[c].status != 0) continue;
+        const jtk_lc_feature_chunk_t &fc = chunks[c];
+        const uint32_t d = std::max<uint32_t>(1, fc.dim), k = std::max<uint32_t>(2, fc.copy_num);
+        (fc.n_reads > JTK_MAX_PILEUP || mcmc_lds_bytes(std::max<uint32_t>(1, fc.n_reads), d, k) > 160 * 1024 ? in_ws : in_lds).push_back((uint32_t)c);
+    }
+    for (;;) {
+        max_n = max_d = 1;
+        for (uint32_t c : in_lds) {
+            max_n = std::max(max_n, chunks[c].n_reads);
+            max_d = std::max(max_d, chunks[c].dim);
+        }
+        if (in_lds.empty() || mcmc_lds_bytes(max_n, max_d, max_k) <= 160 * 1024) break;
+        auto worst = std::max_element(in_lds.begin(), in_lds.end(), [&](uint32_t a, uint32_t b) {
+            return (uint64_t)chunks[a].n_reads * std::max<uint32_t>(1, chunks[a].dim) < (uint64_t)chunks[b].n_reads * std::max<uint32_t>(1, chunks[b].dim);
+        });
+        in_ws.push_back(*worst);  // the maxima of the launch combine beyond a CU's LDS: its largest member leaves
+        in_lds.erase(worst);
+    }
+    std::sort(in_ws.begin(), in_ws.end());
     std::vector<jtk_lc_params_t> pv(1, *params);
     std::vector<double> varv(variants, variants + n_var);
     std::vector<uint32_t> vtv(variant_type, variant_type + 2 * n_vt);
@@ -1957,17 +2072,41 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks, cons
     if ((rc = dev_alloc<uint32_t>(d_label, n_reads))) return rc;
     if ((rc = dev_alloc<double>(d_post, n_reads * post_stride))) return rc;
     if ((rc = dev_alloc<double>(d_lg, lgo))) return rc;
-    if (mcmc_lds_bytes(max_n, max_d, max_k) > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "feature matrix too large for LDS");
+    DevPtr d_split, d_order, d_ws, d_wsoff;  // light / general chunk lists of the chain launch; the two launches' chunk lists
+    std::vector<uint32_t> order(in_lds);
+    order.insert(order.end(), in_ws.begin(), in_ws.end());
+    for (size_t c = 0; c < n_chunks; c++)  // (chunks that failed validation: listed too, they return at once)
+        if (sts[c].status != 0) order.insert(order.begin() + (ptrdiff_t)in_lds.size(), (uint32_t)c);
+    const uint32_t n_lds = (uint32_t)(order.size() - in_ws.size());
+    if ((rc = dev_upload(s, d_order, order))) return rc;
+    std::vector<uint64_t> ws_off;
+    uint64_t ws = 0;
+    uint32_t hn = 1, hd = 1;
+    for (uint32_t c : in_ws) {
+        ws_off.push_back(ws);
+        ws += mcmc_ws_bytes(std::max<uint32_t>(1, chunks[c].n_reads), std::max<uint32_t>(1, chunks[c].dim), std::max<uint32_t>(2, chunks[c].copy_num));
+        hn = std::max(hn, chunks[c].n_reads);
+        hd = std::max(hd, chunks[c].dim);
+    }
+    if (!in_ws.empty()) {
+        if ((rc = dev_alloc<uint8_t>(d_ws, ws))) return rc;
+        if ((rc = dev_upload(s, d_wsoff, ws_off))) return rc;
+    }
     hipEvent_t ev0, ev1;
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
     HIP_TRY(hipEventRecord(ev0, s->stream));
-    DevPtr d_split;  // light / general chunk lists of the chain launch
     if ((rc = dev_alloc<uint32_t>(d_split, 2 * n_chunks + 8))) return rc;
-    if (launch_mcmc(s->stream, (uint32_t)n_chunks, d_chunks.as<ChunkMeta>(), d_state.as<ChunkState>(),
+    if (n_lds && launch_mcmc(s->stream, n_lds, d_chunks.as<ChunkMeta>(), d_state.as<ChunkState>(),
                     d_params.as<jtk_lc_params_t>(), d_var.as<double>(), d_vt.as<uint32_t>(), d_vtoff.as<uint64_t>(), 1,
                     d_label.as<uint32_t>(), d_post.as<double>(), post_stride, d_lg.as<double>(), d_lgoff.as<uint64_t>(),
-                    max_n, max_d, max_k, nullptr, nullptr, d_split.as<uint32_t>(), nullptr, nullptr, nullptr) != 0)
+                    max_n, max_d, max_k, nullptr, d_order.as<uint32_t>(), d_split.as<uint32_t>(), nullptr, nullptr, nullptr) != 0)
+        return fail(JTK_ERR_INTERNAL, "the chain kernel could not be launched (jump table upload failed)");
+    if (!in_ws.empty() &&
+        launch_mcmc_huge(s->stream, (uint32_t)in_ws.size(), d_chunks.as<ChunkMeta>(), d_state.as<ChunkState>(),
+                         d_params.as<jtk_lc_params_t>(), d_var.as<double>(), d_vt.as<uint32_t>(), d_vtoff.as<uint64_t>(), 1,
+                         d_label.as<uint32_t>(), d_post.as<double>(), post_stride, d_lg.as<double>(), d_lgoff.as<uint64_t>(), hn, hd,
+                         max_k, nullptr, d_order.as<uint32_t>() + n_lds, d_ws.as<uint8_t>(), d_wsoff.as<uint64_t>()) != 0)
         return fail(JTK_ERR_INTERNAL, "the chain kernel could not be launched (jump table upload failed)");
     HIP_TRY(hipEventRecord(ev1, s->stream));
     HIP_TRY(hipMemcpyAsync(sts.data(), d_state.p, sts.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, s->stream));

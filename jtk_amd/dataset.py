@@ -228,13 +228,14 @@ def normalize_local_clustering(ds):
             n["posterior"] = post[i].tolist()
 
 
-def local_clustering_selected(ds, selection, gains=None, device=0, failed=None, refit=True):
+def local_clustering_selected(ds, selection, gains=None, device=0, failed=None, refit=True, record=None):
     """mod.rs:56-83 on the parsed JSON object `ds` (modified in place).
 
     The reference panics when a chunk hits one of its asserts; here such a chunk (and a chunk of a shape this build does
     not take) comes back with a status.  With `failed` = a list, those chunks are left exactly as they were, their
     (chunk id, status) pairs are appended to it and every other chunk is written back; with `failed` = None the call
-    raises like the reference, before touching `ds`."""
+    raises like the reference, before touching `ds`.  `record` = a list: the reference's per-chunk RECORD lines (mod.rs:121,
+    `debug!`) of the chunks that were written back are appended to it (api.record_rows)."""
     validate(ds)
     update_coverage(ds)                                                       # mod.rs:57
     if refit:
@@ -282,15 +283,21 @@ def local_clustering_selected(ds, selection, gains=None, device=0, failed=None, 
         chunk["seq"] = bytes(out["cons"][int(out["cons_off"][c]):int(out["cons_off"][c + 1])]).decode("ascii")
         chunk["score"] = float(out["result"][c]["score"])
         chunk["cluster_num"] = k
+    if record is not None:                                                    # mod.rs:121
+        rows = api.record_rows(batch.chunks["chunk_id"], batch.chunks["n_reads"], batch.chunks["tmpl_len"],
+                               [int(batch.read_off[batch.chunk_reads(c).stop] - batch.read_off[batch.chunk_reads(c).start])
+                                for c in range(batch.n_chunks)], batch.chunks["copy_num"], out["result"],
+                               np.diff(out["cons_off"]).astype(np.int64), api.last_timing())
+        record.extend(r for c, r in enumerate(rows) if int(out["result"][c]["status"]) == 0)
     normalize_local_clustering(ds)                                            # mod.rs:82
     return ds
 
 
-def local_clustering(ds, gains=None, device=0, failed=None, refit=True):
+def local_clustering(ds, gains=None, device=0, failed=None, refit=True, record=None):
     """mod.rs:23-26: every selected chunk."""
     validate(ds)
     return local_clustering_selected(ds, [c["id"] for c in ds["selected_chunks"]], gains=gains, device=device,
-                                     failed=failed, refit=refit)
+                                     failed=failed, refit=refit, record=record)
 
 
 def correct_clustering_selected(ds, selection, device=0, min_gain=None):
@@ -417,9 +424,12 @@ def main(argv=None):
     ap.add_argument("--keep-going", action="store_true",
                     help="a chunk that fails (where the reference would panic, or an unsupported shape) is left untouched "
                          "and listed on stderr instead of aborting the stage")
+    ap.add_argument("-v", "--verbose", action="store_true",
+                    help="write the reference's per-chunk RECORD lines (mod.rs:121, its debug! level) to stderr")
     args = ap.parse_args(argv)
     ds = json.load(sys.stdin if args.input == "-" else open(args.input))
     failed = [] if args.keep_going else None
+    record = [] if args.verbose else None
     if args.stage == "correct_clustering":
         validate(ds)
         if args.chunks:
@@ -428,9 +438,11 @@ def main(argv=None):
             correct_clustering(ds, device=args.device)
     elif args.chunks:
         local_clustering_selected(ds, [int(x) for x in args.chunks.split(",")], device=args.device, failed=failed,
-                                  refit=not args.no_refit)
+                                  refit=not args.no_refit, record=record)
     else:
-        local_clustering(ds, device=args.device, failed=failed, refit=not args.no_refit)
+        local_clustering(ds, device=args.device, failed=failed, refit=not args.no_refit, record=record)
+    for row in record or []:
+        sys.stderr.write(row + "\n")
     for cid, status in failed or []:
         sys.stderr.write(f"LC\tFAILED\t{cid}\t{status}\t{ffi.lib().jtk_lc_strerror(status).decode()}\n")
     api.trim_cache(args.device)

@@ -1,6 +1,7 @@
 """Diagnostic (GPU box): what ONE stage call from host buffers costs a fresh process -- jtk_lc_cluster_chunks on the headline data
 set (2,500 x 60 x 2 kbp), first call (device workspaces are mapped) and the two calls after it (pooled blocks), with the device
-memory the library holds after each."""
+memory the library holds after each.  bench.py runs it as a child process (one call) BEFORE it touches the GPU itself:
+`e2e.fresh_process` of the bench line.  usage: cold_call.py [n_chunks] [config] [n_calls]"""
 import json
 import os
 import sys
@@ -16,13 +17,14 @@ from jtk_amd import api, batch as jb, synth  # noqa: E402
 
 n_chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 2500
 config = sys.argv[2] if len(sys.argv) > 2 else "ont_diploid"
+n_calls = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 b, cfg = synth.make_batch(config, n_chunks, first_chunk_id=0)
 p = jb.default_params(haploid_coverage=cfg["coverage"], band_frac=cfg["band_frac"])
 torch.cuda.init()
 free0, total = torch.cuda.mem_get_info(0)
 rows = []
 ref = None
-for call in range(3):
+for call in range(n_calls):
     t = time.perf_counter()
     out = api.cluster_chunks(p, b, device=0)
     dt = time.perf_counter() - t

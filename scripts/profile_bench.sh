@@ -5,9 +5,11 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
-TAG=${1:-r03}
+TAG=${1:-r04}
 shift || true
-ARGS="${@:---steps 2 --warmup 1 --no-cpu-baseline --no-e2e}"
+# --no-shard8: every launch in the profile is a launch of the FULL workload (round 3 left the 313-chunk shard runs in: their
+# small launches diluted the per-launch averages by 1.4x)
+ARGS="${@:---steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-shard8}"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_stats_$TAG $OUT/prof_fetch_$TAG $OUT/prof_write_$TAG

@@ -31,6 +31,10 @@ def main(root, tag):
     m = re.search(r"--workload (\S+)", cmd)
     if m:
         workload = m.group(1)
+    # passes of the workload in the profiled command: warm-up + timed steps + the one serial pass after them
+    ms, mw = re.search(r"--steps (\d+)", cmd), re.search(r"--warmup (\d+)", cmd)
+    n_passes = (int(ms.group(1)) if ms else 6) + (int(mw.group(1)) if mw else 1) + 1
+    clean = "--no-shard8" in cmd  # otherwise the launches of the 313-chunk shard runs are in the sums too
     out = [f"== rocprofv3 --kernel-trace --stats -- {cmd} ==", f"(library sha256[:16] {sha}; kernel sources {jbuild.source_sha16()}; workload {workload})",
            f"{'kernel':28s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>12s} {'pct':>7s}"]
     pmc = {}
@@ -52,14 +56,26 @@ def main(root, tag):
         for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             out.append(f"{k:28s} {n:8d} {v:16.1f} {v / n:16.1f}")
             pmc.setdefault(k, {})[f"{label}_KiB_per_launch"] = v / n
+            pmc[k][f"{label}_KiB_per_pass"] = v / n_passes
             pmc[k]["launches_in_profile"] = n
+    out.append("")
+    out.append(f"== HBM bytes per pass of the workload ({n_passes} passes in the profile; (2 x FETCH_SIZE + WRITE_SIZE) x 1024"
+               + ("" if clean else "; NOT clean: the command ran the shard8 leg too") + ") ==")
+    fam_pass = {}
+    for fam, kernels in FAMILY.items():
+        b = sum((2.0 * pmc.get(k, {}).get("FETCH_SIZE_KiB_per_pass", 0.0) + pmc.get(k, {}).get("WRITE_SIZE_KiB_per_pass", 0.0)) * 1024.0
+                for k in kernels)
+        fam_pass[fam] = b
+        out.append(f"{fam:10s} {b / 1e9:12.2f} GB per pass")
     print("\n".join(out))
     json.dump({"command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- {cmd}",
                "workload": workload, "lib_sha16": sha, "src_sha16": jbuild.source_sha16(),
                "note": "KiB per launch; FETCH_SIZE on gfx950 reports half of the bytes of wide coalesced reads "
                        "(MI355X_MICROARCH.md HBM): hbm_bytes = (2*FETCH + WRITE)*1024",
+               "passes_in_profile": n_passes, "full_workload_launches_only": clean,
+               "family_bytes_per_pass": fam_pass,
                "kernel_family": FAMILY, "kernels": pmc}, open(f"{root}/prof_traffic_{tag}.json", "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "r03")
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "r04")

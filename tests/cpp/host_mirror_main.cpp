@@ -2,6 +2,7 @@
 // over reads), runs jtk::local_clustering on the GPU and dumps what the stage wrote back.
 #include <cstdio>
 #include <cstdlib>
+#include <iostream>
 #include <string>
 #include <vector>
 
@@ -85,6 +86,7 @@ int main(int argc, char **argv) {
     jtk::LocalClusteringOptions opt;
     opt.gains = device_gains ? nullptr : &gains;
     opt.refit_model = argc > 6 && atoi(argv[6]) != 0;  // update_models_on_both_strands (mod.rs:58)
+    if (getenv("JTK_HOST_MIRROR_RECORD")) opt.record = &std::cerr;  // the reference's RECORD lines (mod.rs:121) on stderr
     try {
         if (n_selected >= n_chunks) {
             jtk::local_clustering(ds, opt);

@@ -172,7 +172,7 @@ def test_untouched_fields_survive_the_json_round_trip(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_selected,refit", [(3, False), (2, False), (3, True)])
-def test_json_stage_matches_the_cpp_host_mirror(jtk_lib, tmp_path, n_selected, refit):
+def test_json_stage_matches_the_cpp_host_mirror(jtk_lib, tmp_path, capsys, n_selected, refit):
     assert jtk_lib.jtk_lc_device_ok(0) == 1
     n_chunks, tmpl_len, rph = 3, 400, 8
     ds = synthetic_dataset(n_chunks, tmpl_len, rph)
@@ -180,12 +180,21 @@ def test_json_stage_matches_the_cpp_host_mirror(jtk_lib, tmp_path, n_selected, r
     src.write_text(json.dumps(ds))
     argv = [str(src), str(dst)] + (["--chunks", ",".join(str(c) for c in range(n_selected))] if n_selected < n_chunks else [])
     argv += [] if refit else ["--no-refit"]           # refit: update_models_on_both_strands on the device (mod.rs:58)
+    argv += ["--verbose"]                             # the reference's RECORD lines (mod.rs:121) on stderr
     D.main(argv)                                      # gains: estimate_gain_default on the device (mod.rs:60)
     out = json.loads(dst.read_text())
+    rec = [l.split("\t") for l in capsys.readouterr().err.splitlines() if l.startswith("RECORD\t")]
     exe = HM.build_driver()
     ref = subprocess.run([exe, str(n_chunks), str(tmpl_len), str(rph), "-", str(n_selected), "1" if refit else "0"],
-                         capture_output=True, text=True)
+                         capture_output=True, text=True, env=dict(os.environ, JTK_HOST_MIRROR_RECORD="1"))
     assert ref.returncode == 0, ref.stderr
+    # RECORD\tchunk id\telapsed ms\tpolish ms\tconsensus length\tscore (3 decimals)\tcoverage -- one per clustered chunk, from
+    # the stage itself, in both host mirrors (the milliseconds are a share of the call's kernel time: not compared)
+    rec_cpp = [l.split("\t") for l in ref.stderr.splitlines() if l.startswith("RECORD\t")]
+    assert len(rec) == n_selected == len(rec_cpp)
+    for a, b in zip(rec, rec_cpp):
+        assert len(a) == 7 and (a[1], a[4], a[5], a[6]) == (b[1], b[4], b[5], b[6])
+        assert float(a[2]) >= float(a[3]) >= 0.0 and int(a[6]) == 2 * rph
     chunks, nodes = {}, {}
     for line in ref.stdout.splitlines():
         f = line.split("\t")

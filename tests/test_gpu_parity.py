@@ -350,12 +350,20 @@ def test_large_pileups_match_oracle(lib):
     assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
     assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(ora["log_post"]))
     assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(ora["result"]["score"]))
-    # one more read than the kernel takes is reported, not mis-clustered
-    x, vt, _ = random_feature_problem(np.random.default_rng(3), 1024, 3, 2, 0, 2)
-    ch = np.zeros(1, dtype=ffi.FEATURE_CHUNK_DT)
-    ch[0] = (5, 2, 1024, 3, 0, 0, 0, 0, 512.0)
-    out = api.cluster_features(p, ch, x.ravel(), vt.ravel().astype(np.uint32), 2, raise_on_chunk_failure=False)
-    assert out["rc"] == -6 and out["result"]["status"][0] == -3
+
+
+def test_pileups_beyond_1023_reads_match_oracle(lib):
+    """clustering_on_pileup (mod.rs:86-123) takes any depth.  Beyond JTK_MAX_PILEUP = 1,023 reads (10-bit read indices of the
+    table-driven chains) or a CU's LDS, a pile-up runs in mcmc_kernel_huge: work area in global memory, one proposal per
+    iteration -- slow, and bit-exact: 1,024 and 1,100 reads, K = 2 and 3, next to an ordinary pile-up in the same call"""
+    p = jb.default_params(haploid_coverage=40.0)
+    specs = [(1024, 3, 2, 2), (60, 2, 2, 2), (1100, 4, 3, 3)]
+    dev, ora, truth = run_features_both(p, specs, seed=23)
+    assert np.array_equal(dev["result"]["status"], np.zeros(len(specs), np.int32))
+    assert np.array_equal(dev["label"], ora["label"])
+    assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
+    assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(ora["log_post"]))
+    assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(ora["result"]["score"]))
 
 
 def test_size_only_moves_match_oracle(lib):

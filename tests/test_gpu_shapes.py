@@ -222,8 +222,8 @@ def test_window_polishing_matches_oracle(lib, radius, take_num, ignore_edge):
 
 
 def test_deep_window_polishes_beyond_the_chain_limit(lib):
-    """consensus::polish_seg windows can be deeper than any pile-up the chain kernel takes (JTK_MAX_PILEUP = 1,023 reads):
-    a polish-only call has no chain and no such limit -- 1,100 reads on a 180-bp window, 30 of them voting"""
+    """consensus::polish_seg windows can be deep: 1,100 reads on a 180-bp window, 30 of them voting (a polish-only call has no
+    chain at all)"""
     b, cfg, p = helpers.small_batch(config="ont_noisy", n_chunks=1, tmpl_len=180, reads_per_hap=550, first=77, tmpl_err=1e-2)
     assert int(b.chunks["n_reads"][0]) == 1100
     dev = api.polish_chunks(p, b, radius=20, take_num=30, ignore_edge=0)
@@ -234,6 +234,17 @@ def test_deep_window_polishes_beyond_the_chain_limit(lib):
     assert np.array_equal(dev["cons_off"], ora["cons_off"]) and bytes(dev["cons"][:n]) == bytes(ora["cons"][:n])
     m = int(dev["ops_out_off"][-1])
     assert np.array_equal(dev["ops_out_off"], ora["ops_out_off"]) and np.array_equal(dev["ops_out"][:m], ora["ops_out"][:m])
+
+
+def test_full_path_pileup_of_1100_reads_matches_oracle(lib):
+    """the whole stage path on a pile-up deeper than the table-driven chains take (1,100 reads x 300 bp, diploid): polish,
+    tables, filter on the ordinary kernels, the chain in mcmc_kernel_huge (session class 2) -- no JTK_ERR_UNSUPPORTED for a read
+    count any more"""
+    b, cfg, p = helpers.small_batch(config="ont_diploid", n_chunks=1, tmpl_len=300, reads_per_hap=550, first=91, min_variants=1)
+    assert int(b.chunks["n_reads"][0]) == 1100
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
+    assert_full_parity(dev, ora, b)
 
 
 # ---- bands wider than one wavefront (phmm_wide_kernel): CLR / None reads, ONT chunks longer than 2,033 bp

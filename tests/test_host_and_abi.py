@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(jtk_lib):
     assert declared_in("jtk_synth.h") == set(ffi.SYNTH_SYMBOLS)
     for name in ffi.SYNTH_SYMBOLS:
         assert hasattr(ffi.synth_lib(), name) and not hasattr(jtk_lib, name), name
-    assert jtk_lib.jtk_lc_version() == 1
+    assert jtk_lib.jtk_lc_version() == 2
     assert jtk_lib.jtk_lc_strerror(-5).decode().startswith("alignment ops")
 
 

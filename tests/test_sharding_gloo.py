@@ -143,3 +143,23 @@ def test_result_gather_at_eight_ranks_on_the_headline_partition(tmp_path):
     world = 8
     mp.spawn(_gather8_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(np.load(tmp_path / f"gather8_{r}.npy")[0] == 1 for r in range(world))
+
+
+def test_predicted_cost_spread_of_the_strong_partition():
+    """the partition every rank computes from the metadata alone: on the headline data set the 8 shards differ by one chunk,
+    and on a ragged one (Poisson coverage, 2- and 4-copy chunks, three template lengths) the predicted per-rank cost -- pair-HMM
+    cells + Metropolis steps per candidate k -- stays within 2 % of the mean.  (What the model cannot know before the filter
+    has run is how EVENTFUL a chunk's chain will be: a rank's chain launch lasts as long as its slowest chunk)"""
+    from jtk_amd import sharding
+    parts = sharding.strong_shards(2500, 60, 2000, 2, 8)
+    assert sorted(len(p) for p in parts) == [312] * 4 + [313] * 4
+    assert sorted(np.concatenate(parts).tolist()) == list(range(2500))
+    rng = np.random.default_rng(3)
+    n = 1500
+    reads = rng.poisson(60, n).clip(8, 200)
+    copy = rng.choice([2, 2, 2, 4], n)
+    tlen = rng.choice([1000, 2000, 4000], n)
+    parts = sharding.strong_shards(n, reads * (copy // 2), tlen, copy, 8)
+    cost = np.array([sharding.chunk_cost(r * (c // 2), L, c) for r, c, L in zip(reads, copy, tlen)])
+    per_rank = np.array([cost[p].sum() for p in parts])
+    assert per_rank.max() / per_rank.mean() < 1.02 and per_rank.min() / per_rank.mean() > 0.98
