@@ -219,7 +219,7 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
                     help="strong: the workload's fixed dataset is sharded over the ranks; weak: every rank its own chunks")
     ap.add_argument("--chunks", type=int, default=0, help="override the dataset size (strong) / chunks per GPU (weak)")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=6,
                     help="slices of the rank's shard in flight, each a resident session on its own HIP stream and host thread")
     ap.add_argument("--stagger-ms", type=float, default=0.0,
                     help="slice i starts its first pass i x this many ms after slice 0 (inside the timed region): slices that "

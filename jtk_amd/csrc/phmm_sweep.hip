@@ -715,9 +715,6 @@ __global__ __launch_bounds__(64, 3) __attribute__((amdgpu_num_vgpr(JTK_PHMM_NUM_
     uint32_t *work_counter, uint32_t ticket_base, double *raw_all, int *rawG_all, double *lk_all, uint32_t lds_tmpl,
     uint32_t lds_read, int only_active, uint32_t skip_le_radius) {
     const int lane = threadIdx.x;
-#ifdef JTK_PHMM_PRIO
-    __builtin_amdgcn_s_setprio(JTK_PHMM_PRIO);  // experiment: issue priority over the chain waves that share the SIMD
-#endif
     // this wave's stripe of the device's forward scratch, for as long as the wave lives (device_common.h: StripeSet);
     // the stripe starts with JTK_SCRATCH_GUARD rows of zeros: "the pair of a diagonal below 0" is an ordinary load
     const uint32_t stripe = jtk_stripe_acquire(stripes);
