@@ -366,6 +366,42 @@ def test_pileups_beyond_1023_reads_match_oracle(lib):
     assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(ora["result"]["score"]))
 
 
+def test_high_acceptance_chains_match_oracle(lib):
+    """weak columns (|gain| ~ 0.3: what the refitted model of the real stage lets through the filter): half of the proposals are
+    accepted, and with three or more columns the diploid chain then takes every proposal as one exact step (direct mode) instead
+    of rebuilding its tables after every accepted move; mixed with strong columns so that it goes in and out of that mode"""
+    import ctypes as C
+    p = jb.default_params(haploid_coverage=25.0)
+    rng = np.random.default_rng(41)
+    specs = [(50, 3), (60, 4), (44, 6), (100, 3), (60, 8), (63, 5)]
+    chunks = np.zeros(len(specs), dtype=ffi.FEATURE_CHUNK_DT)
+    var, vts = [], []
+    voff = vtoff = rfirst = 0
+    for i, (n, dim) in enumerate(specs):
+        x, vt, _ = random_feature_problem(rng, n, dim, 2, i, 2)
+        weak = rng.random(dim) < 0.7
+        x[:, weak] = rng.normal(0.0, 0.3, (n, int(weak.sum())))
+        x[np.abs(x) < 2e-5] = 0.0   # (LKCount asserts on |x| == POS_THR exactly; keep clear of it)
+        chunks[i] = (900 + 11 * i, 2, n, dim, 0, voff, vtoff, rfirst, n / 2)
+        var.append(x.ravel())
+        vts.append(vt.ravel())
+        voff += n * dim
+        vtoff += dim
+        rfirst += n
+    var = np.concatenate(var)
+    vts = np.concatenate(vts).astype(np.uint32)
+    dev = api.cluster_features(p, chunks, var, vts, 2)
+    po = helpers.oracle_params(p)
+    lab = np.zeros(rfirst, np.uint32)
+    post = np.zeros((rfirst, 2))
+    res = np.zeros(len(specs), dtype=ffi.RESULT_DT)
+    assert O.lib().jo_cluster_features(C.byref(po), len(specs), chunks.ctypes.data, O.f64p(var), O.u32p(vts),
+                                       O.u32p(lab), O.f64p(post), 2, res.ctypes.data, 0) == 0
+    assert np.array_equal(dev["label"], lab)
+    assert np.array_equal(helpers.bits(dev["log_post"]), helpers.bits(post))
+    assert np.array_equal(helpers.bits(dev["result"]["score"]), helpers.bits(res["score"]))
+
+
 def test_size_only_moves_match_oracle(lib):
     """a third of the reads carry no signal at all (all-zero rows): hundreds of thousands of accepted moves that
     change nothing but the cluster sizes, decided from the per-size tables"""
