@@ -20,9 +20,14 @@
 //    group may hold at most 3 band moves (its read-byte window and its staged rows are per half group for the same reason);
 //  * the first / last ~2r diagonals of a sweep, and any group with a half of 4 band moves, take a generic step (per-lane
 //    predicates, as the round-2 kernel did everywhere);
-//  * forward still streams the pair P_s = (toM of diagonal s-1, toD of diagonal s) per diagonal to an HBM stripe (1 KiB per
-//    diagonal), backward reads it back through a register queue into an 8-slot LDS ring (no wrapped copies: seven address
-//    registers instead).
+//  * the pair P_s = (toM of diagonal s-1, toD of diagonal s) the backward sweep needs of every diagonal goes through an HBM
+//    stripe (1 KiB per diagonal) only at the ends of the sweeps.  Round 4: wherever the backward sweep runs a fast group
+//    (diagonals 8g .. 8g+7) it needs the pairs of the diagonals 8g-5 .. 8g+2, and instead of 8 KiB written and read back it gets
+//    ONE checkpoint of the forward state after diagonal 8g-6 (toM_1, toM_2, toI_1, toD_1: 2 KiB) and REPLAYS the eight forward
+//    steps in front of its own eight (the same instructions on the same values: the same bits); the replayed pairs wait in the
+//    registers the prefetch queue used to occupy and enter the 8-slot LDS ring one per step as before.  Which groups replay is
+//    a bit per group, worked out once per read from the band deltas (bf bits: the backward group is fast AND both forward
+//    groups that produce its pairs were).
 #include "device_common.h"
 
 
@@ -34,7 +39,11 @@ namespace {
 #define S_EI (S_EM + 128)      // eI[20]
 #define S_STAGE (S_EI + 160)   // 3 finished rows x 16 row sums on their way out (a half group retires at most 3 rows)
 #define S_SMETA (S_STAGE + 384)  // their (row, exponent)
-#define S_VAR (S_SMETA + 32)   // delta words | block exponents | template codes | read codes
+#define S_VAR (S_SMETA + 32)   // delta words | block exponents | replay bits | template codes | read codes
+#define JTK_BFW_BYTES(n_blk) ((n_blk) + 8u)  // one bit per group of 8 diagonals, n_blk blocks of 64 diagonals; + slack for the look-ahead
+#ifndef JTK_PHMM_REPLAY
+#define JTK_PHMM_REPLAY 1      // 0: every pair through the stripe (rounds 2-3)
+#endif
 
 __device__ __forceinline__ double rot_from_prev(double v) {  // lane l <- lane (l-1)&63
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -118,7 +127,8 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
     extern __shared__ __align__(16) unsigned char smem[];
     const int T = L + n;
     const uint32_t n_blk = ((lds_tmpl + lds_read) >> 6) + 4;
-    const uint32_t S_DELTA = S_VAR, S_EF = S_DELTA + n_blk * 8, S_XS = (S_EF + n_blk * 4 + 15) & ~15u,
+    const uint32_t S_DELTA = S_VAR, S_EF = S_DELTA + n_blk * 8, S_BFW = S_EF + n_blk * 4,
+                   S_XS = (S_BFW + JTK_BFW_BYTES(n_blk) + 15) & ~15u,
                    S_EY = S_XS + ((((lds_tmpl + 2 * PAD + 3) >> 2) + 15) & ~15u);
     // template codes: four 2-bit codes per byte, PAD codes of padding either side (the sweeps look a template row up once per
     // band move and in the generic steps only, so they can afford the unpacking; a byte per code cost a twelfth wave per CU)
@@ -174,6 +184,30 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                  aII = uni_f64(h->a[4]), aID = uni_f64(h->a[5]), aDM = uni_f64(h->a[6]), aDI = uni_f64(h->a[7]),
                  aDD = uni_f64(h->a[8]);
     const uint64_t BAND = (2ull << (2 * r)) - 1;  // 2r+1 ones
+#if JTK_PHMM_REPLAY
+    // bit g of the replay bits: the backward sweep takes the diagonals 8g .. 8g+7 as a fast group (its own conditions, below) and
+    // the forward sweep takes both 8(g-1) .. and 8g .. as fast groups, so that the pairs of the diagonals 8g-5 .. 8g+2 can be
+    // replayed from the checkpoint after diagonal 8g-6.  Lane-parallel, once per read.
+    for (int gb = 0; gb < (T >> 3) + 10; gb += 64) {
+        const int g = gb + lane, tb = 8 * g + 7;
+        bool ok = false;
+        if (g >= 3 && tb < T && tb <= f_hi && 8 * (g - 1) >= f_lo) {
+            const uint32_t b0 = lds_u8(S_DELTA + (uint32_t)g - 1), b1 = lds_u8(S_DELTA + (uint32_t)g), b2 = lds_u8(S_DELTA + (uint32_t)g + 1);
+            ok = (b2 & 1u) + (uint32_t)__builtin_popcount((b1 >> 5) & 7u) <= 3u && ((b1 >> 1) & 0xfu) != 0xfu  // backward halves
+                 && (b0 & 0xfu) != 0xfu && (b0 >> 4) != 0xfu && (b1 & 0xfu) != 0xfu && (b1 >> 4) != 0xfu;          // forward halves
+        }
+        const uint64_t w = __ballot(ok);
+        if (lane == 0) {
+            *reinterpret_cast<uint32_t *>(smem + S_BFW + (uint32_t)(gb >> 3)) = (uint32_t)w;
+            *reinterpret_cast<uint32_t *>(smem + S_BFW + (uint32_t)(gb >> 3) + 4) = (uint32_t)(w >> 32);
+        }
+    }
+    __syncthreads();
+    auto bf_bits = [&](uint32_t g) -> uint32_t {  // bit 0: group g replays, bit 1: group g+1 (uniform)
+        const uint32_t lo = lds_u8(S_BFW + (g >> 3)), hi = lds_u8(S_BFW + (g >> 3) + 1);
+        return ((uint32_t)uni((int)(lo | hi << 8)) >> (g & 7u)) & 3u;
+    };
+#endif
 
     // =========================== forward ===========================
     int c = 0, EF = 0;                                   // c == c[t-1] between steps
@@ -199,6 +233,9 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
             uint32_t db = 0;
             bool fast = (t & 7) == 0 && t >= f_lo && t + 7 <= f_hi;
 #ifdef JTK_PHMM_NOFAST_FWD
+#if JTK_PHMM_REPLAY
+#error "JTK_PHMM_NOFAST_FWD needs -DJTK_PHMM_REPLAY=0: the replay bits assume the forward sweep's fast groups"
+#endif
             fast = false;
 #endif
             if (fast) {
@@ -261,6 +298,14 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
             }
             uint32_t W = 0;  // the read bytes of the half group's columns j .. j+3, j = (t + u) - row
             double2 *out = scratch + (int64_t)t * 64;
+#if JTK_PHMM_REPLAY
+            // the pairs of the steps 0..2 are the backward group g's, those of the steps 3..7 group g+1's: a group that replays
+            // wants the checkpoint after step 2 (in the slots of the diagonals t+3, t+4) instead of its pairs
+            const uint32_t bf2 = bf_bits((uint32_t)t >> 3);
+#define FWD_STORES(u) ((u) < 3 ? !(bf2 & 1u) : !(bf2 & 2u))
+#else
+#define FWD_STORES(u) true
+#endif
             const bool block_start = (t & (JTK_SCALE_BLOCK - 1)) == 0;  // step u == 0 opens a scaling block
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -315,9 +360,10 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                         toI_1 = fma(fd, aDI, fma(fi, aII, fm * aMI));
                         toD_1 = fma(fd, aDD, fma(fi, aID, fm * aMD));
                     }
-#ifndef JTK_PHMM_X_NOSTORE
-                    out[u * 64 + lane] = make_double2(toM_2, toD_1);  // toM of diagonal t-1 goes out in ITS block's scale ...
-#endif
+                    if (FWD_STORES(u)) {
+                        KEEP_MASKED;
+                        out[u * 64 + lane] = make_double2(toM_2, toD_1);  // toM of diagonal t-1 goes out in ITS block's scale ...
+                    }
                     if (block_start) {
                         KEEP_MASKED;
                         toM_2 *= sc;  // ... and is re-expressed for the steps that read it
@@ -331,11 +377,20 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                         toI_1 = fma(fd, aDI, fma(fi, aII, fm * aMI));
                         toD_1 = fma(fd, aDD, fma(fi, aID, fm * aMD));
                     }
-#ifndef JTK_PHMM_X_NOSTORE
-                    out[u * 64 + lane] = make_double2(toM_2, toD_1);
+                    if (FWD_STORES(u)) {
+                        KEEP_MASKED;
+                        out[u * 64 + lane] = make_double2(toM_2, toD_1);
+                    }
+#if JTK_PHMM_REPLAY
+                    if (u == 2 && (bf2 & 2u)) {
+                        KEEP_MASKED;
+                        out[3 * 64 + lane] = make_double2(toM_1, toM_2);
+                        out[4 * 64 + lane] = make_double2(toI_1, toD_1);
+                    }
 #endif
                 }
             }
+#undef FWD_STORES
             t += 8;
         }
     }
@@ -395,15 +450,26 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
         int rowG = 0;  // exponent of the lane's finished row, until the group's flush
         // pairs on their way from the stripe: qA = those the steps u = 0..3 of the coming group put into the ring (loaded
         // while the previous group ran its steps 4..7), qB = those of the steps u = 4..7 (loaded at the group's start)
+#if JTK_PHMM_REPLAY
+        // q[k] = the replayed pair of diagonal 8g-5+k (step u of the group puts q[7-u] into the ring); ck0 / ck1 = the
+        // checkpoint of the NEXT group below, on its way from the stripe while this group runs
+        double2 q[8], ck0 = make_double2(0.0, 0.0), ck1 = ck0;
+#else
         double2 qA[4], qB[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) qA[k] = qB[k] = make_double2(0.0, 0.0);
+#endif
         while (t >= 0) {
             uint32_t w16 = 0;
+#if JTK_PHMM_REPLAY
+            bool fast = (t & 7) == 7 && (bf_bits((uint32_t)t >> 3) & 1u);
+            int carry = 0;
+            if (fast) {
+                w16 = delta_byte(t >> 3) << 8 | delta_byte((t >> 3) - 1);  // bit k: c[t-15+k] - c[t-16+k]
+                carry = delta_bit(t + 1);
+            }
+#else
             bool fast = (t & 7) == 7 && t - 7 >= f_lo && t <= f_hi && t < T && t >= 23;
-#ifdef JTK_PHMM_NOFAST_BWD
-            fast = false;
-#endif
             int carry = 0;
             if (fast) {
                 w16 = delta_byte(t >> 3) << 8 | delta_byte((t >> 3) - 1);  // bit k: c[t-15+k] - c[t-16+k]
@@ -411,6 +477,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 // band moves at the steps t .. t-3 / t-4 .. t-7: at most three per half group (see the forward sweep)
                 fast = carry + __builtin_popcount((w16 >> 13) & 7u) <= 3 && ((w16 >> 9) & 0xfu) != 0xfu;
             }
+#endif
             if (!fast) {
                 // ---- generic step
                 fast_ready = false;
@@ -517,8 +584,13 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 xrow = S_EM + xs_of(row);
                 band = rotl64(BAND, lo6);
                 fast_ready = true;
+#if JTK_PHMM_REPLAY
+                ck0 = scratch[(int64_t)(t - 12) * 64 + lane];
+                ck1 = scratch[(int64_t)(t - 11) * 64 + lane];
+#else
 #pragma unroll
                 for (int k = 0; k < 4; k++) qA[k] = scratch[(int64_t)(t - 5 - k) * 64 + lane];
+#endif
             }
             const int tb = t;
             uint32_t W = 0;     // read bytes of the half group's columns j-3 .. j, j = (tb - u) - row: step u uses byte 3 - (u & 3)
@@ -528,6 +600,73 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
             double Fsp = 1.0;
             if (low_group) Fsp = fast_pow2(uni(s_EF[(tb >> 6) - 1]) - uni(s_EF[tb >> 6]));
             const double2 *pin = scratch + (int64_t)(tb - 5) * 64 + lane;  // P_{tb-5}; step u puts pin[-64 u] into the ring
+#if JTK_PHMM_REPLAY
+            {   // ---- replay the forward steps of the diagonals tb-12 .. tb-5 from the checkpoint after diagonal tb-13
+                double fM1 = ck0.x, fM2 = ck0.y, fI1 = ck1.x, fD1 = ck1.y;
+                ck0 = pin[-64 * 15];  // the group below, should it replay too: its checkpoint sits in the slots tb-20, tb-19
+                ck1 = pin[-64 * 14];
+                // c == c[tb+1]; the band of diagonal tb-13 lies carry + (the moves of the diagonals tb-12 .. tb) below it
+                const int lof = c - carry - __builtin_popcount(w16 >> 3) - r;
+                int lo6f = lof & 63;
+                int rowf = lof + ((lane - lof) & 63);
+                uint32_t xrowf = S_EM + xs_of(rowf);
+                uint32_t yb = EY0 + (uint32_t)(tb - 12 - rowf);  // the read byte of diagonal tb-12+k: smem[yb + k]
+                uint64_t bandf = rotl64(BAND, lo6f);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const double pM = rot_from_prev(fM2), pD = rot_from_prev(fD1);
+                    fM2 = fM1;
+                    if ((w16 >> (3 + k)) & 1u) {
+                        if (lanes(1ull << lo6f)) {
+                            KEEP_MASKED;
+                            fM1 = 0.0;
+                            fI1 = 0.0;
+                            fD1 = 0.0;
+                            rowf += 64;
+                            yb -= 64;
+                            xrowf = S_EM + xs_of(rowf);
+                        }
+                        lo6f = (lo6f + 1) & 63;
+                        bandf = (bandf << 1) | (bandf >> 63);
+                    }
+                    const bool in_bandf = lanes(bandf);
+                    if (k == 5 && low_group) {  // diagonal tb-7 opens a scaling block: the forward step scaled by 2^-e == Fsp
+                        KEEP_MASKED;
+                        double fm = 0.0, fi = 0.0, fd = 0.0;
+                        if (in_bandf) {
+                            KEEP_MASKED;
+                            const uint32_t byte = lds_u8(yb + k);
+                            const double eMv = lds_f64(xrowf | (byte & 24u)), eIv = lds_f64(S_EI + byte);
+                            fm = eMv * pM;
+                            fi = eIv * fI1;
+                            fd = pD;
+                        }
+                        fm *= Fsp;
+                        fi *= Fsp;
+                        fd *= Fsp;
+                        if (in_bandf) {
+                            KEEP_MASKED;
+                            fM1 = fma(fd, aDM, fma(fi, aIM, fm * aMM));
+                            fI1 = fma(fd, aDI, fma(fi, aII, fm * aMI));
+                            fD1 = fma(fd, aDD, fma(fi, aID, fm * aMD));
+                        }
+                        q[k] = make_double2(fM2, fD1);
+                        fM2 *= Fsp;
+                    } else {
+                        if (in_bandf) {
+                            KEEP_MASKED;
+                            const uint32_t byte = lds_u8(yb + k);
+                            const double eMv = lds_f64(xrowf | (byte & 24u)), eIv = lds_f64(S_EI + byte);
+                            const double fm = eMv * pM, fi = eIv * fI1, fd = pD;
+                            fM1 = fma(fd, aDM, fma(fi, aIM, fm * aMM));
+                            fI1 = fma(fd, aDI, fma(fi, aII, fm * aMI));
+                            fD1 = fma(fd, aDD, fma(fi, aID, fm * aMD));
+                        }
+                        q[k] = make_double2(fM2, fD1);
+                    }
+                }
+            }
+#endif
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 if ((u & 3) == 0) W = window4(EY0 + (uint32_t)(tb - u - row - 3));
@@ -562,25 +701,23 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                     c -= 1;
                     band = (band >> 1) | (band << 63);
                 }
+#if !JTK_PHMM_REPLAY
                 if (u == 0) {
 #pragma unroll
-#ifndef JTK_PHMM_X_NOLOAD
                     for (int k = 0; k < 4; k++) qB[k] = pin[-64 * (4 + k)];
-#else
-                    for (int k = 0; k < 4; k++) qB[k] = make_double2(1e-3 * (tb + k), 0.5);
-#endif
                 }
+#endif
                 {  // the pair five diagonals below enters the ring
+#if JTK_PHMM_REPLAY
+                    double2 v = q[7 - u];
+#else
                     double2 v = u < 4 ? qA[u & 3] : qB[u & 3];
                     if (u == 3) {  // qA is free again: the next group's first four pairs (a group that turns out generic
                                    // reloads what it needs)
 #pragma unroll
-#ifndef JTK_PHMM_X_NOLOAD
                         for (int k = 0; k < 4; k++) qA[k] = pin[-64 * (8 + k)];
-#else
-                        for (int k = 0; k < 4; k++) qA[k] = make_double2(1e-3 * (tb - k), 0.25);
-#endif
                     }
+#endif
                     if (u >= 2 && low_group) {
                         KEEP_MASKED;  // a (rare) uniform branch, not two selects per step
                         v.x *= Fsp;
@@ -750,7 +887,7 @@ __global__ __launch_bounds__(64, 3) __attribute__((amdgpu_num_vgpr(JTK_PHMM_NUM_
 
 size_t phmm_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
     const uint32_t n_blk = ((max_tmpl + max_read) >> 6) + 4;
-    size_t b = S_VAR + (size_t)n_blk * 12;
+    size_t b = S_VAR + (size_t)n_blk * 12 + JTK_BFW_BYTES(n_blk);
     b = (b + 15) & ~(size_t)15;
     b += ((((max_tmpl + 2 * PAD + 3) >> 2) + 15) & ~15u) + max_read + 1 + 2 * PAD + 16;
     return (b + 15) & ~(size_t)15;
