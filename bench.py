@@ -506,6 +506,12 @@ def main():
         ch = batch.chunks[c]
         r0, r1 = int(ch["read_first"]), int(ch["read_first"]) + int(ch["n_reads"])
         diags = int(ch["n_reads"]) * (int(ch["tmpl_len"]) + 24) + int(batch.read_off[r1] - batch.read_off[r0])
+        radius = int(np.ceil(int(ch["tmpl_len"]) * cfg["band_frac"])) // 2
+        if 15 <= radius <= 30:
+            # phmm_kernel (round 4): the ends of a sweep (about 2r + 24 diagonals each) stream a pair per diagonal, the groups
+            # in between one 2 KiB checkpoint per 8 diagonals (the pairs are replayed from it)
+            ends = min(diags, int(ch["n_reads"]) * (4 * radius + 48))
+            diags = ends + (diags - ends) / 4.0
         stripe_bytes += float(passes[c]) * diags * 1024.0 * 2.0
     launches_dom = max(1, serial_launch[dom])
     fam_pass = (traffic or {}).get("phmm")
@@ -518,11 +524,13 @@ def main():
         pmc_bytes_per_pass=fam_pass,
         pmc=None if not fam_pass else dict(GBps=fam_pass / 1e9 / phmm_s, frac_of_8TBps=fam_pass / 1e9 / phmm_s / HBM_PEAK_GBPS,
                                            frac_of_achievable_6p3TBps=fam_pass / 1e9 / phmm_s / 6300.0),
-        note="the pair-HMM family is bound by this stream, not by the 124 KB per chunk of the algorithmic figure: bytes per pass "
-             "of the workload over the serial pass's pair-HMM device time.  by_construction = sum over chunks of passes x "
-             "(anti-diagonals of its reads) x 1 KiB x (write + read back); pmc = (2 x FETCH_SIZE + WRITE_SIZE) of the family's "
-             "kernels from the committed profile of this build (tables and row sums included); 6.3 TB/s = the float4-copy rate "
-             "of MI355X_MICROARCH.md")
+        note="the forward state the pair-HMM family moves through HBM, next to the 124 KB per chunk of the algorithmic figure: "
+             "bytes per pass of the workload over the serial pass's pair-HMM device time.  by_construction = sum over chunks of "
+             "passes x (anti-diagonals of its reads: 1 KiB each at the ends of a sweep, a 2 KiB checkpoint per 8 in between "
+             "since round 4) x (write + read back); pmc = (2 x FETCH_SIZE + WRITE_SIZE) of the family's kernels from the "
+             "committed profile of this build (tables and row sums included); 6.3 TB/s = the float4-copy rate of "
+             "MI355X_MICROARCH.md.  With the replay the family is bound by vector-instruction issue (secondary.fp64_tflops, "
+             "DESIGN.md section 6), not by this stream")
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS * world, unit="GB/s",
                     frac=achieved / (HBM_PEAK_GBPS * world),
                     traffic=(traffic[dom] / launches_dom) if traffic and dom in traffic else None, traffic_note=traffic_note,

@@ -44,6 +44,12 @@ namespace {
 #ifndef JTK_PHMM_REPLAY
 #define JTK_PHMM_REPLAY 1      // 0: every pair through the stripe (rounds 2-3)
 #endif
+#ifndef JTK_PHMM_FWD_PREFETCH
+#define JTK_PHMM_FWD_PREFETCH 1     // the forward sweep's fast steps do the same (and load a half group's read bytes a step early)
+#endif
+#ifndef JTK_PHMM_REPLAY_PREFETCH
+#define JTK_PHMM_REPLAY_PREFETCH 1  // the replayed steps fetch their emission entries one step ahead (0: when they need them)
+#endif
 
 __device__ __forceinline__ double rot_from_prev(double v) {  // lane l <- lane (l-1)&63
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -81,6 +87,11 @@ __device__ __forceinline__ bool lanes(uint64_t m) { return __builtin_amdgcn_inve
 // A block that must run under an EXEC mask (and not be turned into selects over everything it assigns): an empty volatile
 // asm cannot be speculated, so the block stays a branch.
 #define KEEP_MASKED asm volatile("")
+#ifdef JTK_PHMM_MARKS  // region markers in the assembly, for reading it (the compiler lays blocks out of order: no census by text order)
+#define MARK(x) asm volatile("; MARK " x)
+#else
+#define MARK(x)
+#endif
 
 // acc_sub += x_sub * vm and acc_ins += x_ins * vm on the lanes whose read base is `Q` (y8 == 8 Q): the row sums split by
 // read base.  fma(x, 0, acc) == acc exactly, so leaving the other lanes out changes no bit (oracle/phmm.c masks vm).
@@ -229,6 +240,10 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
         bool fast_ready = false;
         uint64_t band = 0;
         int lo6 = 0;
+#if JTK_PHMM_FWD_PREFETCH
+        uint32_t Wn = 0;           // the read bytes of the coming half group
+        double eMn = 0.0, eIn = 0.0;  // the emission entries of the coming step
+#endif
         while (t <= T) {
             uint32_t db = 0;
             bool fast = (t & 7) == 0 && t >= f_lo && t + 7 <= f_hi;
@@ -288,6 +303,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 continue;
             }
             // ---- a group of 8 diagonals t .. t+7 inside the interval: EXEC == the band
+            MARK("fwd_group_begin");
             if (!fast_ready) {  // c == c[t-1]
                 const int lo = c - r;
                 lo6 = lo & 63;
@@ -295,6 +311,11 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 xrow = S_EM + xs_of(row);
                 band = rotl64(BAND, lo6);
                 fast_ready = true;
+#if JTK_PHMM_FWD_PREFETCH
+                Wn = window4(EY0 + (uint32_t)(t - row));
+                eMn = lds_f64(xrow | (Wn & 24u));
+                eIn = lds_f64(S_EI + (Wn & 0xffu));
+#endif
             }
             uint32_t W = 0;  // the read bytes of the half group's columns j .. j+3, j = (t + u) - row
             double2 *out = scratch + (int64_t)t * 64;
@@ -309,7 +330,16 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
             const bool block_start = (t & (JTK_SCALE_BLOCK - 1)) == 0;  // step u == 0 opens a scaling block
 #pragma unroll
             for (int u = 0; u < 8; u++) {
+#if JTK_PHMM_FWD_PREFETCH
+                // (see the replayed steps in the backward sweep: entries of step u+1 fetched during step u by every lane.  The
+                // read bytes of the next half group are loaded at the end of this one -- the same state of `row` as at its top)
+                if ((u & 3) == 0) W = Wn;
+                const double eMk = eMn, eIk = eIn;
+#define FWD_EMISSIONS const double eMv = eMk, eIv = eIk;
+#else
                 if ((u & 3) == 0) W = window4(EY0 + (uint32_t)(t + u - row));
+#define FWD_EMISSIONS const double eMv = lds_f64(xrow | (byte & 24u)), eIv = lds_f64(S_EI + byte);
+#endif
                 const double pM = rot_from_prev(toM_2), pD = rot_from_prev(toD_1);
                 toM_2 = toM_1;  // every lane: a lane outside the band shifts its zeros along
                 if ((db >> u) & 1) {  // the band moves up: row c - r leaves it, its lane is spare for the next three moves
@@ -326,14 +356,23 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                     band = (band << 1) | (band >> 63);
                 }
                 const bool in_band = lanes(band);
+#if JTK_PHMM_FWD_PREFETCH
+                {
+                    if ((u & 3) == 3) Wn = window4(EY0 + (uint32_t)(t + u + 1 - row));
+                    const uint32_t bnext = ((u & 3) == 3 ? Wn : W >> (8 * ((u & 3) + 1))) & 0xffu;
+                    eMn = lds_f64(xrow | (bnext & 24u));
+                    eIn = lds_f64(S_EI + bnext);
+                }
+#else
                 const uint32_t byte = (W >> (8 * (u & 3))) & 0xffu;
+#endif
                 if (u == 0) {
                     // the group's first diagonal may open a scaling block (the maximum over the band decides the block's
                     // exponent): the band's work is split around that rare step
                     double fm = 0.0, fi = 0.0, fd = 0.0;
                     if (in_band) {
                         KEEP_MASKED;
-                        const double eMv = lds_f64(xrow | (byte & 24u)), eIv = lds_f64(S_EI + byte);
+                        FWD_EMISSIONS
                         fm = eMv * pM;
                         fi = eIv * toI_1;
                         fd = pD;
@@ -371,7 +410,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 } else {
                     if (in_band) {
                         KEEP_MASKED;
-                        const double eMv = lds_f64(xrow | (byte & 24u)), eIv = lds_f64(S_EI + byte);
+                        FWD_EMISSIONS
                         const double fm = eMv * pM, fi = eIv * toI_1, fd = pD;
                         toM_1 = fma(fd, aDM, fma(fi, aIM, fm * aMM));
                         toI_1 = fma(fd, aDI, fma(fi, aII, fm * aMI));
@@ -391,6 +430,8 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 }
             }
 #undef FWD_STORES
+#undef FWD_EMISSIONS
+            MARK("fwd_group_end");
             t += 8;
         }
     }
@@ -577,6 +618,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 continue;
             }
             // ---- a group of 8 diagonals t .. t-7 inside the interval
+            MARK("bwd_group_begin");
             if (!fast_ready) {  // c == c[t+1]
                 const int lo = c - r, off = (lane - lo) & 63;
                 lo6 = lo & 63;
@@ -601,6 +643,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
             if (low_group) Fsp = fast_pow2(uni(s_EF[(tb >> 6) - 1]) - uni(s_EF[tb >> 6]));
             const double2 *pin = scratch + (int64_t)(tb - 5) * 64 + lane;  // P_{tb-5}; step u puts pin[-64 u] into the ring
 #if JTK_PHMM_REPLAY
+            MARK("replay_begin");
             {   // ---- replay the forward steps of the diagonals tb-12 .. tb-5 from the checkpoint after diagonal tb-13
                 double fM1 = ck0.x, fM2 = ck0.y, fI1 = ck1.x, fD1 = ck1.y;
                 ck0 = pin[-64 * 15];  // the group below, should it replay too: its checkpoint sits in the slots tb-20, tb-19
@@ -612,10 +655,32 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 uint32_t xrowf = S_EM + xs_of(rowf);
                 uint32_t yb = EY0 + (uint32_t)(tb - 12 - rowf);  // the read byte of diagonal tb-12+k: smem[yb + k]
                 uint64_t bandf = rotl64(BAND, lo6f);
+#if JTK_PHMM_REPLAY_PREFETCH
+                // The emission entries of step k+1 are fetched during step k, the read byte they are indexed with during step
+                // k-1, by EVERY lane: a step otherwise starts with two dependent LDS round trips (byte, then entry) in front of its
+                // chain of multiplies.  Valid because a lane's row changes when it LEAVES the band and it is back at the third
+                // later move at the earliest: whatever a lane fetched less than three steps ago was fetched with the row it
+                // has when it is inside the band (lanes outside fetch something, from the padding at worst, and do not use it).
+                uint32_t bn = lds_u8(yb + 1);
+                double eMn, eIn;
+                {
+                    const uint32_t b0 = lds_u8(yb);
+                    eMn = lds_f64(xrowf | (b0 & 24u));
+                    eIn = lds_f64(S_EI + b0);
+                }
+#endif
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const double pM = rot_from_prev(fM2), pD = rot_from_prev(fD1);
                     fM2 = fM1;
+#if JTK_PHMM_REPLAY_PREFETCH
+                    const double eMk = eMn, eIk = eIn;
+#define REPLAY_EMISSIONS(kk) const double eMv = eMk, eIv = eIk;
+#else
+#define REPLAY_EMISSIONS(kk)                    \
+    const uint32_t byte = lds_u8(yb + (kk)); \
+    const double eMv = lds_f64(xrowf | (byte & 24u)), eIv = lds_f64(S_EI + byte);
+#endif
                     if ((w16 >> (3 + k)) & 1u) {
                         if (lanes(1ull << lo6f)) {
                             KEEP_MASKED;
@@ -629,14 +694,20 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                         lo6f = (lo6f + 1) & 63;
                         bandf = (bandf << 1) | (bandf >> 63);
                     }
+#if JTK_PHMM_REPLAY_PREFETCH
+                    if (k < 7) {
+                        eMn = lds_f64(xrowf | (bn & 24u));
+                        eIn = lds_f64(S_EI + bn);
+                        if (k < 6) bn = lds_u8(yb + (uint32_t)(k + 2));
+                    }
+#endif
                     const bool in_bandf = lanes(bandf);
                     if (k == 5 && low_group) {  // diagonal tb-7 opens a scaling block: the forward step scaled by 2^-e == Fsp
                         KEEP_MASKED;
                         double fm = 0.0, fi = 0.0, fd = 0.0;
                         if (in_bandf) {
                             KEEP_MASKED;
-                            const uint32_t byte = lds_u8(yb + k);
-                            const double eMv = lds_f64(xrowf | (byte & 24u)), eIv = lds_f64(S_EI + byte);
+                            REPLAY_EMISSIONS(k)
                             fm = eMv * pM;
                             fi = eIv * fI1;
                             fd = pD;
@@ -655,8 +726,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                     } else {
                         if (in_bandf) {
                             KEEP_MASKED;
-                            const uint32_t byte = lds_u8(yb + k);
-                            const double eMv = lds_f64(xrowf | (byte & 24u)), eIv = lds_f64(S_EI + byte);
+                            REPLAY_EMISSIONS(k)
                             const double fm = eMv * pM, fi = eIv * fI1, fd = pD;
                             fM1 = fma(fd, aDM, fma(fi, aIM, fm * aMM));
                             fI1 = fma(fd, aDI, fma(fi, aII, fm * aMI));
@@ -664,8 +734,10 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                         }
                         q[k] = make_double2(fM2, fD1);
                     }
+#undef REPLAY_EMISSIONS
                 }
             }
+            MARK("replay_end");
 #endif
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -828,6 +900,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 }
                 if ((u & 3) == 3) left = 0;
             }
+            MARK("bwd_group_end");
             t -= 8;
         }
         // rows still in the band after t == 0; c == c[0]

@@ -1,4 +1,5 @@
-"""Experiment (not part of the product), TIMING ONLY -- the results of these builds are garbage: what a checkpointed pair stream
+"""(Applies to the sources of commit f4dcf3d: round 4 then built the real kernel, jtk_amd/csrc/phmm_sweep.hip -- 54.0 -> 45.0 ms,
+the bound this probe gave for C = 8.)  Experiment (not part of the product), TIMING ONLY -- the results of these builds are garbage: what a checkpointed pair stream
 could buy phmm_kernel at best.  VERDICT round 3 (Next 3) asked for a timed build instead of an estimate.
 
 A checkpoint every C-th anti-diagonal is the lane's four forward values (toM_1, toM_2, toI_1, toD_1: 32 bytes) instead of one 16-byte

@@ -58,6 +58,73 @@ def test_modification_table_matches_oracle(lib, tmpl_len, config):
     assert np.array_equal(helpers.bits(tab), helpers.bits(otab))
 
 
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def indel_run_read(rng, tmpl, runs):
+    """(`tmpl` as codes 0..3; the read comes back as ASCII bases) a read that follows `tmpl` with 4 % substitutions and, at the template positions of `runs`, a deletion (k > 0 template
+    bases without a read base) or an insertion (k < 0: -k read bases without a template base) -> (read, ops)"""
+    read, ops, i = [], [], 0
+    runs = dict(runs)
+    while i < len(tmpl):
+        k = runs.pop(i, 0)
+        if k > 0:
+            k = min(k, len(tmpl) - i)
+            ops += [3] * k
+            i += k
+            continue
+        if k < 0:
+            read += list(rng.integers(0, 4, -k))
+            ops += [2] * (-k)
+        if rng.random() < 0.04:
+            read.append((int(tmpl[i]) + int(rng.integers(1, 4))) & 3)
+            ops.append(1)
+        else:
+            read.append(int(tmpl[i]))
+            ops.append(0)
+        i += 1
+    return ACGT[np.array(read, np.int64)], np.array(ops, np.uint8)
+
+
+@pytest.mark.parametrize("tmpl_len,seed", [(1100, 1), (1531, 2), (1985, 3), (2000, 4)])
+def test_modification_table_with_indel_runs_matches_oracle(lib, tmpl_len, seed):
+    """phmm_kernel replays the forward steps of a group of 8 anti-diagonals from a checkpoint only where both sweeps take their
+    unrolled path, and a run of four band moves (or none) inside half a group takes a sweep off it: reads with deletion and
+    insertion runs of 3-15 bases at every alignment of the run against the groups, near both ends of the sweep and across
+    the 64-diagonal scaling blocks, so that replayed, streamed and generic groups meet in every order"""
+    rng = np.random.default_rng(seed)
+    p = jb.default_params(haploid_coverage=25.0)
+    tmpl = rng.integers(0, 4, tmpl_len).astype(np.uint8)
+    reads, ops = [], []
+    for r in range(6):
+        runs, pos = {}, int(rng.integers(3, 40))
+        while pos < tmpl_len - 20:
+            k = int(rng.integers(3, 16))
+            runs[pos] = k if rng.random() < 0.6 else -k
+            pos += k + int(rng.integers(1, 90))   # sometimes two runs within one group of diagonals
+        if r == 0:
+            runs = {}                               # one plain read: every inner group replays
+        rd, op = indel_run_read(rng, tmpl, runs)
+        reads.append(rd)
+        ops.append(op)
+    strands = [1, 0, 1, 0, 1, 1]
+    tmpl = ACGT[tmpl]
+    tab, lk = api.modification_table(p, tmpl, reads, ops, strands)
+    po = helpers.oracle_params(p)
+    import ctypes as C
+    rb, ob = np.concatenate(reads), np.concatenate(ops)
+    ro = np.zeros(7, np.uint64)
+    oo = np.zeros(7, np.uint64)
+    ro[1:] = np.cumsum([len(x) for x in reads])
+    oo[1:] = np.cumsum([len(x) for x in ops])
+    otab = np.zeros_like(tab)
+    olk = np.zeros(6)
+    O.lib().jo_modification_table(C.byref(po), O.u8p(tmpl), tmpl_len, 6, O.u8p(rb), O.u64p(ro), O.u8p(ob), O.u64p(oo),
+                                  O.u8p(np.array(strands, np.uint8)), O.f64p(otab), O.f64p(olk))
+    assert np.array_equal(helpers.bits(lk), helpers.bits(olk))
+    assert np.array_equal(helpers.bits(tab), helpers.bits(otab))
+
+
 def test_modification_table_rejects_inconsistent_ops(lib):
     b, cfg, p = helpers.small_batch(n_chunks=1, tmpl_len=200, reads_per_hap=2)
     reads = list(b.chunk_reads(0))
