@@ -213,8 +213,10 @@ def pmc_traffic(workload, sha):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=1)
+    # defaults: the first one or two passes of a process still map workspaces and fill the stream pipeline (six slices in flight),
+    # and a pass is < 1 s -- ten timed passes after three untimed ones cost 13 s of a run that takes minutes for its other legs
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3_ont_diploid_2500x60x2kbp", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
                     help="strong: the workload's fixed dataset is sharded over the ranks; weak: every rank its own chunks")
