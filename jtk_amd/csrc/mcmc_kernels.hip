@@ -1295,20 +1295,8 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
     rng.ring = m.ring;
     rng.rec = m.rec;
     const bool small = n <= 63u, big = n > 255u;
-    // size_to_lk[x] = max_{c=1..K} poisson_lk(x, cov*c): registers up to 255 reads, LDS beyond (as mcmc_chain)
-    LaneTab size_to_lk;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t x = lane + 64 * r;
-        double mx = -__builtin_inf();
-        if (x <= n)
-            for (int c = 1; c <= K; c++) {
-                const double lam = cov * (double)c;
-                mx = jtk_fmax(mx, (double)x * jtk_log(lam) - lam - m.lfact[x]);
-            }
-        size_to_lk.v[r] = mx;
-    }
-    if (big) {
+    // size_to_lk[x] = max_{c=1..K} poisson_lk(x, cov*c), in LDS whatever n is (round 4: see size_lk below)
+    {
         for (uint32_t x = lane; x <= n; x += 64) {
             double mx = -__builtin_inf();
             for (int c = 1; c <= K; c++) {
@@ -1319,9 +1307,13 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
         }
         wsync();
     }
-    auto size_lk = [&](uint32_t x) -> double {
-        return big ? unif64(m.size_to_lk[x]) : (small ? tab_get<true>(size_to_lk, x) : tab_get<false>(size_to_lk, x));
-    };
+    // One LDS load, no branch.  Up to round 4 this read the table from its 4 registers for n <= 255 (`tab_get`: a switch on
+    // x >> 6 around a pair of v_readlane): nine look-ups per accepted move and K per get_lk, ~8 branches each -- and a taken
+    // branch costs a lone wave ~20 cycles: 2,200 -> 730 cycles for the state + size terms of an accept, 1,040 -> 480 for
+    // get_lk (K = 2, 160 reads; profiles/r04_tab_event_breakdown.txt).
+    auto size_lk = [&](uint32_t x) -> double { return unif64(m.size_to_lk[x]); };
+    (void)small;
+    (void)big;
     // ---- initial LKCounts in the reference's order (reads outer); lane = column
     double tg[K];
     int np[K], w[K], cl[K];
