@@ -652,7 +652,7 @@ def main():
         api.trim_cache(local_rank)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         cold_ph, _ = stage_e2e(params, batch, cfg, local_rank)
-        warm_ph, st_out = stage_e2e(params, batch, cfg, local_rank, os.path.join(ROOT, "gpurun_out", "record_r03.tsv"))
+        warm_ph, st_out = stage_e2e(params, batch, cfg, local_rank, os.path.join(ROOT, "gpurun_out", "record_r05.tsv"))
         line["stage_e2e"] = dict(
             cold=cold_ph, warm=warm_ph, chunks_per_s_warm=batch.n_chunks / (warm_ph["total_ms"] / 1e3),
             chunks_ok=int((st_out["result"]["status"] == 0).sum()),

@@ -1,6 +1,6 @@
 /* jtk_eigen.h -- symmetric eigendecomposition shared by the product (jtk_amd/csrc/correction.cpp) and the CPU oracle
  * (oracle/correction.c), the way jtk_math.h shares exp / log: the reference takes it from nalgebra
- * (`DMatrix::symmetric_eigen`, haplotyper/src/phmm_likelihood_correction.rs:419), which is not under /root/reference.
+ * (`DMatrix::symmetric_eigen`, haplotyper/src/phmm_likelihood_correction.rs:418), which is not under /root/reference.
  * OWN SPECIFICATION: cyclic Jacobi, rows/columns swept in index order, rotations as in Golub & Van Loan 8.4; stops when
  * no off-diagonal entry exceeds 1e-14 x the largest diagonal magnitude (or after 64 sweeps).  Eigenvalue i is a[i][i],
  * eigenvector i is COLUMN i of v; the order is whatever the sweeps leave (the caller sorts).  Eigenvectors are defined

@@ -18,6 +18,14 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: the entry points below (and the diagnostic ones of jtk_lc_debug.h) are
+ * its only dynamic symbols. */
+#if defined(__GNUC__) || defined(__clang__)
+#define JTK_LC_API __attribute__((visibility("default")))
+#else
+#define JTK_LC_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -43,7 +51,7 @@ typedef enum jtk_status {
     JTK_OK = 0,
     JTK_ERR_INVALID_ARG = -1,     /* null pointer, inconsistent offsets, non-ACGT base, bad op code    */
     JTK_ERR_NO_DEVICE = -2,       /* no usable MI355X / HIP runtime failure (message via last_error)   */
-    JTK_ERR_UNSUPPORTED = -3,     /* band radius > 127, pile-up of more than 1023 reads                 */
+    JTK_ERR_UNSUPPORTED = -3,     /* band radius > 127 (any read count is taken)                        */
     JTK_ERR_ALLOC = -4,           /* hipMalloc / host allocation failed                                */
     JTK_ERR_OPS_MISMATCH = -5,    /* ops do not consume exactly the template and the read              */
     JTK_ERR_CHUNK_FAILED = -6,    /* >=1 chunk hit a condition on which the reference panics; see      */
@@ -125,7 +133,7 @@ typedef struct jtk_lc_result {
  *                   ops_cap bytes (sum(ops_len) + 8*polish edits; same overrun rule).
  * device          : HIP device ordinal (one process drives one GPU; multi-GPU = one process per GPU).
  */
-int jtk_lc_cluster_chunks(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+JTK_LC_API int jtk_lc_cluster_chunks(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
                           const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
                           const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
                           uint32_t *label, double *log_post, uint32_t post_stride, jtk_lc_result_t *result,
@@ -140,7 +148,7 @@ int jtk_lc_cluster_chunks(const jtk_lc_params_t *params, size_t n_chunks, const 
  * Precondition (checked here since ABI 2, as the single-device call always did when it built its session): the chunks' reads
  * are laid out back to back in chunk order (chunks[0].read_first == 0, chunks[c + 1].read_first == chunks[c].read_first +
  * chunks[c].n_reads) -- JTK_ERR_INVALID_ARG otherwise. */
-int jtk_lc_cluster_chunks_multi(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+JTK_LC_API int jtk_lc_cluster_chunks_multi(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
                                 const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
                                 const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
                                 uint32_t *label, double *log_post, uint32_t post_stride, jtk_lc_result_t *result,
@@ -151,7 +159,7 @@ int jtk_lc_cluster_chunks_multi(const jtk_lc_params_t *params, size_t n_chunks, 
  * polish_until_converge_antidiagonal.  This is `pseudo_mcmc::clustering` (pseudo_mcmc.rs:77-107) batched;
  * a Rust host that keeps real kiley polishing calls this one and inherits exactness downstream.
  * cons_out/ops_out are not produced. */
-int jtk_lc_cluster_polished(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+JTK_LC_API int jtk_lc_cluster_polished(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
                             const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
                             const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
                             uint32_t *label, double *log_post, uint32_t post_stride,
@@ -165,7 +173,7 @@ int jtk_lc_cluster_polished(const jtk_lc_params_t *params, size_t n_chunks, cons
  * (band / 2, N, 3)).  Only the first take_num reads of a window vote in a round (0 = all); every read's ops are
  * re-threaded.  radius 0 derives the radius from the window length and params->band_frac as mod.rs:96 does.
  * result[c].polish_rounds / .status are filled; cons_out / ops_out as in jtk_lc_cluster_chunks. */
-int jtk_lc_polish_chunks(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+JTK_LC_API int jtk_lc_polish_chunks(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
                          const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
                          const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t radius,
                          uint32_t take_num, uint32_t ignore_edge, uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap,
@@ -178,25 +186,25 @@ int jtk_lc_polish_chunks(const jtk_lc_params_t *params, size_t n_chunks, const j
  * The reference enters this stage up to ~6 times per pipeline run on overlapping chunk sets
  * (cli/src/pipeline.rs:158,164-168), which is what a resident session serves. */
 typedef struct jtk_lc_session jtk_lc_session_t;
-int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+JTK_LC_API int jtk_lc_session_create(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
                           const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
                           const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
                           uint32_t post_stride, int device, jtk_lc_session_t **out);
 /* One pass of the hot path over the resident batch; skip_polish != 0 gives jtk_lc_cluster_polished
  * semantics.  Returns after the device has finished; results stay on the device until fetched. */
-int jtk_lc_session_run(jtk_lc_session_t *s, int skip_polish);
+JTK_LC_API int jtk_lc_session_run(jtk_lc_session_t *s, int skip_polish);
 /* Copies the last run's results out (any pointer may be NULL to skip that output). */
-int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post, jtk_lc_result_t *result,
+JTK_LC_API int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post, jtk_lc_result_t *result,
                          uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out,
                          uint64_t *ops_out_off, uint64_t ops_cap);
-int jtk_lc_session_destroy(jtk_lc_session_t *s);
+JTK_LC_API int jtk_lc_session_destroy(jtk_lc_session_t *s);
 
 /* ---- stage pieces, exported because the reference exposes them too ------------------------------ */
 
 /* `pseudo_mcmc::modification_table` (pseudo_mcmc.rs:45-68) for one pile-up: for read r, table[r] has
  * JTK_NUM_ROW*(tmpl_len+1) doubles = kiley modification_table_antidiagonal(...) MINUS lk[r]
  * (pseudo_mcmc.rs:62-64); lk[r] is the read's log-likelihood under the unedited template. */
-int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl, uint64_t tmpl_len,
+JTK_LC_API int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl, uint64_t tmpl_len,
                               uint32_t n_reads, const uint8_t *read_bases, const uint64_t *read_off,
                               const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand,
                               double *table, double *lk, int device);
@@ -217,7 +225,7 @@ typedef struct jtk_lc_feature_chunk {
     double local_coverage; /* ClusteringConfig.local_coverage (mod.rs:108-112) */
 } jtk_lc_feature_chunk_t;
 
-int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks,
+JTK_LC_API int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks,
                             const jtk_lc_feature_chunk_t *chunks, const double *variants,
                             const uint32_t *variant_type, uint32_t *label, double *log_post,
                             uint32_t post_stride, jtk_lc_result_t *result, int device);
@@ -231,7 +239,7 @@ int jtk_lc_cluster_features(const jtk_lc_params_t *params, size_t n_chunks,
  * simulated reads, every read scored against both members of its pair with the banded pair-HMM
  * (likelihood_antidiagonal_bootstrap); the sampling runs on the host, the bootstrap alignments and the
  * likelihoods on the device.  `out` is what jtk_lc_params_t.gains expects. */
-int jtk_lc_estimate_gains(const jtk_hmm_t *forward, const jtk_hmm_t *reverse, uint64_t seed, uint32_t seq_len,
+JTK_LC_API int jtk_lc_estimate_gains(const jtk_hmm_t *forward, const jtk_hmm_t *reverse, uint64_t seed, uint32_t seq_len,
                           uint32_t band, uint32_t homop_len, jtk_gains_t *out, int device);
 
 /* `estimate_minimum_gain(&hmm)` (likelihood_gains.rs:6-39), the scale of correct_clustering's protection rule
@@ -240,7 +248,7 @@ int jtk_lc_estimate_gains(const jtk_hmm_t *forward, const jtk_hmm_t *reverse, ui
  * simulated reads of lk(read | template) - lk(read | template minus the base) with the banded bootstrap likelihood; the
  * third smallest median, at least 1.  The reference's constants: seed 23908, 1000, 500, 100, band 25.  Sampling on the
  * host, alignments and likelihoods on the device (the machinery of jtk_lc_estimate_gains; own specification of kiley). */
-int jtk_lc_estimate_minimum_gain(const jtk_hmm_t *forward, const jtk_hmm_t *reverse, uint64_t seed, uint32_t sample_num,
+JTK_LC_API int jtk_lc_estimate_minimum_gain(const jtk_hmm_t *forward, const jtk_hmm_t *reverse, uint64_t seed, uint32_t sample_num,
                                  uint32_t seq_num, uint32_t len, uint32_t band, double *out, int device);
 
 /* ---- stage preamble: model refit ----------------------------------------------------------------------
@@ -252,7 +260,7 @@ int jtk_lc_estimate_minimum_gain(const jtk_hmm_t *forward, const jtk_hmm_t *reve
  * (DataSet.model_param), params->band_frac the read type's; the refitted models are what jtk_lc_params_t.forward /
  * .reverse then carry.  kiley's fit is not part of the reference tree: the step is this build's own specification
  * (expected transition / emission counts of the banded pair-HMM, rows renormalised). */
-int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
+JTK_LC_API int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc_chunk_t *chunks,
                      const uint8_t *tmpl_bases, const uint8_t *read_bases, const uint64_t *read_off,
                      const uint8_t *ops, const uint64_t *ops_off, const uint8_t *strand, uint32_t rounds,
                      jtk_hmm_t *forward_out, jtk_hmm_t *reverse_out, int device);
@@ -260,10 +268,10 @@ int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_l
 /* ---- the first consumer of the stage's posteriors: cross-chunk correction ------------------------------------
  * Replaces `AlignmentCorrection::correct_clustering_selected` (haplotyper/src/phmm_likelihood_correction.rs:32-97): per
  * selected chunk with more than one cluster, a read-by-read similarity matrix from a 3-state affine-gap alignment of the
- * neighbouring nodes' posteriors (`alignment` :475-490, `align_swg` :493-542, `sim` :545-561; on the device), then spectral
- * clustering on the host (graph Laplacian :395-412, eigenvectors below 0.2 :415-473, 20 x misc::kmeans :295-302), the
- * adjusted Rand index against the previous labels (:222-243), suppression of the lowest 5 % (:100-105) unless the chunk's
- * local-clustering score protects it (:108-127).
+ * neighbouring nodes' posteriors (`alignment` :466-479, `align_swg` :482-531, `sim` :534-550; on the device), then spectral
+ * clustering on the host (graph Laplacian :385-402, eigenvectors below 0.2 :405-464, 20 x misc::kmeans :295-302), the
+ * adjusted Rand index against the previous labels (:220-240), suppression of the lowest 5 % (:100-105) unless the chunk's
+ * local-clustering score protects it (:108-129).
  * The data set reaches the call flattened: read r owns nodes node_off[r] .. node_off[r+1] (in read order), node e has
  * post_len log-posteriors at posteriors[post_off].  chunks[] is DataSet.selected_chunks (cluster_num is updated in place).
  * min_gain is `estimate_minimum_gain(&hmm) * PROTECT_FACTOR` (:118): a simulation through kiley that the caller runs.
@@ -284,33 +292,33 @@ typedef struct jtk_cc_chunk {
     uint32_t copy_num;    /* Chunk.copy_num             */
     double score;         /* Chunk.score                */
 } jtk_cc_chunk_t;
-int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id, const uint64_t *node_off, const jtk_cc_node_t *nodes,
+JTK_LC_API int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id, const uint64_t *node_off, const jtk_cc_node_t *nodes,
                               const double *posteriors, size_t n_chunks, jtk_cc_chunk_t *chunks, size_t n_selected,
                               const uint64_t *selection, double haploid_coverage, double min_gain, uint64_t *cluster_out,
                               uint8_t *touched, int device);
 
 /* Sort key of pileup_nodes (mod.rs:47-50): number of alignment columns that are not '|' in
  * Node::recover (definitions/src/lib.rs:773-813) for run-length cigar ops given per base. */
-int jtk_lc_pileup_sort_key(const uint8_t *tmpl, uint64_t tmpl_len, const uint8_t *read, uint64_t read_len,
+JTK_LC_API int jtk_lc_pileup_sort_key(const uint8_t *tmpl, uint64_t tmpl_len, const uint8_t *read, uint64_t read_len,
                            const uint8_t *ops, uint64_t ops_len, uint64_t *key_out);
 
 /* normalize_local_clustering for one pile-up (normalize.rs:21-50): relabels by descending cluster size
  * (ties: larger old index first) and permutes each posterior row in place. */
-int jtk_lc_normalize_pileup(uint32_t n_reads, uint32_t cluster_num, uint32_t *label, double *log_post,
+JTK_LC_API int jtk_lc_normalize_pileup(uint32_t n_reads, uint32_t cluster_num, uint32_t *label, double *log_post,
                             uint32_t post_stride);
 
 /* Device workspaces of finished calls are kept for the next call of similar shape (up to JTK_LC_POOL_GB per device,
  * default 32; 0 disables the pool): mapping tens of GB for a 2500-chunk batch costs seconds otherwise.  This returns
  * them to the driver. */
-int jtk_lc_trim_cache(int device);
+JTK_LC_API int jtk_lc_trim_cache(int device);
 
-const char *jtk_lc_strerror(int status);
+JTK_LC_API const char *jtk_lc_strerror(int status);
 /* Thread-local text of the last failure on this thread (HIP error strings etc.); "" if none.  The pointer is valid until
  * this thread's next call into the library: copy the text before calling anything else. */
-const char *jtk_lc_last_error(void);
-int jtk_lc_version(void);
+JTK_LC_API const char *jtk_lc_last_error(void);
+JTK_LC_API int jtk_lc_version(void);
 /* 1 if a gfx950 device `device` is present and the kernels for it are loaded. */
-int jtk_lc_device_ok(int device);
+JTK_LC_API int jtk_lc_device_ok(int device);
 
 /* Timing of the last jtk_lc_cluster_* call on this thread, measured with HIP events on the library's
  * own stream: total device milliseconds and the milliseconds + launch count of each kernel family
@@ -324,7 +332,7 @@ typedef struct jtk_lc_timing {
     uint32_t chain_lds_bytes[2]; /* LDS work area per chain workgroup of the two launch classes (0: class not used); class 0
                                   * stays <= 80 KiB (two workgroups per CU), class 1 <= 160 KiB */
 } jtk_lc_timing_t;
-int jtk_lc_last_timing(jtk_lc_timing_t *out);
+JTK_LC_API int jtk_lc_last_timing(jtk_lc_timing_t *out);
 
 #ifdef __cplusplus
 }

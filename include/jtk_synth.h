@@ -22,7 +22,7 @@ typedef struct jtk_synth_cfg {
 
 /* One pile-up: n = n_haps*reads_per_hap reads in generation order (NOT yet in pileup_nodes order).
  * read_off/ops_off have n+1 entries; strand[n]; truth[n] = haplotype of each read. 0 or -1. */
-int jtk_synth_pileup(const jtk_synth_cfg_t *cfg, uint8_t *tmpl, uint64_t tmpl_cap, uint64_t *tmpl_len_out,
+__attribute__((visibility("default"))) int jtk_synth_pileup(const jtk_synth_cfg_t *cfg, uint8_t *tmpl, uint64_t tmpl_cap, uint64_t *tmpl_len_out,
                      uint8_t *reads, uint64_t reads_cap, uint64_t *read_off, uint8_t *ops, uint64_t ops_cap,
                      uint64_t *ops_off, uint8_t *strand, uint32_t *truth);
 

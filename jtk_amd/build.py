@@ -11,13 +11,14 @@ OUT = os.path.join(OUT_DIR, "libjtk_lc.so")
 # the synthetic pile-up generator (bench.py and tests only) is NOT part of the product library
 SYNTH_OUT = os.path.join(OUT_DIR, "libjtk_synth.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+EXPORTS_MAP = os.path.join(CSRC, "exports.map")  # only jtk_lc_* leaves the library
 
 SOURCES = ["phmm_kernels.hip", "phmm_sweep.hip", "phmm_pair.hip", "phmm_wide.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip", "session.hip", "gains.hip", "correction.hip",
            "host_api.cpp"]
 SYNTH_SOURCES = ["synth.cpp"]
 # -ffp-contract=off: device f64 arithmetic must round exactly like the reference (no implicit fma);
 # the pair-HMM specification uses explicit fma() where it wants one.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
          "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("JTK_EXTRA_HIPCC_FLAGS", "").split()
 
 
@@ -53,8 +54,8 @@ def build(force=False, verbose=False):
             failed = True
     if failed:
         raise RuntimeError("hipcc failed")
-    if force or _stale(OUT, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if force or _stale(OUT, objs + [EXPORTS_MAP]):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + EXPORTS_MAP, "-o", OUT] + objs
         subprocess.check_call(cmd)
     if force or _stale(SYNTH_OUT, synth_objs):
         subprocess.check_call([HIPCC, "-shared", "-fPIC", "-o", SYNTH_OUT] + synth_objs)
@@ -80,7 +81,7 @@ def build_experiment(name, extra_flags):
             sys.stderr.write(out.decode())
             raise RuntimeError("hipcc failed on " + src)
     lib = os.path.join(out_dir, "libjtk_lc_%s.so" % name)
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + EXPORTS_MAP, "-o", lib] + objs)
     return lib
 
 
@@ -99,7 +100,7 @@ def source_sha16():
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS[:7]).encode())
+    h.update(" ".join(FLAGS[:6] + FLAGS[7:8]).encode())  # (visibility does not change a kernel)
     return h.hexdigest()[:16]
 
 

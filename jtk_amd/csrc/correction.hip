@@ -2,14 +2,14 @@
 //
 // Replaces `AlignmentCorrection::correct_clustering_selected` (haplotyper/src/phmm_likelihood_correction.rs:32-97).
 // Per selected chunk with more than one cluster:
-//   similarity fill (:275-289)  N x N `alignment` (:475-490): two affine-gap alignments of neighbouring nodes' posteriors
-//                               (`align_swg` :493-542 with `sim` :545-561 as the match score) + the centre's `sim`
+//   similarity fill (:272-285)  N x N `alignment` (:466-479): two affine-gap alignments of neighbouring nodes' posteriors
+//                               (`align_swg` :482-531 with `sim` :534-550 as the match score) + the centre's `sim`
 //                               -> ONE DEVICE KERNEL over every ordered pair of every chunk (the O(N^2 ctx^2) part);
-//   spectral clustering         filter_similarity :339-356, graph Laplacian :395-412, eigenvectors with eigenvalue below 0.2
-//                               :415-473 (nalgebra in the reference; include/jtk_eigen.h here), posteriors appended, columns
+//   spectral clustering         filter_similarity :330-347, graph Laplacian :385-402, eigenvectors with eigenvalue below 0.2
+//                               :405-464 (nalgebra in the reference; include/jtk_eigen.h here), posteriors appended, columns
 //                               normalised, 20 x misc::kmeans on Xoroshiro128PlusPlus(id * k) -> host threads, one chunk each;
-//   decision                    adjusted Rand index against the previous labels on biased reads :222-243, suppression of the
-//                               lowest 5 % :100-105 unless the chunk is protected by its local-clustering score :108-127.
+//   decision                    adjusted Rand index against the previous labels on biased reads :220-240, suppression of the
+//                               lowest 5 % :100-105 unless the chunk is protected by its local-clustering score :108-129.
 // Sums, sorts and tie-breaks follow the reference (stable sorts, `max_by` = last maximum, `min_by` = first minimum); the CPU
 // oracle (oracle/correction.c) is the line-by-line restatement this file is tested against.  Where the reference panics the
 // call returns JTK_ERR_CHUNK_FAILED and writes nothing.
@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "device_common.h"
+#include "jtk_lc_debug.h"
 #include "jtk_eigen.h"
 
 extern "C" void jtk_internal_set_error(const char *msg);
@@ -53,14 +54,14 @@ struct PairJob {  // one chunk's block of the similarity fill
 
 __device__ __forceinline__ double d_max3(double a, double b, double c) { return jtk_fmax(jtk_fmax(a, b), c); }
 
-// logit_from_lnp :564-577 (ln_1p as jtk_log(1 + x)); *panic is set where the reference asserts
+// logit_from_lnp :553-566 (ln_1p as jtk_log(1 + x)); *panic is set where the reference asserts
 __device__ double d_logit_from_lnp(double lnp, int *panic) {
     if (!(lnp <= 0.0)) *panic = 1;
     if (lnp < -80.0) return -80.0;
     if (-1.8e-35 < lnp) return 80.0;
     return lnp - jtk_log(1.0 + (-jtk_exp(lnp)));
 }
-// sim :545-561 with the streaming LogSumExp of misc.rs:94-140
+// sim :534-550 with the streaming LogSumExp of misc.rs:94-140
 __device__ double d_sim(const double *xs, uint32_t nx, const double *ys, uint32_t ny, const double *cps, uint32_t nc, int *panic) {
     if (nx != nc || nx != ny) {
         *panic = 1;
@@ -86,7 +87,7 @@ __device__ double d_sim(const double *xs, uint32_t nx, const double *ys, uint32_
     if (logit == __builtin_inf() || logit == -__builtin_inf()) *panic = 1;
     return logit;
 }
-// align_swg :493-542 with two rolling rows of (len2 + 1) x 3 doubles in `rows`
+// align_swg :482-531 with two rolling rows of (len2 + 1) x 3 doubles in `rows`
 __device__ double d_align_swg(const ArmEnt *arm1, uint32_t len1, const ArmEnt *arm2, uint32_t len2, const double *post,
                               const double *cn, const uint64_t *cn_off, const uint32_t *cn_len, double *rows, int *panic) {
     const double GAP_OPEN = -0.5, GAP_EXTEND = -100.0, MISM = -100.0;
@@ -147,7 +148,7 @@ __device__ double d_align_swg(const ArmEnt *arm1, uint32_t len1, const ArmEnt *a
     return best;
 }
 
-// every ordered pair (i, j), i != j, of every job: sims[i][j] = alignment(ctx_i, ctx_j) (:475-490)
+// every ordered pair (i, j), i != j, of every job: sims[i][j] = alignment(ctx_i, ctx_j) (:466-479)
 __global__ void similarity_kernel(uint64_t n_pairs, uint32_t n_jobs, const PairJob *jobs, const Member *members, const ArmEnt *arms,
                                   const double *post, const double *cn, const uint64_t *cn_off, const uint32_t *cn_len,
                                   double *sims, double *scratch, uint32_t row_doubles, int *panic_out) {
@@ -178,7 +179,7 @@ __global__ void similarity_kernel(uint64_t n_pairs, uint32_t n_jobs, const PairJ
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// host: random sampling of rand 0.8.5 on rand_xoshiro 0.6.0's Xoroshiro128PlusPlus (phmm_likelihood_correction.rs:295-296)
+// host: random sampling of rand 0.8.5 on rand_xoshiro 0.6.0's Xoroshiro128PlusPlus (phmm_likelihood_correction.rs:299-301)
 // and misc::kmeans (misc.rs:229-341), as the reference calls them
 // ---------------------------------------------------------------------------------------------------------------------
 struct Rng128 {
@@ -412,10 +413,10 @@ thread_local std::vector<double> g_first_sims;
 
 }  // namespace
 
-// test hooks (not in include/jtk_lc.h): keep the raw similarity matrix of the first corrected chunk of the next calls on this
+// test hooks (include/jtk_lc_debug.h, not the boundary header): keep the raw similarity matrix of the first corrected chunk of the next calls on this
 // thread, and read it back -- the device fill is compared bit for bit with the oracle's
-extern "C" void jtk_internal_cc_keep_sims(int on) { g_keep_sims = on != 0; }
-extern "C" size_t jtk_internal_cc_first_sims(double *out, size_t cap) {
+extern "C" void jtk_lc_debug_cc_keep_sims(int on) { g_keep_sims = on != 0; }
+extern "C" size_t jtk_lc_debug_cc_first_sims(double *out, size_t cap) {
     const size_t n = std::min(cap, g_first_sims.size());
     if (out && n) memcpy(out, g_first_sims.data(), n * sizeof(double));
     return g_first_sims.size();
@@ -469,7 +470,7 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
         }
     }
     if (panic) return cc_fail(JTK_ERR_CHUNK_FAILED, "a node refers to a chunk id beyond the selected chunks");
-    // ---- estimate_copy_number_of_cluster :129-182
+    // ---- estimate_copy_number_of_cluster :131-181
     std::vector<uint64_t> cn_off(n_chunks + 1, 0);
     std::vector<uint32_t> cn_len(n_chunks);
     for (size_t c = 0; c < n_chunks; c++) {
@@ -509,7 +510,7 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
         }
         for (size_t q = 0; q < kk; q++) obs[q] = est[q];
     }
-    // ---- the chunks to correct (selected_chunks order), their members (correct_chunk :191-199) and contexts (:246-264)
+    // ---- the chunks to correct (selected_chunks order), their members (correct_chunk :191-199) and contexts (:243-261)
     struct Job {
         size_t chunk;
         std::vector<std::pair<size_t, size_t>> mem;  // (read, idx), sorted by the node's cluster (stable)
@@ -681,7 +682,7 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
             j.panic = true;
             return;
         }
-        {  // filter_similarity :339-356
+        {  // filter_similarity :330-347
             std::vector<uint8_t> keep(n * n, 0);
             std::vector<double> tmp(n);
             for (size_t i = 0; i < n; i++) {
@@ -695,7 +696,7 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
                 if (!keep[e]) S[e] = 0.0000000000000001;
         }
         std::vector<double> rowsum(n), sq_inv(n), lap(n * n), vec(n * n);
-        for (size_t i = 0; i < n; i++) {  // get_graph_laplacian :395-412
+        for (size_t i = 0; i < n; i++) {  // get_graph_laplacian :385-402
             double s = 0.0;
             for (size_t q = 0; q < n; q++) s += S[i * n + q];
             rowsum[i] = s;
@@ -703,7 +704,7 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
         }
         for (size_t i = 0; i < n; i++)
             for (size_t q = 0; q < n; q++) lap[i * n + q] = q == i ? 1.0 : -S[i * n + q] * sq_inv[i] * sq_inv[q];
-        jtk_symmetric_eigen(lap.data(), n, vec.data());  // get_eigenvalues :415-473
+        jtk_symmetric_eigen(lap.data(), n, vec.data());  // get_eigenvalues :405-464
         std::vector<size_t> order(n);
         for (size_t i = 0; i < n; i++) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return std::fabs(lap[a * n + a]) < std::fabs(lap[b * n + b]); });
@@ -727,18 +728,18 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
             const double total = logsumexp(p, pl);
             for (size_t q = 0; q < pl; q++) feat[i * dim + pick_k + q] = jtk_exp(p[q] - total);
         }
-        for (size_t q = 0; q < dim; q++) {  // normalize_columns :378-391
+        for (size_t q = 0; q < dim; q++) {  // normalize_columns :369-381
             double s = 0.0;
             for (size_t i = 0; i < n; i++) s += feat[i * dim + q] * feat[i * dim + q];
             s = std::sqrt(s);
             for (size_t i = 0; i < n; i++) feat[i * dim + q] /= s;
         }
-        Rng128 rng(chunk.id * (uint64_t)chunk.cluster_num);  // :295-296
+        Rng128 rng(chunk.id * (uint64_t)chunk.cluster_num);  // :299-301
         const size_t cluster_num = std::min<size_t>(chunk.cluster_num, pick_k);
         std::vector<size_t> cur;
         double best = 0.0;
         bool have = false;
-        for (int it = 0; it < 20; it++) {  // :298-302: min_by keeps the first minimum
+        for (int it = 0; it < 20; it++) {  // :303-307: min_by keeps the first minimum
             double dist = 0.0;
             if (!kmeans(feat, n, dim, cluster_num, rng, &dist, cur)) {
                 j.panic = true;
@@ -751,7 +752,7 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
             }
         }
         j.k = cluster_num;
-        // adj_rand_on_biased :222-243
+        // adj_rand_on_biased :220-240
         std::vector<size_t> prev(n), pb, ab;
         for (size_t i = 0; i < n; i++) {
             const jtk_cc_node_t &nd = nodes[node_off[j.mem[i].first] + j.mem[i].second];
@@ -786,7 +787,7 @@ extern "C" int jtk_lc_correct_clustering(size_t n_reads, const uint64_t *read_id
     }  // batches
     for (const Job &j : jobs)
         if (j.panic) return cc_fail(JTK_ERR_CHUNK_FAILED, "chunk " + std::to_string(chunks[j.chunk].id) + ": the reference panics on this pile-up");
-    // ---- get_protected_clusterings :108-127, supress_threshold :100-105, write-back :46-96
+    // ---- get_protected_clusterings :108-129, supress_threshold :100-105, write-back :46-96
     std::vector<uint8_t> prot(n_chunks, 0);
     for (size_t c = 0; c < n_chunks; c++) {
         if (coverage[c] == 0) continue;

@@ -1734,59 +1734,75 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
 // the window with one v_readlane per step.
 // Bit-identical to the one-step-at-a-time chain by construction; checked against the oracle.
 // The consumer's view of 64 consecutive stream positions (lane l = position base + l): the producer's record of
-// the proposal that WOULD start there.
+// the proposal that WOULD start there.  LDS is addressed by byte offset here (a generic pointer indexed per lane costs a
+// 64-bit add and a null check per access).
+typedef __attribute__((address_space(3))) const volatile u32x4_t lds_cvu32x4;
+typedef __attribute__((address_space(3))) volatile u32x4_t lds_vu32x4;
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
 struct Window {
     uint32_t base;
-    uint32_t nxt;  // per lane: window offset of the following proposal (Bernoulli draw taken), 255 = not in this window
+    uint32_t w0;   // per lane: the state-independent part of the hop word: nxt in bits 0..5, HW_OUT
     uint32_t idx;  // per lane: the read index the proposal starting here picks
-    float u;       // per lane: the draw its Bernoulli test compares, / 2^64, truncated to 19 bits
+    float u;       // per lane: the draw its Bernoulli test compares, / 2^64, truncated to 19 bits; -1 outside the window
 };
-__device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t base, uint32_t lane) {
+// The hop word of window position l (one v_readlane per hop yields all of it):
+//   bits 0..5 nxt[l] | 64 skip: the proposal starting at l lies inside the window, is certainly rejected and leaves no residue
+//   | 128 certainly accepted | 256 accepted without a draw | 512 certainly rejected | 1024 not in this window.
+#define HW_SKIP 64u
+#define HW_ACC 128u
+#define HW_NODRAW 256u
+#define HW_REJ 512u
+#define HW_OUT 1024u
+__device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t rec_lds, uint32_t base, uint32_t lane) {
     rng.pos = base;
     rng_release(rng, lane);
     rng_wait_rec(rng, base + 64);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     wd.base = base;
-    const uint32_t r = lds_ld32(&rng.rec[(base + lane) & (RN - 1)]);
-    const uint32_t len = (r >> 7) & 63u;
+    const uint32_t r = *(lds_vu32 *)(uintptr_t)(rec_lds + (((base + lane) & (RN - 1)) << 2));
+    const uint32_t len = (r >> 7) & 63u, nxt = lane + len;
+    const bool in_w = len != 0 && nxt < 64;
     wd.idx = r & 127u;
-    wd.nxt = (len != 0 && lane + len < 64) ? lane + len : 255u;
-    wd.u = (float)(r >> 13) * 0x1p-19f;
+    wd.w0 = in_w ? nxt : HW_OUT;
+    wd.u = in_w ? (float)(r >> 13) * 0x1p-19f : -1.0f;
 }
-// per window position l: nxt[l] in bits 0..5 and, in bit 6, "the proposal starting at l lies inside the window and
-// is certainly rejected" -- one v_readlane per hop yields both.  thr_tab[r]: lane i = rejection threshold of read 64 r + i.
-template <int NR>
-__device__ __forceinline__ uint32_t hop_words(const Window &wd, const float *thr_tab) {
-    float thr = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((wd.idx & 63u) << 2), __float_as_int(thr_tab[0])));
-    if (NR == 2) {
-        const float hi = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((wd.idx & 63u) << 2), __float_as_int(thr_tab[NR - 1])));
-        thr = wd.idx >= 64u ? hi : thr;
-    }
-    return (wd.nxt & 63u) | ((wd.nxt != 255u && wd.u > thr) ? 64u : 0u);
+// thr[i] (16 bytes): the two f32 thresholds of "flip read i" in the current state -- the draw is certainly above exp(diff)
+// beyond .x, certainly below it under .y -- and two ready-made pieces of the hop word: .z if it is above, .w in any case.
+__device__ __forceinline__ uint32_t hop_words(const Window &wd, uint32_t thr_lds) {
+    const u32x4_t tv = *(lds_cvu32x4 *)(uintptr_t)(thr_lds + (wd.idx << 4));
+    uint32_t w = wd.w0 | tv.w;
+    w |= wd.u > __uint_as_float(tv.x) ? tv.z : 0u;
+    w |= wd.u < __uint_as_float(tv.y) ? HW_ACC : 0u;
+    return w;
 }
-// Walks from window position p over certainly rejected proposals; returns the number of steps taken (<= limit).
-// Straight-line hops with forward exits: a taken branch costs a lone wave far more than the hop itself.
-__device__ __forceinline__ uint32_t walk_rejected(uint32_t hopw, uint32_t &p, uint32_t limit) {
+// Walks from window position p over certainly rejected proposals; returns the number of steps taken (<= limit) and the hop
+// word it stopped at.  Straight-line hops with forward exits: a taken branch costs a lone wave far more than the hop itself.
+__device__ __forceinline__ uint32_t walk_rejected(uint32_t hopw, uint32_t &p, uint32_t limit, uint32_t &hv_out) {
+    uint32_t hv = 0;
     if (limit >= 24) {  // a window holds at most 21 proposals: no need to watch the step budget
         uint32_t steps = 22;
 #pragma unroll
         for (uint32_t k = 0; k < 22; k++) {
-            const uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
-            if (!(hv & 64u)) {
+            hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
+            if (!(hv & HW_SKIP)) {
                 steps = k;
                 break;
             }
             p = hv & 63u;
         }
+        hv_out = hv;
         return steps;
     }
     uint32_t steps = 0;
     while (steps < limit) {
-        const uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
-        if (!(hv & 64u)) break;
+        hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
+        if (!(hv & HW_SKIP)) break;
         p = hv & 63u;
         steps++;
     }
+    hv_out = hv;
     return steps;
 }
 // One proposal taken with scalar draws (a start the producer could not parse): the read index and the stream
@@ -1800,32 +1816,59 @@ __device__ __forceinline__ void scalar_proposal(Rng &rng, uint32_t start, uint32
 
 #ifdef JTK_MCMC_STATS
 // counters live in scalar registers during the chain and are folded into LDS once per chain
-#define ST_T0() unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_t0 = __builtin_readcyclecounter()
-#define ST_ADD(k) st_acc[k] += __builtin_readcyclecounter() - st_t0; if (lane == 0) { for (int q_ = 0; q_ < 10; q_++) m.k2_stats[q_] += st_acc[q_]; }
+#define ST_T0() unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_mk = 0; (void)st_mk; const unsigned long long st_t0 = __builtin_readcyclecounter()
+#define ST_ADD(k) st_acc[k] += __builtin_readcyclecounter() - st_t0; if (lane == 0) { for (int q_ = 0; q_ < 16; q_++) m.k2_stats[q_] += st_acc[q_]; }
 #define ST_CNT(k, v) st_acc[k] += (v)
+// the pieces of an event: ST_MARK0 starts the stopwatch, ST_MARK(k) adds the time since the last mark to counter k
+#define ST_MARK0() st_mk = __builtin_readcyclecounter()
+#define ST_MARK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[k] += now_ - st_mk; st_mk = now_; }
 #else
 #define ST_T0()
 #define ST_ADD(k)
 #define ST_CNT(k, v)
+#define ST_MARK0()
+#define ST_MARK(k)
 #endif
 
-// REPL: the state is replicated in every lane (wave-uniform values in vector registers; neither the exact step nor
-// the table rebuild needs a cross-lane operation) -- used up to 4 columns.  Otherwise lane d holds column d and
-// the rebuild / the ordered sum fetch it with v_readlane (8 replicated columns do not fit the register budget).
+// The diploid chain (round 5).  Lane i holds read i (and read 64 + i when NR == 2): its row signed by the direction of its
+// flip, and -- rebuilt lane-parallel after every move of the state -- the EXACT likelihood of the state "read i flipped"
+// (get_lk's own left-to-right sum), whether flip + flip-back would leave a rounding residue, and two f32 thresholds for the
+// Bernoulli draw with guard bands.  The walk skips proposals that are certainly rejected and leave nothing behind; everything
+// else is an event, and an event is settled from the read's lane: its decision comes with the hop word (the exact exp only
+// inside the guard bands), its new likelihood and its row are three v_readlane away.  The state (LKCount[c][d] of the two
+// clusters, wave-uniform) is replicated in every lane, so neither the event nor the rebuild needs a cross-lane operation;
+// size-only moves (a read with an all-zero row) need no special case: the size terms are the start of every lane's sum.
 // Out of line on purpose: inlined into the kernel, the chain inherits the register pressure of everything that is
 // live around it and spills scalar registers inside its loop (each reload is a v_readlane on the critical path).
 struct K2Mem {
     const double *data;  // n x D likelihood gains
     const double *lfact;
     uint8_t *assign;
+    double *thr;         // 16 n bytes of threshold entries (the k-means scratch fbuf + cum: idle during a chain)
     unsigned long long *k2_stats;
 };
 // NR: registers per per-read / per-size table: 1 serves n <= 63, 2 serves n <= 127 (read or size 64 r + lane)
-template <int DMAX, bool REPL, int NR>
-__device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, uint32_t D, double cov, Rng *rng_io,
+template <typename T>
+__device__ __forceinline__ T *uni_ptr(T *p) { return reinterpret_cast<T *>((uintptr_t)uni64((uint64_t)(uintptr_t)p)); }
+template <int DMAX, int NR>
+__device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n_in, uint32_t D_in, double cov_in, Rng *rng_io,
                                                           uint32_t lane) {
+    // Arguments of an out-of-line function arrive in vector registers and the compiler then treats everything derived from
+    // them -- the step counter, the window position, every branch of the event -- as divergent (exec-mask regions instead
+    // of scalar branches): all of it is re-made wave-uniform here.
+    const uint32_t n = uni(n_in), D = uni(D_in);
+    const double cov = unif64(cov_in);
+    const K2Mem m = {uni_ptr(m_in.data), uni_ptr(m_in.lfact), uni_ptr(m_in.assign), uni_ptr(m_in.thr), uni_ptr(m_in.k2_stats)};
     Rng rng = *rng_io;
-    constexpr int NS = REPL ? DMAX : 1;  // state registers per lane
+    rng.pos = uni(rng.pos);
+    rng.wr_seen = uni(rng.wr_seen);
+    rng.wp_seen = uni(rng.wp_seen);
+    rng.pmode = uni(rng.pmode);
+    rng.win_base = uni(rng.win_base);
+    rng.ctl = uni_ptr(rng.ctl);
+    rng.ring = uni_ptr(rng.ring);
+    rng.rec = uni_ptr(rng.rec);
+    const uint32_t rec_lds = uni(lds_addr(rng.rec)), thr_lds = uni(lds_addr(m.thr));
     // pair table: lane c0 holds (0.0 + size_to_lk[c0]) + size_to_lk[n - c0]   (get_lk :788)
     double pair_v[NR];
     auto tab64 = [&](const double *tab, uint32_t i) -> double {  // entry i of a per-lane table of NR registers
@@ -1851,10 +1894,10 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
     }
     // ---- exact state LKCount[c][d]; columns >= D are all-zero, never used and add +0.0.  The two counters travel
     //      packed: pk = num_pos + 65536 * (3*num_pos - 7*num_neg), so pk > 0xffff <=> the second one is positive.
-    double tg0[NS], tg1[NS];
-    int pk0[NS], pk1[NS], tp2[NS];
+    double tg0[DMAX], tg1[DMAX];
+    int pk0[DMAX], pk1[DMAX], tp2[DMAX];
 #pragma unroll
-    for (int d = 0; d < NS; d++) {
+    for (int d = 0; d < DMAX; d++) {
         tg0[d] = tg1[d] = 0.0;
         pk0[d] = pk1[d] = tp2[d] = 0;
     }
@@ -1865,10 +1908,9 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t c = uni(m.assign[i]);
 #pragma unroll
-        for (int d = 0; d < NS; d++) {
-            const uint32_t col = REPL ? (uint32_t)d : lane;
+        for (int d = 0; d < DMAX; d++) {
             Elem el = {0.0, 0, 0};
-            if (col < D) el = elem_of(m.data[i * D + col]);
+            if ((uint32_t)d < D) el = elem_of(m.data[i * D + d]);
             tp2[d] += 2 * el.dp;  // 2 x reads with a positive value in this column: constant along the chain
             if (c == 0) {
                 tg0[d] += el.x;
@@ -1886,275 +1928,181 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
             lab[0] |= 1ull << (i & 63u);
     }
     // ---- the rows of reads lane, 64 + lane, signed by the direction of their flip: sx[r][d] is what cluster 0 would gain
-    uint32_t ri[NR];
     double sx[NR][DMAX];
     int spk[NR][DMAX];
-    unsigned long long nullm[NR];  // reads whose row is 0.0 in every column: flipping one moves nothing but the sizes
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-        ri[r] = lane + 64 * r < n ? lane + 64 * r : 0;
-        const bool a = bit128(lab, ri[r]);
-        bool nzr = false;
+        const uint32_t ri = lane + 64 * r < n ? lane + 64 * r : 0;
+        const bool a = bit128(lab, ri);
 #pragma unroll
         for (int d = 0; d < DMAX; d++) {
             Elem el = {0.0, 0, 0};
-            if ((uint32_t)d < D) el = elem_of(m.data[ri[r] * D + d]);
+            if ((uint32_t)d < D) el = elem_of(m.data[ri * D + d]);
             sx[r][d] = a ? el.x : -el.x;
             spk[r][d] = a ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
-            nzr = nzr || sx[r][d] != 0.0 || spk[r][d] != 0;
         }
-        const uint32_t live = n > 64u * r ? n - 64u * r : 0u;  // reads held by register r
-        nullm[r] = ~__ballot(nzr) & (live >= 64 ? ~0ull : ((1ull << live) - 1ull));
     }
     wsync();
     auto pair_at = [&](uint32_t c) -> double { return tab64(pair_v, c <= n ? c : n); };
-    // the per-column terms of get_lk (:785-795) for a (tentative) state
-    auto column_terms = [&](const double *T0, const double *T1, const int *K0, const int *K1, double *t0, double *t1) {
+    // get_lk (:785-795) of the start state: size terms, then clusters outer / columns inner, left to right
+    double lk;
+    {
+        double t0[DMAX], t1[DMAX];
 #pragma unroll
-        for (int d = 0; d < NS; d++) {
-            const bool pos0 = 0.0 < T0[d], pos1 = 0.0 < T1[d];
-            const int in_use = ((pos0 ? K0[d] : 0) + (pos1 ? K1[d] : 0)) & 0xffff;
-            const bool any = (pos0 && K0[d] > 0xffff) || (pos1 && K1[d] > 0xffff);
+        for (int d = 0; d < DMAX; d++) {
+            const bool pos0 = 0.0 < tg0[d], pos1 = 0.0 < tg1[d];
+            const int in_use = ((pos0 ? pk0[d] : 0) + (pos1 ? pk1[d] : 0)) & 0xffff;
+            const bool any = (pos0 && pk0[d] > 0xffff) || (pos1 && pk1[d] > 0xffff);
             const bool used = any && 3 * in_use > tp2[d];  // get_used_columns (:847-869)
-            t0[d] = (used && pos0) ? T0[d] : 0.0;
-            t1[d] = (used && pos1) ? T1[d] : 0.0;
+            t0[d] = (used && pos0) ? tg0[d] : 0.0;
+            t1[d] = (used && pos1) ? tg1[d] : 0.0;
         }
-    };
-    // get_lk of a tentative state, exactly: size terms, then clusters outer / columns inner, left to right
-    auto exact_eval = [&](const double *T0, const double *T1, const int *K0, const int *K1, double base) -> double {
-        double t0[NS], t1[NS];
-        column_terms(T0, T1, K0, K1, t0, t1);
-        double S = base;
-        if (REPL) {
+        double S = pair_at(c0);
 #pragma unroll
-            for (int d = 0; d < DMAX; d++) S += t0[d];
+        for (int d = 0; d < DMAX; d++) S += t0[d];
 #pragma unroll
-            for (int d = 0; d < DMAX; d++) S += t1[d];
-        } else {
-#pragma unroll
-            for (int q = 0; q < DMAX; q++) S += readlane_f64(t0[0], q);
-#pragma unroll
-            for (int q = 0; q < DMAX; q++) S += readlane_f64(t1[0], q);
-        }
-        return S;
-    };
-    double lk = exact_eval(tg0, tg1, pk0, pk1, pair_at(c0));
+        for (int d = 0; d < DMAX; d++) S += t1[d];
+        lk = unif64(S);
+    }
     double pair_up = pair_at(c0 + 1), pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
-    // ---- the table: for "flip read `lane`" in the current state, the order-free sum of its column terms and
-    //      whether flip + flip-back would leave a rounding residue; thresholds follow from those and the size terms
-    double sum_l[NR];
-    bool pert_l[NR];
-    auto rebuild_sums = [&]() {
+    // ---- per read, for the current state: prop_l = get_lk of the state with the read flipped (exactly: the same sum, the
+    //      same order), ndm = the step draws nothing, pertm = a rejected flip leaves a residue; thresholds to LDS
+    double prop_l[NR];
+    unsigned long long ndm[NR], pertm[NR];
+    auto evaluate = [&]() {
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            double sum = 0.0;
+            const bool a = __builtin_amdgcn_inverse_ballot_w64(lab[r]);  // the read sits in cluster 1: cluster 0 would grow
+            double t1[DMAX];
+            double S = a ? pair_up : pair_dn;
             bool pert = false;
 #pragma unroll
             for (int d = 0; d < DMAX; d++) {
-                const double s0 = REPL ? tg0[REPL ? d : 0] : readlane_f64(tg0[0], d);
-                const double s1 = REPL ? tg1[REPL ? d : 0] : readlane_f64(tg1[0], d);
-                const int k0 = REPL ? pk0[REPL ? d : 0] : __builtin_amdgcn_readlane(pk0[0], d);
-                const int k1 = REPL ? pk1[REPL ? d : 0] : __builtin_amdgcn_readlane(pk1[0], d);
-                const int tp = REPL ? tp2[REPL ? d : 0] : __builtin_amdgcn_readlane(tp2[0], d);
-                const double T0 = s0 + sx[r][d], T1 = s1 - sx[r][d];  // s - x == s + (-x) bit for bit
-                const int K0 = k0 + spk[r][d], K1 = k1 - spk[r][d];
+                const double x = sx[r][d];
+                const double T0 = tg0[d] + x, T1 = tg1[d] - x;  // s - x == s + (-x) bit for bit
+                const int K0 = pk0[d] + spk[r][d], K1 = pk1[d] - spk[r][d];
                 const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
-                const int in_use = ((pos0 ? K0 : 0) + (pos1 ? K1 : 0)) & 0xffff;
-                const bool any = (pos0 && K0 > 0xffff) || (pos1 && K1 > 0xffff);
-                const bool used = any && 3 * in_use > tp;
-                sum += ((used && pos0) ? T0 : 0.0) + ((used && pos1) ? T1 : 0.0);
-                pert = pert || (T0 - sx[r][d] != s0) || (T1 + sx[r][d] != s1);  // flip back (:746) would not restore the sum
+                const int m0 = pos0 ? K0 : 0, m1 = pos1 ? K1 : 0;
+                // get_used_columns (:847-869): some cluster is informative, and the positives sit where the gain is
+                const bool used = (m0 > m1 ? m0 : m1) > 0xffff && 3 * ((m0 + m1) & 0xffff) > tp2[d];
+                S += (used && pos0) ? T0 : 0.0;
+                t1[d] = (used && pos1) ? T1 : 0.0;
+                pert = pert || (T0 - x != tg0[d]) || (T1 + x != tg1[d]);  // flip back (:746) would not restore the sum
             }
-            sum_l[r] = sum;
-            pert_l[r] = pert;
+#pragma unroll
+            for (int d = 0; d < DMAX; d++) S += t1[d];
+            prop_l[r] = S;
+            const double diff = S - lk;
+            // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
+            // exactly when diff >= -2^-54
+            const bool nd = diff >= -0x1p-54;
+            ndm[r] = __ballot(nd);
+            pertm[r] = __ballot(pert);
+            // the 19 known bits u of the draw (true value in [u, u + 2^-19)) decide gen_bool unless exp(diff) is within
+            // the guard bands: exp in f32 is good to ~1e-5 relative
+            const float pe = __expf((float)diff);
+            const bool in_range = diff < -1e-3 && diff > -44.4;
+            float rej = in_range ? pe * 1.001f + 1.3e-6f : 3.0f;   // 3.0: cannot tell
+            rej = diff <= -44.4 ? -1.0f : rej;                     // exp(diff) * 2^64 < 1 => p_int == 0
+            const float acc = in_range ? pe * 0.999f - (3e-7f + 0x1p-19f) : -2.0f;
+            u32x4_t e;
+            e.x = __float_as_uint(rej);
+            e.y = __float_as_uint(acc);
+            e.z = pert ? HW_REJ : HW_REJ | HW_SKIP;
+            e.w = nd ? HW_NODRAW : 0u;
+            if (lane + 64 * r < n) *(lds_vu32x4 *)(uintptr_t)(thr_lds + ((lane + 64 * r) << 4)) = e;
         }
-    };
-    float thr_tab[NR];
-    auto thresholds = [&]() {
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const bool a = bit128(lab, ri[r]);
-            thr_tab[r] = reject_threshold(((a ? pair_up : pair_dn) + sum_l[r]) - lk, pert_l[r]);
-        }
-    };
-    // ---- size-only moves (a read with an all-zero row): with the column sums fixed, get_lk is a function of the
-    //      cluster-0 size alone.  Lane c holds G[c] = get_lk at size c (the same left-to-right sum), and for the
-    //      move to size c' the new likelihood is G[c'] exactly.  Built on demand, stale once a column sum moves.
-    double Gtab[NR];
-    bool gtab_ok = false;
-    auto build_gtab = [&]() {
-        double t0[NS], t1[NS];
-        column_terms(tg0, tg1, pk0, pk1, t0, t1);
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            double G = pair_v[r];
-            if (REPL) {
-#pragma unroll
-                for (int d = 0; d < DMAX; d++) G += t0[d];
-#pragma unroll
-                for (int d = 0; d < DMAX; d++) G += t1[d];
-            } else {
-#pragma unroll
-                for (int q = 0; q < DMAX; q++) G += readlane_f64(t0[0], q);
-#pragma unroll
-                for (int q = 0; q < DMAX; q++) G += readlane_f64(t1[0], q);
-            }
-            Gtab[r] = G;
-        }
-        gtab_ok = true;
     };
     double max = lk;
     unsigned long long argmax[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) argmax[r] = lab[r];
-    rebuild_sums();
-    thresholds();
+    evaluate();
     const uint32_t total = 2000u * n;
     uint32_t t = 0, p = 0;
     Window wd;
-    window_load(wd, rng, rng.pos, lane);
-    uint32_t hopw = hop_words<NR>(wd, thr_tab);
+    window_load(wd, rng, rec_lds, rng.pos, lane);
+    uint32_t hopw = hop_words(wd, thr_lds);
     ST_T0();
     while (t < total) {
-        t += walk_rejected(hopw, p, total - t);
+        uint32_t hv;
+        t += walk_rejected(hopw, p, total - t, hv);
         if (t >= total) break;
         // ---- p is a proposal that is not certainly rejected, or one this window cannot serve
+#ifdef JTK_MCMC_STATS
+        const unsigned long long g0c = __builtin_readcyclecounter();
+#endif
+        ST_MARK0();
         uint32_t e_idx, pos_v;  // the read it picks; stream position of the draw a Bernoulli test would compare
-        const uint32_t e_nxt = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.nxt, (int)p));
         bool reload = false;
-        if (e_nxt != 255u) {
+        if (!(hv & HW_OUT)) {
             e_idx = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.idx, (int)p));
-            pos_v = wd.base + e_nxt - 1;
+            pos_v = wd.base + (hv & 63u) - 1;
         } else if (p != 0) {  // move the window there
-            window_load(wd, rng, wd.base + p, lane);
+            window_load(wd, rng, rec_lds, wd.base + p, lane);
             p = 0;
-            hopw = hop_words<NR>(wd, thr_tab);
+            hopw = hop_words(wd, thr_lds);
             ST_CNT(6, 1);
             continue;
         } else {  // not even at the window start: the producer could not parse this one
             scalar_proposal(rng, wd.base, n, e_idx, pos_v);
             reload = true;
+            hv = 0;
         }
         const bool old = bit128(lab, e_idx);
-        auto flip_label = [&]() {
-            if (NR == 2 && e_idx >= 64)
-                lab[NR - 1] ^= 1ull << (e_idx & 63u);
-            else
-                lab[0] ^= 1ull << (e_idx & 63u);
-        };
-        auto new_max = [&](double v) {
-            max = v;
+        if (reload) hv = bit128(ndm, e_idx) ? HW_NODRAW : 0u;
+        const uint32_t no_draw = (hv / HW_NODRAW) & 1u;
+        // the read's lane: the likelihood of the flipped state and its signed row
+        double proposed, x0[DMAX];
+        int k0[DMAX];
+        if (NR == 2 && e_idx >= 64) {
+            proposed = readlane_f64(prop_l[NR - 1], e_idx & 63u);
 #pragma unroll
-            for (int r = 0; r < NR; r++) argmax[r] = lab[r];
-        };
-        if (bit128(nullm, e_idx)) {
-            // ---- a size-only move: the decision and the new likelihood come from the size tables
-#ifdef JTK_MCMC_STATS
-            const unsigned long long n0c = __builtin_readcyclecounter();
-#endif
-            if (!gtab_ok) build_gtab();
-            // proposed - lk with the lk the chain carries (flip-back residues move the sums, not lk: :746), so this
-            // is NOT a difference of two table entries
-            const double diff = tab64(Gtab, old ? c0 + 1 : c0 - 1) - lk;
-            const bool nd = ubool(diff >= -0x1p-54);  // gen_bool(1.0) draws nothing
-            bool acc = true;
-            if (!nd) {
-                // u: the Bernoulli draw / 2^64 truncated to 19 bits (true value < u + 2^-19); pe within ~1e-5 relative
-                const float pe = __expf((float)diff);
-                const float u = reload ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd.u), (int)p));
-                const bool in_range = u >= 0.0f && diff < -1e-3 && diff > -44.4;
-                if (ubool(diff <= -44.4 || (in_range && u > pe * 1.001f + 1.3e-6f))) {
-                    acc = false;
-                } else if (!ubool(in_range && u + 0x1p-19f < pe * 0.999f - 3e-7f)) {
-                    rng_wait(rng, pos_v + 1);
-                    acc = ubool(bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff));  // (an out-of-line call returns in a vector register)
-                }
+            for (int d = 0; d < DMAX; d++) {
+                x0[d] = readlane_f64(sx[NR - 1][d], e_idx & 63u);
+                k0[d] = __builtin_amdgcn_readlane(spk[NR - 1][d], (int)(e_idx & 63u));
             }
-            if (acc) {
-                c0 = old ? c0 + 1 : c0 - 1;
-                flip_label();
-                lk = tab64(Gtab, c0);
-                pair_up = pair_at(c0 + 1);
-                pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
-                if (ubool(max < lk)) new_max(lk);
-                thresholds();
-            }
-            t++;
-            const uint32_t pos_next = nd ? pos_v : pos_v + 1;
-            ST_CNT(7, 1);
-            ST_CNT(8, acc ? 1 : 0);
-            ST_CNT(2, 1);
-            if (reload || pos_next - wd.base >= 64) {
-                window_load(wd, rng, pos_next, lane);
-                p = 0;
-                hopw = hop_words<NR>(wd, thr_tab);
-                ST_CNT(6, 1);
-            } else {
-                p = pos_next - wd.base;
-                if (acc) hopw = hop_words<NR>(wd, thr_tab);
-            }
-#ifdef JTK_MCMC_STATS
-            ST_CNT(3, __builtin_readcyclecounter() - n0c);
-#endif
-            continue;
-        }
-        // ---- the event: one exact step
-#ifdef JTK_MCMC_STATS
-        const unsigned long long g0c = __builtin_readcyclecounter();
-#endif
-        double x0[NS], T0[NS], T1[NS];  // x0: what cluster 0 gains
-        int K0[NS], K1[NS];
+        } else {
+            proposed = readlane_f64(prop_l[0], e_idx & 63u);
 #pragma unroll
-        for (int d = 0; d < NS; d++) {
-            int k0;
-            if (REPL && DMAX <= 2 && NR == 1) {  // the read's own lane has its signed row in registers
-                x0[d] = readlane_f64(sx[0][d], e_idx);
-                k0 = __builtin_amdgcn_readlane(spk[0][d], (int)e_idx);
-            } else {
-                const uint32_t col = REPL ? (uint32_t)d : lane;
-                Elem el = {0.0, 0, 0};
-                if (col < D) el = elem_of(m.data[e_idx * D + col]);
-                x0[d] = old ? el.x : -el.x;
-                k0 = old ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
+            for (int d = 0; d < DMAX; d++) {
+                x0[d] = readlane_f64(sx[0][d], e_idx & 63u);
+                k0[d] = __builtin_amdgcn_readlane(spk[0][d], (int)(e_idx & 63u));
             }
-            T0[d] = tg0[d] + x0[d];
-            T1[d] = tg1[d] - x0[d];
-            K0[d] = pk0[d] + k0;
-            K1[d] = pk1[d] - k0;
         }
-        const double proposed = exact_eval(T0, T1, K0, K1, old ? pair_up : pair_dn);
-        const double diff = proposed - lk;
-        // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
-        // exactly when diff >= -2^-54
-        const bool no_draw = ubool(diff >= -0x1p-54);
+        ST_MARK(10);
         bool accept = true;
-        if (!no_draw) {
-            // the 20 known bits of the draw decide gen_bool unless it is within the guard bands of exp(diff)
-            const float u = reload ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wd.u), (int)p));
-            const float pe = __expf((float)diff);
-            const bool in_range = u >= 0.0f && diff < -1e-3 && diff > -44.4;
-            if (ubool(diff <= -44.4 || (in_range && u > pe * 1.001f + 1.3e-6f))) {
-                accept = false;
-            } else if (!ubool(in_range && u + 0x1p-19f < pe * 0.999f - 3e-7f)) {
+        if (!(hv & (HW_NODRAW | HW_ACC))) {
+            accept = false;
+            if (!(hv & HW_REJ)) {  // inside the guard bands (or a start without a record): the exact test
                 rng_wait(rng, pos_v + 1);
-                accept = ubool(bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff));
+                accept = ubool(bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), proposed - lk));  // (an out-of-line call returns in a vector register)
+                ST_CNT(15, 1);
             }
         }
-        int changed = 2;  // 0: nothing moved, 2: sums moved
+        ST_MARK(11);
+        bool changed = true;
         if (accept) {
 #pragma unroll
-            for (int d = 0; d < NS; d++) {
-                tg0[d] = T0[d];
-                tg1[d] = T1[d];
-                pk0[d] = K0[d];
-                pk1[d] = K1[d];
+            for (int d = 0; d < DMAX; d++) {
+                tg0[d] = tg0[d] + x0[d];
+                tg1[d] = tg1[d] - x0[d];
+                pk0[d] += k0[d];
+                pk1[d] -= k0[d];
             }
             c0 = old ? c0 + 1 : c0 - 1;
             pair_up = pair_at(c0 + 1);
             pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
-            flip_label();
+            if (NR == 2 && e_idx >= 64)
+                lab[NR - 1] ^= 1ull << (e_idx & 63u);
+            else
+                lab[0] ^= 1ull << (e_idx & 63u);
             lk = proposed;
-            if (ubool(max < lk)) new_max(proposed);
+            if (ubool(max < lk)) {
+                max = proposed;
+#pragma unroll
+                for (int r = 0; r < NR; r++) argmax[r] = lab[r];
+            }
 #pragma unroll
             for (int r = 0; r < NR; r++)
                 if (lane + 64 * r == e_idx) {  // the read now flips the other way
@@ -2164,36 +2112,34 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m, uint32_t n, u
                         spk[r][d] = -spk[r][d];
                     }
                 }
-        } else {
-            bool ch = false;
+        } else if (bit128(pertm, e_idx)) {
+            // flip back (:746) keeps the rounding residue: the sums move although nothing was accepted
 #pragma unroll
-            for (int d = 0; d < NS; d++) {
-                const double b0 = T0[d] - x0[d], b1 = T1[d] + x0[d];  // flip back (:746), keeping the rounding residue
-                ch = ch || b0 != tg0[d] || b1 != tg1[d];
-                tg0[d] = b0;
-                tg1[d] = b1;
+            for (int d = 0; d < DMAX; d++) {
+                tg0[d] = (tg0[d] + x0[d]) - x0[d];
+                tg1[d] = (tg1[d] - x0[d]) + x0[d];
             }
-            changed = ubool(ch) ? 2 : 0;
+        } else {
+            changed = false;
         }
         t++;
-        const uint32_t pos_next = no_draw ? pos_v : pos_v + 1;
+        const uint32_t pos_next = pos_v + 1 - no_draw;
         ST_CNT(7, 1);
         ST_CNT(8, accept ? 1 : 0);
-        ST_CNT(9, changed == 2 ? 1 : 0);
-        if (changed) {
-            gtab_ok = false;
-            rebuild_sums();
-            thresholds();
-        }
+        ST_CNT(9, changed ? 1 : 0);
+        ST_MARK(12);
+        if (changed) evaluate();
+        ST_MARK(13);
         if (reload || pos_next - wd.base >= 64) {
-            window_load(wd, rng, pos_next, lane);
+            window_load(wd, rng, rec_lds, pos_next, lane);
             p = 0;
-            hopw = hop_words<NR>(wd, thr_tab);
+            hopw = hop_words(wd, thr_lds);
             ST_CNT(6, 1);
         } else {
             p = pos_next - wd.base;
-            if (changed) hopw = hop_words<NR>(wd, thr_tab);
+            if (changed) hopw = hop_words(wd, thr_lds);
         }
+        ST_MARK(14);
 #ifdef JTK_MCMC_STATS
         ST_CNT(4, __builtin_readcyclecounter() - g0c);
 #endif
@@ -2261,29 +2207,31 @@ template <int K, bool LIGHT, bool HUGE>
 __device__ __forceinline__ double mcmc_chain_dispatch(const Lds &m, uint32_t n, uint32_t D, double cov, Rng &rng, uint32_t lane) {
     if (HUGE) return mcmc_chain<K, false>(m, n, D, cov, rng, lane);  // the work area is in global memory (mcmc_kernel_huge)
     if (LIGHT) {
-        // the light kernel (mcmc_kernel_light) holds only the two chain variants that fit 168 registers; chain_split_kernel
+        // the light kernel (mcmc_kernel_light) holds only the chain variants that fit 168 registers; chain_split_kernel
         // sends it nothing else.  NaN = the chunk fails, loudly, should that ever not hold.
         if (!(K == 2 && n <= JTK_LIGHT_MAX_READS && D >= 1 && D <= JTK_LIGHT_MAX_DIM)) return __builtin_nan("");
         rng_set_parse_mode(rng, PM_K2, lane);
-        const K2Mem km = {m.data, m.lfact, m.assign, m.k2_stats};
+        const K2Mem km = {m.data, m.lfact, m.assign, m.fbuf, m.k2_stats};
         if (n <= 63) {
-            if (D == 1) return mcmc_chain_k2<1, true, 1>(km, n, D, cov, &rng, lane);
-            return mcmc_chain_k2<2, true, 1>(km, n, D, cov, &rng, lane);
+            if (D == 1) return mcmc_chain_k2<1, 1>(km, n, D, cov, &rng, lane);
+            return mcmc_chain_k2<2, 1>(km, n, D, cov, &rng, lane);
         }
-        if (D == 1) return mcmc_chain_k2<1, true, 2>(km, n, D, cov, &rng, lane);  // 64 .. 127 reads: two table registers
-        return mcmc_chain_k2<2, true, 2>(km, n, D, cov, &rng, lane);
+        if (D == 1) return mcmc_chain_k2<1, 2>(km, n, D, cov, &rng, lane);  // 64 .. 127 reads: two table registers
+        return mcmc_chain_k2<2, 2>(km, n, D, cov, &rng, lane);
     }
     if (K == 2 && n <= 127 && D >= 1 && D <= 8) {
         rng_set_parse_mode(rng, PM_K2, lane);
-        const K2Mem km = {m.data, m.lfact, m.assign, m.k2_stats};
+        const K2Mem km = {m.data, m.lfact, m.assign, m.fbuf, m.k2_stats};
         if (n <= 63) {
-            if (D == 1) return mcmc_chain_k2<1, true, 1>(km, n, D, cov, &rng, lane);
-            if (D == 2) return mcmc_chain_k2<2, true, 1>(km, n, D, cov, &rng, lane);
-            if (D <= 4) return mcmc_chain_k2<4, true, 1>(km, n, D, cov, &rng, lane);
-            return mcmc_chain_k2<8, false, 1>(km, n, D, cov, &rng, lane);
+            if (D == 1) return mcmc_chain_k2<1, 1>(km, n, D, cov, &rng, lane);
+            if (D == 2) return mcmc_chain_k2<2, 1>(km, n, D, cov, &rng, lane);
+            if (D == 3) return mcmc_chain_k2<3, 1>(km, n, D, cov, &rng, lane);
+            if (D == 4) return mcmc_chain_k2<4, 1>(km, n, D, cov, &rng, lane);
+            return mcmc_chain_k2<8, 1>(km, n, D, cov, &rng, lane);
         }
-        if (D <= 4) return mcmc_chain_k2<4, true, 2>(km, n, D, cov, &rng, lane);
-        return mcmc_chain_k2<8, false, 2>(km, n, D, cov, &rng, lane);
+        if (D <= 2) return mcmc_chain_k2<2, 2>(km, n, D, cov, &rng, lane);
+        if (D <= 4) return mcmc_chain_k2<4, 2>(km, n, D, cov, &rng, lane);
+        return mcmc_chain_k2<8, 2>(km, n, D, cov, &rng, lane);
     }
     rng_set_parse_mode(rng, (uint32_t)K, lane);
     return mcmc_chain_tab<K>(m.shape, n, D, cov, &rng, lane);
@@ -2620,9 +2568,10 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     if (lane == 0)
         printf("K2WAIT chunk %u waits %u\n", ci, rng.waits);
     if (lane == 0)
-        printf("K2STAT chunk %u n %u D %u cyc %llu walk %llu win %llu event %llu rebuild %llu steps %llu windows %llu events %llu accepts %llu changed %llu\n",
+        printf("K2STAT chunk %u n %u D %u cyc %llu walk %llu win %llu event %llu rebuild %llu steps %llu windows %llu events %llu accepts %llu changed %llu head %llu bern %llu book %llu tables %llu hops %llu exact %llu\n",
                ci, n, D, m.k2_stats[0], m.k2_stats[1], m.k2_stats[2], m.k2_stats[3], m.k2_stats[4], m.k2_stats[5],
-               m.k2_stats[6], m.k2_stats[7], m.k2_stats[8], m.k2_stats[9]);
+               m.k2_stats[6], m.k2_stats[7], m.k2_stats[8], m.k2_stats[9], m.k2_stats[10], m.k2_stats[11], m.k2_stats[12],
+               m.k2_stats[13], m.k2_stats[14], m.k2_stats[15]);
 #endif
     if (failed) {
         if (lane == 0) st->status = JTK_ERR_CHUNK_FAILED;

@@ -1,10 +1,10 @@
 /* correction.c -- CPU ORACLE (test infrastructure).  Restatement of the first consumer of the stage's posteriors,
  * `AlignmentCorrection::correct_clustering_selected` (haplotyper/src/phmm_likelihood_correction.rs:32-97) with everything
- * it calls in that file: estimate_copy_number_of_cluster :129-182, correct_chunk :185-220, adj_rand_on_biased :222-243,
- * to_context :246-264, clustering :266-337, filter_similarity :339-356, select_nth :358-363, append_posterior_probability
- * :365-376, normalize_columns :378-391, get_graph_laplacian :395-412, get_eigenvalues :415-473, alignment :475-490,
- * align_swg :493-542, sim :545-561, logit_from_lnp :564-577, supress_threshold :100-105, get_protected_clusterings
- * :108-127; misc.rs adjusted_rand_index :22-46, LogSumExp :94-140, kmeans :231-341; definitions Node::is_biased :703-709.
+ * it calls in that file: estimate_copy_number_of_cluster :131-181, correct_chunk :184-218, adj_rand_on_biased :220-240,
+ * to_context :243-261, clustering :263-328, filter_similarity :330-347, select_nth :349-354, append_posterior_probability
+ * :356-367, normalize_columns :369-381, get_graph_laplacian :385-402, get_eigenvalues :405-464, alignment :466-479,
+ * align_swg :482-531, sim :534-550, logit_from_lnp :553-566, supress_threshold :100-105, get_protected_clusterings
+ * :108-129; misc.rs adjusted_rand_index :22-46, LogSumExp :94-140, kmeans :231-341; definitions Node::is_biased :703-709.
  * Followed line by line (iterator order, stable sorts, `max_by` = last maximum, `min_by` = first minimum).
  * Three things are NOT in the reference tree and are stood in for (parity with them is unpinned):
  *   nalgebra `symmetric_eigen` (:419)         -> include/jtk_eigen.h (cyclic Jacobi; eigenvectors up to sign)
@@ -42,7 +42,7 @@ typedef struct view { /* the dataset as the functions below see it */
 
 static int g_panic; /* thread-unsafe on purpose: the oracle runs this path single-threaded */
 
-/* logit_from_lnp :564-577 */
+/* logit_from_lnp :553-566 */
 static double logit_from_lnp(double lnp) {
     if (!(lnp <= 0.0)) g_panic = 1;
     const double LOWER_CUT = -80.0, UPPER_CUT = 80.0, UPPER_THR = -1.8e-35;
@@ -51,7 +51,7 @@ static double logit_from_lnp(double lnp) {
     return lnp - jtk_log(1.0 + (-jtk_exp(lnp)));
 }
 
-/* sim :545-561 (LogSumExp: misc.rs:94-140) */
+/* sim :534-550 (LogSumExp: misc.rs:94-140) */
 static double sim(const double *xs, size_t nx, const double *ys, size_t ny, const double *cps, size_t nc) {
     if (nx != nc || nx != ny) {
         g_panic = 1;
@@ -80,7 +80,7 @@ static double sim(const double *xs, size_t nx, const double *ys, size_t ny, cons
 
 static double max3(double a, double b, double c) { return jtk_fmax(jtk_fmax(a, b), c); }
 
-/* align_swg :493-542 */
+/* align_swg :482-531 */
 static double align_swg(const arm_ent_t *arm1, size_t len1, const arm_ent_t *arm2, size_t len2, const view_t *v) {
     const double GAP_OPEN = -0.5, GAP_EXTEND = -100.0, MISM = -100.0;
     const double lower = (double)(len1 + len2 + 2) * MISM;
@@ -130,7 +130,7 @@ static double align_swg(const arm_ent_t *arm1, size_t len1, const arm_ent_t *arm
     return best;
 }
 
-/* alignment :475-490 */
+/* alignment :466-479 */
 static double alignment(const context_t *c1, const context_t *c2, const view_t *v) {
     if (c1->center->chunk != c2->center->chunk) g_panic = 1;
     const double up_aln = align_swg(c1->up, c1->n_up, c2->up, c2->n_up, v);
@@ -142,7 +142,7 @@ static double alignment(const context_t *c1, const context_t *c2, const view_t *
     return 1.0 / (1.0 + jtk_exp(-likelihood_ratio));
 }
 
-/* the full similarity matrix of one chunk (:275-289): also exported, so that the device kernel can be compared on it */
+/* the full similarity matrix of one chunk (:272-285): also exported, so that the device kernel can be compared on it */
 static void similarity_matrix(const context_t *ctx, size_t n, const view_t *v, double *sims) {
     for (size_t i = 0; i < n; i++)
         for (size_t j = 0; j < n; j++) sims[i * n + j] = i == j ? 0.0 : alignment(&ctx[i], &ctx[j], v);
@@ -153,7 +153,7 @@ static int cmp_f64(const void *a, const void *b) {
     return x < y ? -1 : (x > y ? 1 : 0);
 }
 
-/* filter_similarity :339-356, select_nth :358-363 */
+/* filter_similarity :330-347, select_nth :349-354 */
 static void filter_similarity(double *sims, size_t n, size_t len) {
     const double SMALL = 0.0000000000000001, MIN_REQ = 0.51;
     uint8_t *keep = (uint8_t *)calloc(n * n, 1);
@@ -229,11 +229,11 @@ typedef struct member { /* one (idx, read) of correct_chunk's `reads` */
     uint64_t cluster;
 } member_t;
 
-/* clustering :266-337 on the members of one chunk (already sorted); asn_out[n]; returns cluster_num */
+/* clustering :263-328 on the members of one chunk (already sorted); asn_out[n]; returns cluster_num */
 static size_t clustering(const member_t *mem, size_t n, size_t k, const jtk_cc_chunk_t *chunk, const view_t *v, size_t *asn_out,
                          double *sims_out) {
     context_t *ctx = (context_t *)calloc(n ? n : 1, sizeof(context_t));
-    for (size_t m = 0; m < n; m++) { /* to_context :246-264 */
+    for (size_t m = 0; m < n; m++) { /* to_context :243-261 */
         const size_t r = mem[m].read, idx = mem[m].idx;
         const jtk_cc_node_t *rn = v->nodes + v->node_off[r];
         const size_t len = (size_t)(v->node_off[r + 1] - v->node_off[r]);
@@ -268,7 +268,7 @@ static size_t clustering(const member_t *mem, size_t n, size_t k, const jtk_cc_c
         filter_similarity(sims, n, cov_per_copy);
     }
     if (!g_panic) {
-        /* get_graph_laplacian :395-412 */
+        /* get_graph_laplacian :385-402 */
         double *rowsum = (double *)malloc(n * sizeof(double)), *sq_inv = (double *)malloc(n * sizeof(double));
         double *lap = (double *)malloc(n * n * sizeof(double)), *vec = (double *)malloc(n * n * sizeof(double));
         for (size_t i = 0; i < n; i++) {
@@ -279,7 +279,7 @@ static size_t clustering(const member_t *mem, size_t n, size_t k, const jtk_cc_c
         }
         for (size_t i = 0; i < n; i++)
             for (size_t j = 0; j < n; j++) lap[i * n + j] = j == i ? 1.0 : -sims[i * n + j] * sq_inv[i] * sq_inv[j];
-        /* get_eigenvalues :415-473 */
+        /* get_eigenvalues :405-464 */
         if (n == 0) g_panic = 1;
         jtk_symmetric_eigen(lap, n, vec);
         eig_pair_t *ep = (eig_pair_t *)malloc((n ? n : 1) * sizeof(eig_pair_t));
@@ -306,7 +306,7 @@ static size_t clustering(const member_t *mem, size_t n, size_t k, const jtk_cc_c
             for (size_t i = 0; i < n; i++) {
                 const double d = __builtin_sqrt(1.0 / rowsum[i]);
                 for (size_t j = 0; j < pick_k; j++) feat[i * dim + j] = vec[i * n + ep[j].col] * d;
-                /* append_posterior_probability :365-376 */
+                /* append_posterior_probability :356-367 */
                 const jtk_cc_node_t *nd = ctx[i].center;
                 if (nd->post_len != pl) {
                     g_panic = 1; /* rows of different length: normalize_columns indexes out of bounds or kmeans asserts */
@@ -318,7 +318,7 @@ static size_t clustering(const member_t *mem, size_t n, size_t k, const jtk_cc_c
                 for (size_t c = 0; c < pl; c++) feat[i * dim + pick_k + c] = jtk_exp(ctx[i].center_post[c] - total);
             }
             if (!g_panic) {
-                /* normalize_columns :378-391 */
+                /* normalize_columns :369-381 */
                 for (size_t c = 0; c < dim; c++) {
                     double s = 0.0;
                     for (size_t i = 0; i < n; i++) s += feat[i * dim + c] * feat[i * dim + c];
@@ -326,12 +326,12 @@ static size_t clustering(const member_t *mem, size_t n, size_t k, const jtk_cc_c
                     for (size_t i = 0; i < n; i++) feat[i * dim + c] /= s;
                 }
                 jo_rng_t rng;
-                jo_rng128pp_seed_from_u64(&rng, chunk->id * (uint64_t)k); /* :295-296 */
+                jo_rng128pp_seed_from_u64(&rng, chunk->id * (uint64_t)k); /* :299-301 */
                 cluster_num = k < pick_k ? k : pick_k;
                 size_t *cur = (size_t *)malloc(n * sizeof(size_t));
                 double best = 0.0;
                 int have = 0;
-                for (int it = 0; it < 20; it++) { /* :298-302: min_by keeps the first minimum */
+                for (int it = 0; it < 20; it++) { /* :303-307: min_by keeps the first minimum */
                     double dist = 0.0;
                     if (jo_kmeans(feat, n, dim, cluster_num, &rng, &dist, cur) != 0) {
                         g_panic = 1;
@@ -385,7 +385,7 @@ int jo_correct_clustering(size_t n_reads, const uint64_t *read_id, const uint64_
     v.post = posteriors;
     for (size_t c = 0; c < n_chunks; c++)
         if (chunks[c].id > v.max_id) v.max_id = chunks[c].id;
-    /* ---- estimate_copy_number_of_cluster :129-182 */
+    /* ---- estimate_copy_number_of_cluster :131-181 */
     size_t *cps = (size_t *)calloc(v.max_id + 1, sizeof(size_t)), *cls = (size_t *)calloc(v.max_id + 1, sizeof(size_t));
     v.copy_numbers = (double **)calloc(v.max_id + 1, sizeof(double *));
     v.cn_len = (size_t *)calloc(v.max_id + 1, sizeof(size_t));
@@ -435,7 +435,7 @@ int jo_correct_clustering(size_t n_reads, const uint64_t *read_id, const uint64_
         memcpy(obs, est, kk * sizeof(double));
         free(est);
     }
-    /* ---- correct_chunk :185-220 for every selected chunk with more than one cluster, in selected_chunks order */
+    /* ---- correct_chunk :184-218 for every selected chunk with more than one cluster, in selected_chunks order */
     typedef struct result {
         member_t *mem;
         size_t *asn;
@@ -472,7 +472,7 @@ int jo_correct_clustering(size_t n_reads, const uint64_t *read_id, const uint64_
         size_t *asn = (size_t *)calloc(n ? n : 1, sizeof(size_t));
         const size_t k = clustering(mem, n, chunks[c].cluster_num, &chunks[c], &v, asn, n_res == 0 ? sims_first : NULL);
         double ari = 0.0;
-        if (!g_panic) { /* adj_rand_on_biased :222-243 */
+        if (!g_panic) { /* adj_rand_on_biased :220-240 */
             size_t *prev = (size_t *)malloc((n ? n : 1) * sizeof(size_t)), *pb = (size_t *)malloc((n ? n : 1) * sizeof(size_t)),
                    *ab = (size_t *)malloc((n ? n : 1) * sizeof(size_t));
             size_t nb = 0;
@@ -502,7 +502,7 @@ int jo_correct_clustering(size_t n_reads, const uint64_t *read_id, const uint64_
         n_res++;
     }
     if (!g_panic) {
-        /* get_protected_clusterings :108-127 */
+        /* get_protected_clusterings :108-129 */
         uint8_t *prot = (uint8_t *)calloc(n_chunks, 1);
         for (size_t c = 0; c < n_chunks; c++) {
             size_t cov = 0;

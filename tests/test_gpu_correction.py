@@ -19,7 +19,7 @@ def both(prob, selection=None, cov=20.0, min_gain=1e9, want_sims=0):
                                                         sel, cov, min_gain, want_sims)
     gch = prob["chunks"].copy()
     L = ffi.lib()
-    L.jtk_internal_cc_keep_sims(1 if want_sims else 0)
+    L.jtk_lc_debug_cc_keep_sims(1 if want_sims else 0)
     try:
         gcl, gtouched = api.correct_clustering(prob["read_id"], prob["node_off"], prob["nodes"], prob["posteriors"], gch, sel, cov,
                                                min_gain)
@@ -29,10 +29,10 @@ def both(prob, selection=None, cov=20.0, min_gain=1e9, want_sims=0):
     gsims = None
     if want_sims and grc == 0:
         gsims = np.zeros((want_sims, want_sims))
-        L.jtk_internal_cc_first_sims.restype = C.c_size_t
-        L.jtk_internal_cc_first_sims.argtypes = [C.POINTER(C.c_double), C.c_size_t]
-        assert L.jtk_internal_cc_first_sims(ffi.f64p(gsims), gsims.size) == gsims.size
-    L.jtk_internal_cc_keep_sims(0)
+        L.jtk_lc_debug_cc_first_sims.restype = C.c_size_t
+        L.jtk_lc_debug_cc_first_sims.argtypes = [C.POINTER(C.c_double), C.c_size_t]
+        assert L.jtk_lc_debug_cc_first_sims(ffi.f64p(gsims), gsims.size) == gsims.size
+    L.jtk_lc_debug_cc_keep_sims(0)
     return (orc, ocl, otouched, och, osims), (grc, gcl, gtouched, gch, gsims)
 
 
@@ -70,7 +70,7 @@ def test_correction_protected_and_selected():
 
 
 def test_correction_copy_number_three():
-    """three clusters on a copy-number-3 chunk chain: the copy-number estimate (:129-182) feeds sim() on the device"""
+    """three clusters on a copy-number-3 chunk chain: the copy-number estimate (:131-181) feeds sim() on the device"""
     prob = correction_problem(31, n_chunks=5, n_reads=90)
     rng = np.random.default_rng(31)
     # rewrite every node as a 3-cluster posterior

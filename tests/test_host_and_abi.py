@@ -32,6 +32,17 @@ def test_library_exports_every_declared_symbol(jtk_lib):
     assert jtk_lib.jtk_lc_strerror(-5).decode().startswith("alignment ops")
 
 
+def test_library_exports_nothing_but_the_declared_entry_points():
+    """the library is built with -fvisibility=hidden: what `nm -D` lists as defined are the entry points of include/jtk_lc.h and
+    the diagnostic ones of include/jtk_lc_debug.h -- no helper of the implementation (a Rust binary links these by name)"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", ffi.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    names = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-2] in "TDBRW"}
+    debug = set(re.findall(r"\b(jtk_lc_debug_[a-z_0-9]+)\s*\(", re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "jtk_lc_debug.h")).read(), flags=re.S)))
+    assert debug, "jtk_lc_debug.h declares the diagnostic entry points"
+    assert names == set(ffi.EXPORTED_SYMBOLS) | debug, sorted(names ^ (set(ffi.EXPORTED_SYMBOLS) | debug))
+
+
 def test_struct_layouts_match_between_bindings():
     assert C.sizeof(ffi.Params) == C.sizeof(O.Params) == 2 * 45 * 8 + 8 + 3 * 8 * 16 + 16
     assert ffi.CHUNK_DT.itemsize == 40 and ffi.RESULT_DT.itemsize == 24 and ffi.FEATURE_CHUNK_DT.itemsize == 56

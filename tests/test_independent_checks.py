@@ -78,7 +78,7 @@ def jo_eigen(a):
 
 
 def test_jacobi_eigen_matches_numpy_eigh(oracle):
-    """include/jtk_eigen.h stands in for nalgebra's symmetric_eigen (phmm_likelihood_correction.rs:419): eigenvalues and the
+    """include/jtk_eigen.h stands in for nalgebra's symmetric_eigen (phmm_likelihood_correction.rs:418): eigenvalues and the
     spanned subspaces must be those of LAPACK (eigenvectors themselves are defined up to sign / rotation in a degenerate
     eigenspace, so the comparison is of projectors onto the clusters of close eigenvalues)"""
     rng = np.random.default_rng(7)
