@@ -160,6 +160,8 @@ def stage_e2e(params0, batch, cfg, device, record_path=None):
                                        mean_polish_rounds=float(out["result"]["polish_rounds"].mean()),
                                        mean_n_variants=float(out["result"]["n_variants"].mean()),
                                        mean_cluster_num=float(out["result"]["cluster_num"].mean()))
+    raw = dict(label=out["label"].copy(), log_post=out["log_post"].copy(), score=out["result"]["score"].copy(),
+               cluster_num=out["result"]["cluster_num"].copy())   # as the device returned them: what the oracle is compared with
     t3 = time.perf_counter()
     for c in range(batch.n_chunks):
         rr = batch.chunk_reads(c)
@@ -182,7 +184,36 @@ def stage_e2e(params0, batch, cfg, device, record_path=None):
             fh.write("\n".join(rows) + "\n")
     ph["record_rows"] = rows[:3]
     ph["record_file"] = record_path
-    return ph, out
+    return ph, out, p, raw
+
+
+# chunks of the cfg-3 data set whose chains the refitted model makes eventful (profiles/r05_chain_pieces_before.txt: 10^5 .. 10^6
+# accepted moves each): the refit-model parity sample of bench.py and tests/golden/cfg3_refit_32.npz name them explicitly
+REFIT_EVENTFUL = (196, 206, 269, 332, 367, 464, 478, 498)
+
+
+def refit_parity(p_refit, batch, raw, n_plain=56):
+    """The stage as JTK enters it (refitted model + calibrated gains), checked: the oracle on the SAME parameters for a bounded
+    sample -- the first `n_plain` chunks plus the eventful ones -- against what the device returned for them (labels, posterior
+    bits, scores, cluster counts)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as O
+    import helpers
+    ids = sorted(set(range(min(n_plain, batch.n_chunks))) | {c for c in REFIT_EVENTFUL if c < batch.n_chunks})
+    sub = batch.subset(ids)
+    n_aff, quota = usable_cpus()
+    t0 = time.perf_counter()
+    ora = O.cluster_chunks(helpers.oracle_params(p_refit), sub, skip_polish=False,
+                           n_threads=n_aff if quota is None else max(1, min(n_aff, int(quota + 0.5))))
+    rows = np.concatenate([np.arange(batch.chunk_reads(c).start, batch.chunk_reads(c).stop) for c in ids])
+    k = ora["result"]["cluster_num"]
+    return dict(chunks=len(ids), eventful=[c for c in REFIT_EVENTFUL if c < batch.n_chunks], oracle_seconds=round(time.perf_counter() - t0, 1),
+                oracle_rc=int(ora["rc"]),
+                labels_equal=bool(np.array_equal(raw["label"][rows], ora["label"])),
+                cluster_num_equal=bool(np.array_equal(raw["cluster_num"][ids], k)),
+                score_bits_equal=bool(np.array_equal(raw["score"][ids].view(np.uint64), ora["result"]["score"].view(np.uint64))),
+                log_post_bits_equal=bool(np.array_equal(raw["log_post"][rows].view(np.uint64), ora["log_post"].view(np.uint64))),
+                max_abs_dlogpost=float(np.abs(raw["log_post"][rows] - ora["log_post"]).max()))
 
 
 PMC_PROFILE = "r04_pmc_traffic.json"
@@ -651,15 +682,15 @@ def main():
         # ---- the whole stage call with its preambles (refit + gains calibration + clustering + normalisation), cold and warm
         api.trim_cache(local_rank)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        cold_ph, _ = stage_e2e(params, batch, cfg, local_rank)
-        warm_ph, st_out = stage_e2e(params, batch, cfg, local_rank, os.path.join(ROOT, "gpurun_out", "record_r05.tsv"))
+        cold_ph, _, _, _ = stage_e2e(params, batch, cfg, local_rank)
+        warm_ph, st_out, p_refit, st_raw = stage_e2e(params, batch, cfg, local_rank, os.path.join(ROOT, "gpurun_out", "record_r05.tsv"))
         line["stage_e2e"] = dict(
             cold=cold_ph, warm=warm_ph, chunks_per_s_warm=batch.n_chunks / (warm_ph["total_ms"] / 1e3),
             chunks_ok=int((st_out["result"]["status"] == 0).sum()),
             note="one LocalClustering::local_clustering_selected call on this rank's shard from host buffers: model refit (10 rounds "
                  "x 5 pile-ups x 2 strands) + gains calibration + jtk_lc_cluster_chunks + normalisation; cold = first call "
                  "(maps the device workspaces), warm = the next one.  The refitted model differs from the resident runs' default "
-                 "model, so labels are not compared with them here")
+                 "model: its results are checked against the oracle on the same parameters in parity_on_refit_sample")
     api.trim_cache(local_rank)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -670,6 +701,8 @@ def main():
         line["parity_on_cpu_sample"] = dict(
             chunks=int(sub.n_chunks), labels_equal=bool(np.array_equal(out["label"][:nr], ora["label"])),
             max_abs_dlogpost=float(np.abs(out["log_post"][:nr] - ora["log_post"]).max()))
+        if not args.no_e2e:
+            line["parity_on_refit_sample"] = refit_parity(p_refit, batch, st_raw)
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:

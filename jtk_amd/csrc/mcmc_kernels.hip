@@ -16,8 +16,9 @@
 //    diploid chain, parses the proposal that would start at every stream position into a 32-bit record; wave 0
 //    ("consumer") runs the algorithm and takes every random draw -- k-means initialisation, proposals, Bernoulli
 //    tests -- from that ring, in stream order.  The stream never depends on the chain, so nothing is speculated.
-//  * THE DIPLOID CHAIN (K == 2, n <= 63, D <= 8) is a table-driven walk over certainly rejected proposals with
-//    exact single steps for everything else (mcmc_chain_k2).
+//  * THE DIPLOID CHAIN (K == 2, n <= 127, D <= 8) keeps, per read, the exact likelihood of the state with that read
+//    flipped (rebuilt lane-parallel after every move) and walks over the proposals that are certainly rejected and
+//    leave no rounding residue; everything else is settled from the read's lane (mcmc_chain_k2).
 //  * THE GENERIC CHAIN keeps LKCount[c][d] in registers (lane = column, K a template parameter), the counts as
 //    integers (num_pos and 3*num_pos - 7*num_neg, which decides is_informative exactly), labels / sizes / >0 masks
 //    as wave-uniform scalars, and commits or undoes a proposal with the reference's own arithmetic
@@ -591,7 +592,10 @@ __device__ __forceinline__ uint32_t choose_pos(Rng &r, uint32_t k) {
 // M^(63*SEG), done as 128 two-bit look-ups in a 16 KiB table (g_jump_tab, computed once on the host from the step
 // function itself, staged in LDS) XOR-ed together.  The sequence of draws is exactly that of the sequential generator.
 static_assert(RN == 2 * SBLK, "the ring holds two superblocks");
-__device__ ulonglong2 g_jump_tab[128 * 4 * 2];  // [2-bit digit position][digit] -> 256-bit column sum of M^(63*SEG)
+// [byte of the state][value of that byte] -> 256-bit image under M^(63*SEG): 256 KiB in device memory, read by every producer
+// wave of the machine (L2 resident).  One jump is 32 look-ups of 32 bytes XOR-ed together; up to round 4 the digits had two bits
+// (128 look-ups in a 16 KiB table): 12 cycles per draw, as much as parsing the proposals -- now 4.
+__device__ ulonglong2 g_jump_tab[32 * 256 * 2];
 
 struct Xo {
     uint64_t s0, s1, s2, s3;
@@ -605,47 +609,36 @@ __device__ __forceinline__ void xo_step(Xo &x) {
     x.s2 ^= t;
     x.s3 = rotl64(x.s3, 45);
 }
-// The table sits in LDS whenever two workgroups per CU can afford it (a look-up that goes to L2 costs a lone wave
-// microseconds: 10.8 K vs 32 K cycles per jump); the loop is compact on purpose: fully unrolled it is kilobytes of
-// straight-line code executed once per superblock, and this kernel is large.
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) const u64x2 lds_cu2;
-template <typename PTR>
-__device__ __forceinline__ void xo_jump_from(Xo &x, PTR tab) {
+// The loop is compact on purpose: fully unrolled it is kilobytes of straight-line code executed once per superblock, and
+// this kernel is large.  Eight look-ups (16 loads) are in flight at a time.
+__device__ __forceinline__ void xo_jump(Xo &x, const ulonglong2 *) {
+    const u64x2 *tab = reinterpret_cast<const u64x2 *>(g_jump_tab);
     uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll 1
     for (int q = 0; q < 4; q++) {
         const uint64_t wq = q == 0 ? x.s0 : (q == 1 ? x.s1 : (q == 2 ? x.s2 : x.s3));
-        PTR row = tab + (q * 32) * 4 * 2;
-#pragma unroll 1
-        for (int k = 0; k < 32; k += 8) {
-            u64x2 lo[8], hi[8];
+        const u64x2 *row = tab + (size_t)(q * 8) * 256 * 2;
+        u64x2 lo[8], hi[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t v = (uint32_t)(wq >> (2 * (k + u))) & 3u;
-                PTR e = row + ((k + u) * 4 + v) * 2;
-                lo[u] = e[0];
-                hi[u] = e[1];
-            }
+        for (int u = 0; u < 8; u++) {
+            const uint32_t v = (uint32_t)(wq >> (8 * u)) & 255u;
+            const u64x2 *e = row + ((size_t)u * 256 + v) * 2;
+            lo[u] = e[0];
+            hi[u] = e[1];
+        }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                a0 ^= lo[u].x;
-                a1 ^= lo[u].y;
-                a2 ^= hi[u].x;
-                a3 ^= hi[u].y;
-            }
+        for (int u = 0; u < 8; u++) {
+            a0 ^= lo[u].x;
+            a1 ^= lo[u].y;
+            a2 ^= hi[u].x;
+            a3 ^= hi[u].y;
         }
     }
     x.s0 = a0;
     x.s1 = a1;
     x.s2 = a2;
     x.s3 = a3;
-}
-__device__ __forceinline__ void xo_jump(Xo &x, const ulonglong2 *lds_tab) {
-    if (lds_tab)
-        xo_jump_from<lds_cu2 *>(x, (lds_cu2 *)lds_tab);
-    else
-        xo_jump_from<const u64x2 *>(x, reinterpret_cast<const u64x2 *>(g_jump_tab));
 }
 // Proposal records.  For the diploid chain a proposal is: gen_range(0..n) takes the first draw at or after its start
 // whose widening multiply is accepted, gen_index(1) (the single candidate of K == 2, pseudo_mcmc.rs:732) then takes
@@ -1714,71 +1707,37 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
 }
 
 // ------------------------------------------------------------------------------------------------------
-// The diploid chain (K == 2, n <= 127, D <= 8) as a table-driven walk.
+// ---- the diploid chain (round 5).
 //
-// More than 96% of the proposals are rejected, and in a given state the fate of "flip read i" is the same every
-// time it is proposed: proposed - lk depends on the state only.  So the chain keeps, per read (one lane each), a
-// REJECTION THRESHOLD thr[i]: the proposal is certainly rejected when the uniform behind its Bernoulli draw
-// exceeds thr[i].  thr[i] comes from an order-free evaluation of get_lk (error ~1e-12, far inside the 1e-3 guard
-// band of the f32 test), and is 2.0 ("cannot tell") when the proposal could be accepted, draws nothing, or when
-// flip + flip-back would leave a rounding residue in a cluster sum ((tg - x) + x != tg).  A certainly rejected
-// proposal of a residue-free read changes nothing at all, so the walk only has to find the next proposal that is
-// NOT one of those -- an EVENT -- and redo that single step with the reference's exact arithmetic (ordered
-// left-to-right sum, exact exp only when the guarded test cannot decide).  After an event that changed the state
-// (accept, or a residue) the table is rebuilt, all reads in parallel.
+// Lane i of the consumer holds READ i (and read 64 + i when NR == 2): its row, signed by the direction of its flip, and --
+// rebuilt lane-parallel after every move of the state -- the EXACT likelihood of the state with that read flipped (get_lk's
+// own left-to-right sum) and whether flip + flip-back would leave a rounding residue.  Both go to a 16-byte entry per read
+// in LDS.  A window is 64 consecutive stream positions (lane l = position base + l): the producer's record of the proposal
+// that WOULD start there (read index, length, 19 bits of its Bernoulli draw); per window the known bits of the draw become
+// two thresholds in the log domain, and the hop word of a position follows from its read's entry: diff = proposed - lk below
+// the one: certainly rejected, above the other: certainly accepted.  The walk follows the hop words over proposals that are
+// certainly rejected and leave nothing behind; everything else is an event, settled from the hop word (the exact exp only
+// inside the guard bands) and the read's lane.  The state (LKCount[c][d] of the two clusters) is wave-uniform and replicated
+// in every lane: neither the event nor the re-evaluation needs a cross-lane operation.  Size-only moves (all-zero rows) are
+// not a special case: the size terms are where every lane's sum starts.
 //
-// Proposals are parsed from a 64-draw window of the raw stream held one draw per lane: the widening-multiply
-// acceptance of gen_range(0..n) and the top-bit acceptance of gen_index(1) are evaluated for all 64 draws at
-// once ("next accepted draw at or after p" is a ballot + s_ff1 -- no rejection loops), every lane holds the
-// proposal that WOULD start at its draw and whether it is certainly rejected; the walk then follows nxt[] through
-// the window with one v_readlane per step.
-// Bit-identical to the one-step-at-a-time chain by construction; checked against the oracle.
-// The consumer's view of 64 consecutive stream positions (lane l = position base + l): the producer's record of
-// the proposal that WOULD start there.  LDS is addressed by byte offset here (a generic pointer indexed per lane costs a
-// 64-bit add and a null check per access).
-typedef __attribute__((address_space(3))) const volatile u32x4_t lds_cvu32x4;
-typedef __attribute__((address_space(3))) volatile u32x4_t lds_vu32x4;
-__device__ __forceinline__ uint32_t lds_addr(const void *p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
-}
-struct Window {
-    uint32_t base;
-    uint32_t w0;   // per lane: the state-independent part of the hop word: nxt in bits 0..5, HW_OUT
-    uint32_t idx;  // per lane: the read index the proposal starting here picks
-    float u;       // per lane: the draw its Bernoulli test compares, / 2^64, truncated to 19 bits; -1 outside the window
-};
 // The hop word of window position l (one v_readlane per hop yields all of it):
-//   bits 0..5 nxt[l] | 64 skip: the proposal starting at l lies inside the window, is certainly rejected and leaves no residue
-//   | 128 certainly accepted | 256 accepted without a draw | 512 certainly rejected | 1024 not in this window.
+//   bits 0..5 nxt[l] | 64 skip: inside the window, certainly rejected, no residue | 128 certainly accepted
+//   | 256 accepted without a draw | 512 certainly rejected | 1024 not in this window | 2048 a rejected flip leaves a residue
 #define HW_SKIP 64u
 #define HW_ACC 128u
 #define HW_NODRAW 256u
 #define HW_REJ 512u
 #define HW_OUT 1024u
-__device__ __forceinline__ void window_load(Window &wd, Rng &rng, uint32_t rec_lds, uint32_t base, uint32_t lane) {
-    rng.pos = base;
-    rng_release(rng, lane);
-    rng_wait_rec(rng, base + 64);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    wd.base = base;
-    const uint32_t r = *(lds_vu32 *)(uintptr_t)(rec_lds + (((base + lane) & (RN - 1)) << 2));
-    const uint32_t len = (r >> 7) & 63u, nxt = lane + len;
-    const bool in_w = len != 0 && nxt < 64;
-    wd.idx = r & 127u;
-    wd.w0 = in_w ? nxt : HW_OUT;
-    wd.u = in_w ? (float)(r >> 13) * 0x1p-19f : -1.0f;
+#define HW_PERT 2048u
+typedef __attribute__((address_space(3))) const volatile double lds_cvf64;
+typedef __attribute__((address_space(3))) const volatile u32x4_t lds_cvu32x4;
+typedef __attribute__((address_space(3))) volatile u32x4_t lds_vu32x4;
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {  // LDS byte address (a generic pointer indexed per lane costs a
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;  // 64-bit add and a null check per access)
 }
-// thr[i] (16 bytes): the two f32 thresholds of "flip read i" in the current state -- the draw is certainly above exp(diff)
-// beyond .x, certainly below it under .y -- and two ready-made pieces of the hop word: .z if it is above, .w in any case.
-__device__ __forceinline__ uint32_t hop_words(const Window &wd, uint32_t thr_lds) {
-    const u32x4_t tv = *(lds_cvu32x4 *)(uintptr_t)(thr_lds + (wd.idx << 4));
-    uint32_t w = wd.w0 | tv.w;
-    w |= wd.u > __uint_as_float(tv.x) ? tv.z : 0u;
-    w |= wd.u < __uint_as_float(tv.y) ? HW_ACC : 0u;
-    return w;
-}
-// Walks from window position p over certainly rejected proposals; returns the number of steps taken (<= limit) and the hop
-// word it stopped at.  Straight-line hops with forward exits: a taken branch costs a lone wave far more than the hop itself.
+// Walks from window position p over skippable proposals; returns the number of steps taken (<= limit) and the hop word it
+// stopped at.  Straight-line hops with forward exits: a taken branch costs a lone wave far more than the hop itself.
 __device__ __forceinline__ uint32_t walk_rejected(uint32_t hopw, uint32_t &p, uint32_t limit, uint32_t &hv_out) {
     uint32_t hv = 0;
     if (limit >= 24) {  // a window holds at most 21 proposals: no need to watch the step budget
@@ -1830,26 +1789,18 @@ __device__ __forceinline__ void scalar_proposal(Rng &rng, uint32_t start, uint32
 #define ST_MARK(k)
 #endif
 
-// The diploid chain (round 5).  Lane i holds read i (and read 64 + i when NR == 2): its row signed by the direction of its
-// flip, and -- rebuilt lane-parallel after every move of the state -- the EXACT likelihood of the state "read i flipped"
-// (get_lk's own left-to-right sum), whether flip + flip-back would leave a rounding residue, and two f32 thresholds for the
-// Bernoulli draw with guard bands.  The walk skips proposals that are certainly rejected and leave nothing behind; everything
-// else is an event, and an event is settled from the read's lane: its decision comes with the hop word (the exact exp only
-// inside the guard bands), its new likelihood and its row are three v_readlane away.  The state (LKCount[c][d] of the two
-// clusters, wave-uniform) is replicated in every lane, so neither the event nor the rebuild needs a cross-lane operation;
-// size-only moves (a read with an all-zero row) need no special case: the size terms are the start of every lane's sum.
 // Out of line on purpose: inlined into the kernel, the chain inherits the register pressure of everything that is
 // live around it and spills scalar registers inside its loop (each reload is a v_readlane on the critical path).
 struct K2Mem {
     const double *data;  // n x D likelihood gains
     const double *lfact;
     uint8_t *assign;
-    double *thr;         // 16 n bytes of threshold entries (the k-means scratch fbuf + cum: idle during a chain)
+    double *tab;         // 16 n bytes: one entry per read (the k-means scratch fbuf + cum: idle during a chain)
     unsigned long long *k2_stats;
 };
-// NR: registers per per-read / per-size table: 1 serves n <= 63, 2 serves n <= 127 (read or size 64 r + lane)
 template <typename T>
 __device__ __forceinline__ T *uni_ptr(T *p) { return reinterpret_cast<T *>((uintptr_t)uni64((uint64_t)(uintptr_t)p)); }
+// NR: registers per per-read / per-size table: 1 serves n <= 63, 2 serves n <= 127 (read or size 64 r + lane)
 template <int DMAX, int NR>
 __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n_in, uint32_t D_in, double cov_in, Rng *rng_io,
                                                           uint32_t lane) {
@@ -1858,7 +1809,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
     // of scalar branches): all of it is re-made wave-uniform here.
     const uint32_t n = uni(n_in), D = uni(D_in);
     const double cov = unif64(cov_in);
-    const K2Mem m = {uni_ptr(m_in.data), uni_ptr(m_in.lfact), uni_ptr(m_in.assign), uni_ptr(m_in.thr), uni_ptr(m_in.k2_stats)};
+    const K2Mem m = {uni_ptr(m_in.data), uni_ptr(m_in.lfact), uni_ptr(m_in.assign), uni_ptr(m_in.tab), uni_ptr(m_in.k2_stats)};
     Rng rng = *rng_io;
     rng.pos = uni(rng.pos);
     rng.wr_seen = uni(rng.wr_seen);
@@ -1868,7 +1819,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
     rng.ctl = uni_ptr(rng.ctl);
     rng.ring = uni_ptr(rng.ring);
     rng.rec = uni_ptr(rng.rec);
-    const uint32_t rec_lds = uni(lds_addr(rng.rec)), thr_lds = uni(lds_addr(m.thr));
+    const uint32_t rec_lds = uni(lds_addr(rng.rec)), data_lds = uni(lds_addr(m.data)), tab_lds = uni(lds_addr(m.tab));
     // pair table: lane c0 holds (0.0 + size_to_lk[c0]) + size_to_lk[n - c0]   (get_lk :788)
     double pair_v[NR];
     auto tab64 = [&](const double *tab, uint32_t i) -> double {  // entry i of a per-lane table of NR registers
@@ -1910,7 +1861,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
 #pragma unroll
         for (int d = 0; d < DMAX; d++) {
             Elem el = {0.0, 0, 0};
-            if ((uint32_t)d < D) el = elem_of(m.data[i * D + d]);
+            if ((uint32_t)d < D) el = elem_of(unif64(m.data[i * D + d]));
             tp2[d] += 2 * el.dp;  // 2 x reads with a positive value in this column: constant along the chain
             if (c == 0) {
                 tg0[d] += el.x;
@@ -1937,14 +1888,40 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
 #pragma unroll
         for (int d = 0; d < DMAX; d++) {
             Elem el = {0.0, 0, 0};
-            if ((uint32_t)d < D) el = elem_of(m.data[ri * D + d]);
+            if ((uint32_t)d < D) el = elem_of(*(lds_cvf64 *)(uintptr_t)(data_lds + ((ri * D + (uint32_t)d) << 3)));
+            const int kk = el.dp + 65536 * el.pw;
             sx[r][d] = a ? el.x : -el.x;
-            spk[r][d] = a ? el.dp + 65536 * el.pw : -(el.dp + 65536 * el.pw);
+            spk[r][d] = a ? kk : -kk;
         }
     }
     wsync();
     auto pair_at = [&](uint32_t c) -> double { return tab64(pair_v, c <= n ? c : n); };
-    // get_lk (:785-795) of the start state: size terms, then clusters outer / columns inner, left to right
+    // get_lk (:785-795) of the state in which a read with the signed row (x, k), sitting in cluster 1 iff `a`, is flipped --
+    // exactly: the size terms, then clusters outer / columns inner, left to right -- and whether flip + flip-back (:746)
+    // would leave a rounding residue in the sums
+    double pair_up, pair_dn;
+    auto flipped_lk = [&](const double *x, const int *k, bool a, double &S_out, bool &pert_out) {
+        double t1[DMAX];
+        double S = a ? pair_up : pair_dn;
+        bool pert = false;
+#pragma unroll
+        for (int d = 0; d < DMAX; d++) {
+            const double T0 = tg0[d] + x[d], T1 = tg1[d] - x[d];  // s - x == s + (-x) bit for bit
+            const int K0 = pk0[d] + k[d], K1 = pk1[d] - k[d];
+            const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
+            const int m0 = pos0 ? K0 : 0, m1 = pos1 ? K1 : 0;
+            // get_used_columns (:847-869): some cluster is informative, and the positives sit where the gain is
+            const bool used = (m0 > m1 ? m0 : m1) > 0xffff && 3 * ((m0 + m1) & 0xffff) > tp2[d];
+            S += (used && pos0) ? T0 : 0.0;
+            t1[d] = (used && pos1) ? T1 : 0.0;
+            pert = pert || (T0 - x[d] != tg0[d]) || (T1 + x[d] != tg1[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < DMAX; d++) S += t1[d];
+        S_out = S;
+        pert_out = pert;
+    };
+    // get_lk of the start state: the same sum with nothing flipped
     double lk;
     {
         double t0[DMAX], t1[DMAX];
@@ -1953,7 +1930,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
             const bool pos0 = 0.0 < tg0[d], pos1 = 0.0 < tg1[d];
             const int in_use = ((pos0 ? pk0[d] : 0) + (pos1 ? pk1[d] : 0)) & 0xffff;
             const bool any = (pos0 && pk0[d] > 0xffff) || (pos1 && pk1[d] > 0xffff);
-            const bool used = any && 3 * in_use > tp2[d];  // get_used_columns (:847-869)
+            const bool used = any && 3 * in_use > tp2[d];
             t0[d] = (used && pos0) ? tg0[d] : 0.0;
             t1[d] = (used && pos1) ? tg1[d] : 0.0;
         }
@@ -1964,54 +1941,57 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
         for (int d = 0; d < DMAX; d++) S += t1[d];
         lk = unif64(S);
     }
-    double pair_up = pair_at(c0 + 1), pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
-    // ---- per read, for the current state: prop_l = get_lk of the state with the read flipped (exactly: the same sum, the
-    //      same order), ndm = the step draws nothing, pertm = a rejected flip leaves a residue; thresholds to LDS
+    pair_up = pair_at(c0 + 1);
+    pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
+    // ---- per read, for the current state: prop_l = get_lk with the read flipped; its entry in LDS: diff = prop_l - lk (the
+    //      quantity `0f64 < diff || rng.gen_bool(diff.exp())` (:736) decides on), the hop-word bits that hold if the draw is
+    //      above exp(diff) (.z), and those that hold anyway (.w: gen_bool(1.0) draws nothing, and exp(diff) == 1.0 exactly
+    //      when diff >= -2^-54; the residue flag)
     double prop_l[NR];
-    unsigned long long ndm[NR], pertm[NR];
     auto evaluate = [&]() {
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            const bool a = __builtin_amdgcn_inverse_ballot_w64(lab[r]);  // the read sits in cluster 1: cluster 0 would grow
-            double t1[DMAX];
-            double S = a ? pair_up : pair_dn;
-            bool pert = false;
-#pragma unroll
-            for (int d = 0; d < DMAX; d++) {
-                const double x = sx[r][d];
-                const double T0 = tg0[d] + x, T1 = tg1[d] - x;  // s - x == s + (-x) bit for bit
-                const int K0 = pk0[d] + spk[r][d], K1 = pk1[d] - spk[r][d];
-                const bool pos0 = 0.0 < T0, pos1 = 0.0 < T1;
-                const int m0 = pos0 ? K0 : 0, m1 = pos1 ? K1 : 0;
-                // get_used_columns (:847-869): some cluster is informative, and the positives sit where the gain is
-                const bool used = (m0 > m1 ? m0 : m1) > 0xffff && 3 * ((m0 + m1) & 0xffff) > tp2[d];
-                S += (used && pos0) ? T0 : 0.0;
-                t1[d] = (used && pos1) ? T1 : 0.0;
-                pert = pert || (T0 - x != tg0[d]) || (T1 + x != tg1[d]);  // flip back (:746) would not restore the sum
-            }
-#pragma unroll
-            for (int d = 0; d < DMAX; d++) S += t1[d];
-            prop_l[r] = S;
-            const double diff = S - lk;
-            // `0f64 < diff || rng.gen_bool(diff.exp())` (:736): gen_bool(1.0) draws nothing, and exp(diff) == 1.0
-            // exactly when diff >= -2^-54
-            const bool nd = diff >= -0x1p-54;
-            ndm[r] = __ballot(nd);
-            pertm[r] = __ballot(pert);
-            // the 19 known bits u of the draw (true value in [u, u + 2^-19)) decide gen_bool unless exp(diff) is within
-            // the guard bands: exp in f32 is good to ~1e-5 relative
-            const float pe = __expf((float)diff);
-            const bool in_range = diff < -1e-3 && diff > -44.4;
-            float rej = in_range ? pe * 1.001f + 1.3e-6f : 3.0f;   // 3.0: cannot tell
-            rej = diff <= -44.4 ? -1.0f : rej;                     // exp(diff) * 2^64 < 1 => p_int == 0
-            const float acc = in_range ? pe * 0.999f - (3e-7f + 0x1p-19f) : -2.0f;
+            bool pert;
+            flipped_lk(sx[r], spk[r], __builtin_amdgcn_inverse_ballot_w64(lab[r]), prop_l[r], pert);
+            const double diff = prop_l[r] - lk;
             u32x4_t e;
-            e.x = __float_as_uint(rej);
-            e.y = __float_as_uint(acc);
+            e.x = (uint32_t)__double2loint(diff);
+            e.y = (uint32_t)__double2hiint(diff);
             e.z = pert ? HW_REJ : HW_REJ | HW_SKIP;
-            e.w = nd ? HW_NODRAW : 0u;
-            if (lane + 64 * r < n) *(lds_vu32x4 *)(uintptr_t)(thr_lds + ((lane + 64 * r) << 4)) = e;
+            e.w = (diff >= -0x1p-54 ? HW_NODRAW : 0u) | (pert ? HW_PERT : 0u);
+            if (lane + 64 * r < n) *(lds_vu32x4 *)(uintptr_t)(tab_lds + ((lane + 64 * r) << 4)) = e;
         }
+    };
+    // ---- the window
+    uint32_t w_base = 0;          // stream position of lane 0
+    uint32_t w_idx = 0, w_w0 = 0; // per lane: the read the proposal starting here picks; nxt in bits 0..5 or HW_OUT
+    double w_lrej = 0.0, w_lacc = 0.0;  // per lane: diff below w_lrej: certainly rejected; above w_lacc: certainly accepted
+    uint32_t hopw = 0;
+    auto hop_words = [&]() {
+        const u32x4_t tv = *(lds_cvu32x4 *)(uintptr_t)(tab_lds + (w_idx << 4));
+        const double diff = __hiloint2double((int)tv.y, (int)tv.x);
+        hopw = w_w0 | tv.w | (diff < w_lrej ? tv.z : 0u) | (diff > w_lacc ? HW_ACC : 0u);
+    };
+    auto window_load = [&](uint32_t base) {
+        rng.pos = base;
+        rng_release(rng, lane);
+        rng_wait_rec(rng, base + 64);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        w_base = base;
+        const uint32_t r = *(lds_vu32 *)(uintptr_t)(rec_lds + (((base + lane) & (RN - 1)) << 2));
+        const uint32_t len = (r >> 7) & 63u, nxt = lane + len;
+        const bool in_w = len != 0 && nxt < 64;
+        w_idx = r & 127u;
+        w_w0 = in_w ? nxt : HW_OUT;
+        // The 19 known bits u of the Bernoulli draw (its true value / 2^64 lies in [u, u + 2^-19)) against exp(diff), in the
+        // log domain, with guard bands far wider than the error of the f32 logarithm (< 2e-6 here):
+        //   diff < ln(u - 1.3e-6) - 2e-3  =>  exp(diff) * 1.002 < u - 1.3e-6: the draw is above p: rejected;  below -44.39
+        //                                     exp(diff) * 2^64 < 1, p_int == 0: rejected whatever the draw
+        //   diff > ln(u + 2^-19 + 3e-7) + 2e-3  =>  exp(diff) > 1.002 (u + 2^-19 + 3e-7): the draw is below p: accepted
+        const float u = (float)(r >> 13) * 0x1p-19f;
+        const float lr = __logf(fmaxf(u - 1.3e-6f, 1e-30f)) - 2e-3f, la = __logf(u + (0x1p-19f + 3e-7f)) + 2e-3f;
+        w_lrej = in_w ? (double)fmaxf(lr, -44.39f) : -__builtin_inf();
+        w_lacc = in_w ? (double)la : __builtin_inf();
     };
     double max = lk;
     unsigned long long argmax[NR];
@@ -2020,39 +2000,52 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
     evaluate();
     const uint32_t total = 2000u * n;
     uint32_t t = 0, p = 0;
-    Window wd;
-    window_load(wd, rng, rec_lds, rng.pos, lane);
-    uint32_t hopw = hop_words(wd, thr_lds);
+    uint32_t load_at = rng.pos, need_load = 1;
     ST_T0();
-    while (t < total) {
-        uint32_t hv;
-        t += walk_rejected(hopw, p, total - t, hv);
-        if (t >= total) break;
-        // ---- p is a proposal that is not certainly rejected, or one this window cannot serve
+    for (;;) {
+        // ---- the walk, across windows, up to the next proposal that cannot be skipped.  An inner loop of its own: it
+        //      writes the window's registers and nothing of the chain's state, so the event below meets the back edge
+        //      without a block of register moves between them.
+        uint32_t hv = 0;
+        bool done = false;
+        for (;;) {
+            if (need_load) {
+                window_load(load_at);
+                hop_words();
+                p = 0;
+                need_load = 0;
+                ST_CNT(6, 1);
+            }
+            if (t >= total) {
+                done = true;
+                break;
+            }
+            t += walk_rejected(hopw, p, total - t, hv);
+            if (t >= total) {
+                done = true;
+                break;
+            }
+            if (!((hv & HW_OUT) && p != 0)) break;
+            load_at = w_base + p;  // the proposal at p does not end inside this window: move the window there
+            need_load = 1;
+        }
+        if (done) break;
 #ifdef JTK_MCMC_STATS
         const unsigned long long g0c = __builtin_readcyclecounter();
 #endif
         ST_MARK0();
         uint32_t e_idx, pos_v;  // the read it picks; stream position of the draw a Bernoulli test would compare
-        bool reload = false;
         if (!(hv & HW_OUT)) {
-            e_idx = uni((uint32_t)__builtin_amdgcn_readlane((int)wd.idx, (int)p));
-            pos_v = wd.base + (hv & 63u) - 1;
-        } else if (p != 0) {  // move the window there
-            window_load(wd, rng, rec_lds, wd.base + p, lane);
-            p = 0;
-            hopw = hop_words(wd, thr_lds);
-            ST_CNT(6, 1);
-            continue;
-        } else {  // not even at the window start: the producer could not parse this one
-            scalar_proposal(rng, wd.base, n, e_idx, pos_v);
-            reload = true;
-            hv = 0;
+            e_idx = uni((uint32_t)__builtin_amdgcn_readlane((int)w_idx, (int)p));
+            pos_v = w_base + (hv & 63u) - 1;
+        } else {
+            // not even at the window start: the producer could not parse this one (it needs more look-ahead than a window
+            // has, p ~ 2^-14).  Scalar draws and the exact Bernoulli test; the window is reloaded behind it.
+            scalar_proposal(rng, w_base, n, e_idx, pos_v);
+            const u32x4_t tv = *(lds_cvu32x4 *)(uintptr_t)(tab_lds + (e_idx << 4));
+            hv = HW_OUT | uni(tv.w);
         }
-        const bool old = bit128(lab, e_idx);
-        if (reload) hv = bit128(ndm, e_idx) ? HW_NODRAW : 0u;
-        const uint32_t no_draw = (hv / HW_NODRAW) & 1u;
-        // the read's lane: the likelihood of the flipped state and its signed row
+        // the read's lane: the likelihood of the flipped state and the read's signed row
         double proposed, x0[DMAX];
         int k0[DMAX];
         if (NR == 2 && e_idx >= 64) {
@@ -2071,17 +2064,14 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
             }
         }
         ST_MARK(10);
-        bool accept = true;
-        if (!(hv & (HW_NODRAW | HW_ACC))) {
-            accept = false;
-            if (!(hv & HW_REJ)) {  // inside the guard bands (or a start without a record): the exact test
-                rng_wait(rng, pos_v + 1);
-                accept = ubool(bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), proposed - lk));  // (an out-of-line call returns in a vector register)
-                ST_CNT(15, 1);
-            }
+        uint32_t accept = (hv & (HW_NODRAW | HW_ACC)) ? 1u : 0u;
+        if (!(hv & (HW_NODRAW | HW_ACC | HW_REJ))) {  // inside the guard bands (or a start without a record): the exact test
+            rng_wait(rng, pos_v + 1);
+            accept = ubool(bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), proposed - lk)) ? 1u : 0u;  // (an out-of-line call returns in a vector register)
+            ST_CNT(15, 1);
         }
         ST_MARK(11);
-        bool changed = true;
+        uint32_t moved = 0;
         if (accept) {
 #pragma unroll
             for (int d = 0; d < DMAX; d++) {
@@ -2090,13 +2080,16 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
                 pk0[d] += k0[d];
                 pk1[d] -= k0[d];
             }
-            c0 = old ? c0 + 1 : c0 - 1;
+            const unsigned long long bit = 1ull << (e_idx & 63u);
+            if (NR == 2 && e_idx >= 64) {
+                c0 = (lab[NR - 1] & bit) ? c0 + 1 : c0 - 1;
+                lab[NR - 1] ^= bit;
+            } else {
+                c0 = (lab[0] & bit) ? c0 + 1 : c0 - 1;  // the read sat in cluster 1: cluster 0 grows
+                lab[0] ^= bit;
+            }
             pair_up = pair_at(c0 + 1);
             pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
-            if (NR == 2 && e_idx >= 64)
-                lab[NR - 1] ^= 1ull << (e_idx & 63u);
-            else
-                lab[0] ^= 1ull << (e_idx & 63u);
             lk = proposed;
             if (ubool(max < lk)) {
                 max = proposed;
@@ -2104,40 +2097,38 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
                 for (int r = 0; r < NR; r++) argmax[r] = lab[r];
             }
 #pragma unroll
-            for (int r = 0; r < NR; r++)
-                if (lane + 64 * r == e_idx) {  // the read now flips the other way
+            for (int r = 0; r < NR; r++) {  // the read now flips the other way
+                const bool mine = lane + 64 * r == e_idx;
 #pragma unroll
-                    for (int d = 0; d < DMAX; d++) {
-                        sx[r][d] = -sx[r][d];
-                        spk[r][d] = -spk[r][d];
-                    }
+                for (int d = 0; d < DMAX; d++) {
+                    sx[r][d] = mine ? -sx[r][d] : sx[r][d];
+                    spk[r][d] = mine ? -spk[r][d] : spk[r][d];
                 }
-        } else if (bit128(pertm, e_idx)) {
+            }
+            moved = 1;
+        } else if (hv & HW_PERT) {
             // flip back (:746) keeps the rounding residue: the sums move although nothing was accepted
 #pragma unroll
             for (int d = 0; d < DMAX; d++) {
                 tg0[d] = (tg0[d] + x0[d]) - x0[d];
                 tg1[d] = (tg1[d] - x0[d]) + x0[d];
             }
-        } else {
-            changed = false;
+            moved = 1;
         }
         t++;
-        const uint32_t pos_next = pos_v + 1 - no_draw;
+        const uint32_t pos_next = pos_v + 1 - ((hv / HW_NODRAW) & 1u);
         ST_CNT(7, 1);
-        ST_CNT(8, accept ? 1 : 0);
-        ST_CNT(9, changed ? 1 : 0);
+        ST_CNT(8, accept);
+        ST_CNT(9, moved);
         ST_MARK(12);
-        if (changed) evaluate();
+        if (moved) evaluate();
         ST_MARK(13);
-        if (reload || pos_next - wd.base >= 64) {
-            window_load(wd, rng, rec_lds, pos_next, lane);
-            p = 0;
-            hopw = hop_words(wd, thr_lds);
-            ST_CNT(6, 1);
+        if ((hv & HW_OUT) || pos_next - w_base >= 64) {
+            load_at = pos_next;
+            need_load = 1;
         } else {
-            p = pos_next - wd.base;
-            if (changed) hopw = hop_words(wd, thr_lds);
+            p = pos_next - w_base;
+            if (moved) hop_words();
         }
         ST_MARK(14);
 #ifdef JTK_MCMC_STATS
@@ -2146,7 +2137,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
     }
     ST_CNT(5, total);
     ST_ADD(0);
-    rng.pos = wd.base + p;
+    rng.pos = w_base + p;
     rng_release(rng, lane);
 #pragma unroll
     for (int r = 0; r < NR; r++)
@@ -2432,8 +2423,6 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     const LdsShape shape = {HUGE ? n : lds_n, HUGE ? D : lds_d, HUGE ? (copy_num < 2 ? 2u : copy_num) : lds_k, jump_in_lds,
                             HUGE ? (uint64_t)(uintptr_t)(ws_base + ws_off[blockIdx.x]) : 0ull};
     Lds m = lds_carve<HUGE>(shape);
-    if (jump_in_lds)
-        for (uint32_t e = threadIdx.x; e < JUMP_TAB_BYTES / 16; e += blockDim.x) m.jump[e] = g_jump_tab[e];
     if (threadIdx.x == 0) {
         lds_st32(&m.ctl->rd, 0);
         lds_st32(&m.ctl->quit, 0);
@@ -2676,12 +2665,11 @@ static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
            al((size_t)lds_d * 16);
 }
 static uint32_t clamp_k(uint32_t lds_k) { return lds_k < 2 ? 2 : (lds_k > JTK_MAX_COPY ? JTK_MAX_COPY : lds_k); }
-static bool mcmc_jump_in_lds(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
-    // The producer's 16 KiB jump table is read from global memory (L2-resident: every workgroup reads the same table) unless
-    // JTK_MCMC_JUMP_LDS asks for a per-workgroup copy: the copy makes the serial chain no faster (the producer has slack) and
-    // costs the kernels that overlap with it 16 KiB of LDS per chunk: 1,823 -> 1,893 chunks/s without it.
-    static const bool in_lds = getenv("JTK_MCMC_JUMP_LDS") != nullptr;
-    return in_lds && mcmc_lds_core(lds_n, lds_d, lds_k) + JUMP_TAB_BYTES <= 80 * 1024;
+static bool mcmc_jump_in_lds(uint32_t, uint32_t, uint32_t) {
+    // The producer's jump table is read from global memory (L2-resident: every workgroup reads the same table).  Up to round 4
+    // the 16 KiB two-bit table could be staged in LDS (JTK_MCMC_JUMP_LDS); the 256 KiB byte table cannot, and LDS is what the
+    // kernels that overlap with the chain need.
+    return false;
 }
 // mcmc_kernel_huge: the LDS in front of the sized arrays (ring + control block) and the global workspace of one chunk (an upper
 // bound: everything sized by n, d, k -- lds_carve keeps what fits JTK_HUGE_LDS in LDS)
@@ -2698,7 +2686,7 @@ size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
     return mcmc_lds_core(lds_n, lds_d, lds_k) + (mcmc_jump_in_lds(lds_n, lds_d, lds_k) ? JUMP_TAB_BYTES : 0);
 }
 
-// ---- host: the two-bit-digit table of M^(63*SEG), from nothing but the generator's own step function
+// ---- host: the byte-digit table of M^(63*SEG), from nothing but the generator's own step function
 namespace {
 struct V256 {
     uint64_t w[4];
@@ -2744,13 +2732,13 @@ std::vector<uint64_t> build_jump_table() {
         m_mul(*m, *m, *tmp);
         *m = *tmp;
     }
-    tab.resize(128 * 4 * 4);
-    for (int k = 0; k < 128; k++)
-        for (int v = 0; v < 4; v++) {
+    tab.resize((size_t)32 * 256 * 4);
+    for (int k = 0; k < 32; k++)
+        for (int v = 0; v < 256; v++) {
             V256 x{{0, 0, 0, 0}};
-            x.w[k >> 5] = (uint64_t)v << (2 * (k & 31));
+            x.w[k >> 3] = (uint64_t)v << (8 * (k & 7));
             const V256 r = m_apply(*acc, x);
-            for (int q = 0; q < 4; q++) tab[((size_t)k * 4 + v) * 4 + q] = r.w[q];
+            for (int q = 0; q < 4; q++) tab[((size_t)k * 256 + v) * 4 + q] = r.w[q];
         }
     delete m;
     delete acc;

@@ -114,7 +114,7 @@ def main():
     print("library: %s, %d chunks of cfg 3, %s model" % (os.environ.get("JTK_LC_LIB", "product"), args.chunks,
                                                        "default" if args.default_model else "refitted"))
     if args.solo:
-        sys.stdout.write("".join(l + "\n" for l in pr.stdout.splitlines() if l.startswith("SOLO")))
+        sys.stdout.write("".join(l + "\n" for l in pr.stdout.splitlines() if l.startswith("SOLO") or "K2STAT" in l or "K2PROD" in l or "K2WAIT" in l))
         return 0
     summarize(pr.stdout, sys.stdout)
     return 0

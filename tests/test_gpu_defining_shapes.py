@@ -9,7 +9,7 @@ import pytest
 
 import helpers
 import oracle_ffi as O
-from jtk_amd import api, batch as jb, synth
+from jtk_amd import api, batch as jb, ffi, synth
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -39,6 +39,43 @@ def test_cfg3_golden_64_chunks(jtk_lib):
     p = jb.default_params(cfg["coverage"], cfg["band_frac"])
     dev = api.cluster_chunks(p, b)
     check_equal(dev, dict(result=g["result"], label=g["label"], log_post=g["log_post"], cons=g["cons"], cons_off=g["cons_off"]), b)
+
+
+def test_cfg3_refit_golden_32_chunks(jtk_lib):
+    """tests/golden/cfg3_refit_32.npz (made by the oracle, tests/golden/make_cfg3_refit_32.py): the stage as JTK enters it
+    (mod.rs:56-83) at full shape -- model refitted on the stage's training pile-ups, gains calibrated on it -- with no oracle in the
+    loop.  The refitted model lets weak columns through the filter: eight of the 32 chunks are ones whose chains accept 10^5 .. 10^6
+    moves (bench.REFIT_EVENTFUL), the regime a table-driven walk is most likely to get wrong.  The device's own refit + gains
+    calibration must reproduce the stored parameters bit for bit, and the clustering on them the stored results."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_cfg3_refit_32 as mk
+    g = np.load(os.path.join(HERE, "golden", "cfg3_refit_32.npz"))
+    b, cfg = mk.make_inputs()
+    assert mk.inputs_digest(b) == str(g["inputs_sha256"][0]), "the generator no longer produces the golden's inputs"
+    p0 = jb.default_params(cfg["coverage"], cfg["band_frac"])
+    f, r = api.fit_model(p0, b.subset(mk.training_chunks(b)), rounds=10)
+    p = ffi.Params.from_buffer_copy(bytes(p0))
+    p.forward, p.reverse = f, r
+    p.gains = api.estimate_gains(f, r)
+    assert bytes(p) == g["params"].tobytes(), "refit / gains calibration differ from the golden's parameters"
+    dev = api.cluster_chunks(p, b)
+    check_equal(dev, dict(result=g["result"], label=g["label"], log_post=g["log_post"], cons=g["cons"], cons_off=g["cons_off"]), b)
+    assert (g["result"]["n_variants"] >= 1).sum() >= 16   # the refitted model does let columns through
+
+
+def test_refit_stage_matches_the_oracle(jtk_lib, oracle):
+    """the same stage (refit + gains + clustering) with the oracle in the loop, on sixteen other chunks of cfg 3: RNG streams and
+    band paths the golden does not hold; parameters from the device's refit, oracle run on exactly those"""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_cfg3_refit_32 as mk
+    g = np.load(os.path.join(HERE, "golden", "cfg3_refit_32.npz"))
+    cfg = dict(synth.CONFIGS["ont_diploid"])
+    b = jb.pack([synth.make_pileup(c, cfg) for c in range(40, 56)])
+    p = ffi.Params.from_buffer_copy(g["params"].tobytes())   # (the refit itself is pinned by the golden test above)
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
+    assert ora["rc"] == 0
+    check_equal(dev, ora, b)
 
 
 def test_256_chunks_of_the_headline_workload_match_the_oracle(jtk_lib, oracle):
