@@ -154,7 +154,12 @@ void launch_phmm_pair(hipStream_t s, uint32_t n_items, const uint32_t *items, co
                       double *raw, int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active);
 void launch_finalize(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                      const ChunkState *state, const HmmDev *hmm2, double *raw, const int *rawG, const double *lk,
-                     uint32_t max_tmpl, int only_active);  // in place: a read's table takes the place of its row sums
+                     uint32_t max_tmpl, int only_active, int converged_in = -1);  // in place: a read's table takes the place of
+                                                                                   // its row sums; converged_in >= 0: only the
+                                                                                   // chunks that converged in that polish round
+// the column totals of a polish round straight from the row sums (finalize's arithmetic + sum_tables' sum, no table written)
+void launch_sum_final(hipStream_t s, uint32_t n_chunks, const ReadMeta *reads, const ChunkMeta *chunks, const ChunkState *state,
+                      const HmmDev *hmm2, const double *raw, const int *rawG, const double *lk, double *total, uint32_t max_tmpl);
 // phmm_wide.hip: the reads of chunks whose band radius exceeds JTK_MAX_RADIUS (phmm_kernel skips them)
 size_t phmm_wide_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
 uint64_t phmm_wide_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius);
@@ -176,4 +181,5 @@ void launch_reset_pass(hipStream_t s, uint32_t n_chunks, ChunkState *state, cons
 void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, const ReadMeta *reads,
                          const ChunkMeta *chunks, ChunkState *state, DevBufs bufs, const uint8_t *ey,
                          const double *table, double *total, Edit *edits, uint32_t *new_len, uint32_t max_tmpl,
-                         uint32_t ignore_edge, int final_pass, uint32_t *n_active_out, uint32_t *n_active_host);
+                         uint32_t ignore_edge, int final_pass, uint32_t *n_active_out, uint32_t *n_active_host,
+                         int totals_ready = 0);  // totals_ready: `total` already holds the round's column totals (launch_sum_final)

@@ -1566,17 +1566,29 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
                 const uint32_t hn = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)pn));
                 const double xn = row_of(hn);
                 const uint32_t old = (hv >> 21) & 7u, nw = (hv >> 24) & 7u;
+#ifdef JTK_MCMC_STATS
+                bool st_res = false;
+#endif
 #pragma unroll
                 for (int c = 0; c < K; c++) {
                     if ((uint32_t)c == old) {
                         asm volatile("" : "+v"(tg[c]));  // keep this a branch: only two of the K sums move
+#ifdef JTK_MCMC_STATS
+                        st_res = st_res || (tg[c] - x) + x != tg[c];
+#endif
                         tg[c] = (tg[c] - x) + x;
                     }
                     if ((uint32_t)c == nw) {
                         asm volatile("" : "+v"(tg[c]));
+#ifdef JTK_MCMC_STATS
+                        st_res = st_res || (tg[c] + x) - x != tg[c];
+#endif
                         tg[c] = (tg[c] + x) - x;
                     }
                 }
+#ifdef JTK_MCMC_STATS
+                TS_ADD(7, __ballot(st_res) != 0ull ? 1 : 0);  // rejected steps that leave a rounding residue in some sum
+#endif
                 p = pn;
                 hv = hn;
                 x = xn;
@@ -1693,8 +1705,8 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
     }
 #ifdef JTK_MCMC_STATS
     if (lane == 0)
-        printf("TABSTAT chunk %u K %d n %u D %u steps %u fast %llu events %llu accepts %llu reloads %llu scalars %llu cyc_rebuild %llu cyc_event %llu cyc_total %llu\n",
-               blockIdx.x, K, n, D, total, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], __builtin_readcyclecounter() - ts_t0);
+        printf("TABSTAT chunk %u K %d n %u D %u steps %u fast %llu events %llu accepts %llu reloads %llu scalars %llu cyc_rebuild %llu cyc_event %llu cyc_total %llu residues %llu\n",
+               blockIdx.x, K, n, D, total, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], __builtin_readcyclecounter() - ts_t0, ts[7]);
 #endif
 #undef TS_ADD
     rng.pos = wd.base + p;

@@ -148,9 +148,66 @@ __device__ __forceinline__ double fin_log(double v, int G, double lk) {
 #define FIN_TILE 128                   // positions per tile
 #define FIN_ROWS (FIN_TILE + 4)        // raw rows a tile reads: p .. p+4 for its last position
 #define FIN_PITCH (JTK_ACC_N + 1)      // doubles per staged row: 17 keeps the 128-byte rows off each other's LDS banks
+// rows p0 .. p0 + n_rows - 1 of a read's row sums into LDS, with coalesced 16-byte loads
+__device__ __forceinline__ void fin_stage(double *s_raw, int *s_G, const double *raw, const int *rawG, int p0, int n_rows,
+                                          int tid, bool dead) {
+    if (dead) return;
+    const double2 *src = reinterpret_cast<const double2 *>(raw + (uint64_t)p0 * JTK_ACC_N);
+    for (int e = tid; e < n_rows * (JTK_ACC_N / 2); e += FIN_TILE) {
+        const double2 v = src[e];
+        const int row = e / (JTK_ACC_N / 2), k = e % (JTK_ACC_N / 2);
+        s_raw[row * FIN_PITCH + 2 * k] = v.x;
+        s_raw[row * FIN_PITCH + 2 * k + 1] = v.y;
+    }
+    for (int e = tid; e < n_rows; e += FIN_TILE) s_G[e] = rawG[p0 + e];
+}
+// the 14 table entries of position p (thread tid of the tile), minus the read's lk, from the staged rows
+__device__ __forceinline__ void fin_position(const double *s_raw, const int *s_G, const double *eM, int tid, int p, int L,
+                                             double lk, bool dead, double *res) {
+#pragma unroll
+    for (int k = 0; k < JTK_NUM_ROW; k++) res[k] = JTK_LOG_ZERO - (dead ? 0.0 : lk);
+    if (!dead && p <= L) {
+        if (p + 1 <= L) {  // row p+1: sub[p], copy_c[p]
+            const double *a = s_raw + (tid + 1) * FIN_PITCH;
+            const int G = s_G[tid + 1];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                double v = eM[4 * b + 0] * a[0];
+                v = fma(eM[4 * b + 1], a[1], v);
+                v = fma(eM[4 * b + 2], a[2], v);
+                v = fma(eM[4 * b + 3], a[3], v);
+                v = v + a[4];
+                res[b] = fin_log(v, G, lk);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) res[8 + cc] = fin_log(a[10 + cc], G, lk);
+        }
+        {  // row p: ins[p]
+            const double *a = s_raw + tid * FIN_PITCH;
+            const int G = s_G[tid];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                double v = eM[4 * b + 0] * a[5];
+                v = fma(eM[4 * b + 1], a[6], v);
+                v = fma(eM[4 * b + 2], a[7], v);
+                v = fma(eM[4 * b + 3], a[8], v);
+                v = v + a[9];
+                res[4 + b] = fin_log(v, G, lk);
+            }
+        }
+#pragma unroll
+        for (int dd = 1; dd <= 3; dd++) {  // row p+d+1: del_d[p]
+            if (p + dd + 1 <= L) {
+                const double *a = s_raw + (tid + dd + 1) * FIN_PITCH;
+                res[11 + dd - 1] = fin_log(a[13 + dd - 1], s_G[tid + dd + 1], lk);
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(FIN_TILE) void finalize_kernel(uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                                                            const ChunkState *state, const HmmDev *hmm2, double *raw_all,
-                                                           const int *rawG_all, const double *lk_all, int only_active) {
+                                                           const int *rawG_all, const double *lk_all, int only_active,
+                                                           int converged_in) {
     // A tile's raw rows come in through LDS with coalesced 16-byte loads and its 14 x 128 table entries leave the same way:
     // a thread's own rows (128 B apart) and its 112 bytes of output would otherwise be 16-byte pieces of different lines.
     __shared__ __align__(16) double s_raw[FIN_ROWS * FIN_PITCH];
@@ -160,6 +217,9 @@ __global__ __launch_bounds__(FIN_TILE) void finalize_kernel(uint32_t n_reads, co
     const ChunkState st = state[rm.chunk];
     if (st.status != 0) return;
     if (only_active && !st.active) return;
+    // converged_in >= 0: only the chunks whose polishing converged in that round (select_edits_kernel found no edit: the
+    // chunk left the active set with `rounds` = round + 1) -- their row sums become their final table, once
+    if (converged_in >= 0 && (st.active || (int)st.rounds != converged_in + 1)) return;
     {
         const ChunkMeta &cm = chunks[rm.chunk];
         if (cm.take_num && item - cm.read_first >= cm.take_num) return;
@@ -177,57 +237,10 @@ __global__ __launch_bounds__(FIN_TILE) void finalize_kernel(uint32_t n_reads, co
     for (int p0 = 0; p0 <= L; p0 += FIN_TILE) {
         const int p = p0 + tid;
         const int n_rows = min(FIN_ROWS, L + 1 - p0);  // rows p0 .. min(p0 + FIN_ROWS - 1, L)
-        if (!dead) {
-            const double2 *src = reinterpret_cast<const double2 *>(raw + (uint64_t)p0 * JTK_ACC_N);
-            for (int e = tid; e < n_rows * (JTK_ACC_N / 2); e += FIN_TILE) {
-                const double2 v = src[e];
-                const int row = e / (JTK_ACC_N / 2), k = e % (JTK_ACC_N / 2);
-                s_raw[row * FIN_PITCH + 2 * k] = v.x;
-                s_raw[row * FIN_PITCH + 2 * k + 1] = v.y;
-            }
-            for (int e = tid; e < n_rows; e += FIN_TILE) s_G[e] = rawG[p0 + e];
-        }
+        fin_stage(s_raw, s_G, raw, rawG, p0, n_rows, tid, dead);
         __syncthreads();
         double res[JTK_NUM_ROW];
-#pragma unroll
-        for (int k = 0; k < JTK_NUM_ROW; k++) res[k] = JTK_LOG_ZERO - (dead ? 0.0 : lk);
-        if (!dead && p <= L) {
-            if (p + 1 <= L) {  // row p+1: sub[p], copy_c[p]
-                const double *a = s_raw + (tid + 1) * FIN_PITCH;
-                const int G = s_G[tid + 1];
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    double v = eM[4 * b + 0] * a[0];
-                    v = fma(eM[4 * b + 1], a[1], v);
-                    v = fma(eM[4 * b + 2], a[2], v);
-                    v = fma(eM[4 * b + 3], a[3], v);
-                    v = v + a[4];
-                    res[b] = fin_log(v, G, lk);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 3; cc++) res[8 + cc] = fin_log(a[10 + cc], G, lk);
-            }
-            {  // row p: ins[p]
-                const double *a = s_raw + tid * FIN_PITCH;
-                const int G = s_G[tid];
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    double v = eM[4 * b + 0] * a[5];
-                    v = fma(eM[4 * b + 1], a[6], v);
-                    v = fma(eM[4 * b + 2], a[7], v);
-                    v = fma(eM[4 * b + 3], a[8], v);
-                    v = v + a[9];
-                    res[4 + b] = fin_log(v, G, lk);
-                }
-            }
-#pragma unroll
-            for (int dd = 1; dd <= 3; dd++) {  // row p+d+1: del_d[p]
-                if (p + dd + 1 <= L) {
-                    const double *a = s_raw + (tid + dd + 1) * FIN_PITCH;
-                    res[11 + dd - 1] = fin_log(a[13 + dd - 1], s_G[tid + dd + 1], lk);
-                }
-            }
-        }
+        fin_position(s_raw, s_G, eM, tid, p, L, lk, dead, res);
         __syncthreads();  // the staged rows are not needed any more: the tile's table entries take their place
         double *s_out = s_raw;  // FIN_TILE x 14 doubles <= FIN_ROWS x 17
         if (p <= L) {
@@ -243,6 +256,63 @@ __global__ __launch_bounds__(FIN_TILE) void finalize_kernel(uint32_t n_reads, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// A polish round needs only the column totals  total[p][row] = sum over the voting reads, IN READ ORDER, of
+// (table_r[p][row] - lk_r)  -- never the per-read tables of a template that is about to be edited.  This kernel is
+// finalize_kernel's arithmetic (the same staged rows, the same 14 logs per position) with the sum of sum_tables_kernel on top:
+// one workgroup per (chunk, tile of 128 positions) walks the reads in order and keeps the 14 totals of its position in
+// registers.  Per read and round it reads the 16 row sums per position once and writes nothing -- finalize + sum_tables wrote
+// the 14-entry table in place and read it back (704 -> 256 bytes per position), and the row sums of a chunk stay intact, so
+// a chunk that turns out to have converged gets its table from finalize_kernel afterwards (converged_in).  Bit for bit the
+// totals of the two-kernel path: the same values are added in the same order.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FIN_TILE) void sum_final_kernel(const ReadMeta *reads, const ChunkMeta *chunks, const ChunkState *state,
+                                                           const HmmDev *hmm2, const double *raw_all, const int *rawG_all,
+                                                           const double *lk_all, double *total_all) {
+    __shared__ __align__(16) double s_raw[FIN_ROWS * FIN_PITCH];
+    __shared__ int s_G[FIN_ROWS];
+    const uint32_t ci = blockIdx.y;
+    const ChunkState st = state[ci];
+    if (st.status != 0 || !st.active) return;
+    const ChunkMeta cm = chunks[ci];
+    const int L = (int)st.tmpl_len;
+    const int p0 = (int)blockIdx.x * FIN_TILE;
+    if (p0 > L) return;
+    const int tid = threadIdx.x, p = p0 + tid;
+    const int n_rows = min(FIN_ROWS, L + 1 - p0);
+    double eMf[16], eMr[16];  // strand 1 -> hmm2[0], strand 0 -> hmm2[1] (as finalize_kernel)
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        eMf[k] = hmm2[0].eM[k];
+        eMr[k] = hmm2[1].eM[k];
+    }
+    double tot[JTK_NUM_ROW];
+#pragma unroll
+    for (int k = 0; k < JTK_NUM_ROW; k++) tot[k] = 0.0;
+    const uint32_t voters = (cm.take_num && cm.take_num < cm.n_reads) ? cm.take_num : cm.n_reads;
+    for (uint32_t r = 0; r < voters; r++) {
+        const uint32_t item = cm.read_first + r;
+        const ReadMeta rm = reads[item];
+        const double lk = lk_all[item];
+        const bool dead = !(lk > JTK_LOG_ZERO);
+        fin_stage(s_raw, s_G, raw_all + rm.raw_off, rawG_all + rm.row_off, p0, n_rows, tid, dead);
+        __syncthreads();
+        double res[JTK_NUM_ROW];
+        if (rm.strand)
+            fin_position(s_raw, s_G, eMf, tid, p, L, lk, dead, res);
+        else
+            fin_position(s_raw, s_G, eMr, tid, p, L, lk, dead, res);
+#pragma unroll
+        for (int k = 0; k < JTK_NUM_ROW; k++) tot[k] += res[k];
+        __syncthreads();  // before the next read's rows are staged
+    }
+    if (p <= L) {
+        double *total = total_all + cm.total_off + (uint64_t)p * JTK_NUM_ROW;
+#pragma unroll
+        for (int k = 0; k < JTK_NUM_ROW; k++) total[k] = tot[k];
+    }
+}
+
 }  // namespace
 
 void launch_band_prep(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
@@ -254,8 +324,16 @@ void launch_band_prep(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, co
 
 void launch_finalize(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                      const ChunkState *state, const HmmDev *hmm2, double *raw, const int *rawG, const double *lk,
-                     uint32_t max_tmpl, int only_active) {
+                     uint32_t max_tmpl, int only_active, int converged_in) {
     if (n_reads == 0) return;
     (void)max_tmpl;
-    finalize_kernel<<<n_reads, FIN_TILE, 0, s>>>(n_reads, reads, chunks, state, hmm2, raw, rawG, lk, only_active);
+    finalize_kernel<<<n_reads, FIN_TILE, 0, s>>>(n_reads, reads, chunks, state, hmm2, raw, rawG, lk, only_active, converged_in);
+}
+
+// the column totals of a polish round straight from the row sums (sum_final_kernel): total[chunk][p][row]
+void launch_sum_final(hipStream_t s, uint32_t n_chunks, const ReadMeta *reads, const ChunkMeta *chunks, const ChunkState *state,
+                      const HmmDev *hmm2, const double *raw, const int *rawG, const double *lk, double *total, uint32_t max_tmpl) {
+    if (n_chunks == 0) return;
+    dim3 grid((max_tmpl + 1 + FIN_TILE - 1) / FIN_TILE, n_chunks);
+    sum_final_kernel<<<grid, FIN_TILE, 0, s>>>(reads, chunks, state, hmm2, raw, rawG, lk, total);
 }

@@ -265,11 +265,12 @@ void launch_reset_pass(hipStream_t s, uint32_t n_chunks, ChunkState *state, cons
 void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, const ReadMeta *reads,
                          const ChunkMeta *chunks, ChunkState *state, DevBufs bufs, const uint8_t *ey,
                          const double *table, double *total, Edit *edits, uint32_t *new_len, uint32_t max_tmpl,
-                         uint32_t ignore_edge, int final_pass, uint32_t *n_active_out, uint32_t *n_active_host) {
+                         uint32_t ignore_edge, int final_pass, uint32_t *n_active_out, uint32_t *n_active_host,
+                         int totals_ready) {
     if (n_chunks == 0) return;
     // n_active_out is this round's own counter (commit_kernel stores it; no fill blit here); n_active_host, if given, is a
     // device-visible pointer into pinned host memory that receives the same number
-    if (!final_pass) {
+    if (!final_pass && !totals_ready) {
         const uint32_t cols = JTK_NUM_ROW * (max_tmpl + 1);
         dim3 grid((cols + 255) / 256, n_chunks);
         sum_tables_kernel<<<grid, 256, 0, s>>>(reads, chunks, state, table, total);

@@ -871,17 +871,30 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                              hmm2, s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves,
                              s->d_wide_counter.as<uint32_t>(), &s->tk_wide, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                              s->d_lk.as<double>(), s->max_tmpl, s->max_read, only_active);
-        launch_finalize(st, s->n_reads, reads, chunks, state, hmm2, s->d_raw.as<double>(), s->d_rawG.as<int>(),
-                        s->d_lk.as<double>(), s->max_tmpl, only_active);
+        // A polish round needs the column totals of the active chunks, not their per-read tables: the totals come straight from
+        // the row sums (sum_final_kernel), and only a chunk that turns out to have converged -- no edit selected -- gets its
+        // table, once, from the row sums it still holds.  The last pass materialises the tables of whatever is still active.
+        if (final_pass)
+            launch_finalize(st, s->n_reads, reads, chunks, state, hmm2, s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                            s->d_lk.as<double>(), s->max_tmpl, only_active);
+        else
+            launch_sum_final(st, s->n_chunks, reads, chunks, state, hmm2, s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                             s->d_lk.as<double>(), s->d_total.as<double>(), s->max_tmpl);
         tstop(s);
         tstart(s, JTK_K_POLISH);
         launch_polish_round(st, s->n_chunks, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(),
                             s->d_raw.as<double>(), s->d_total.as<double>(), s->d_edits.as<Edit>(),
                             s->d_newlen.as<uint32_t>(), s->max_tmpl, s->ignore_edge, final_pass,
-                            s->d_nactive.as<uint32_t>() + round, s->h_nactive_dev + round);
+                            s->d_nactive.as<uint32_t>() + round, s->h_nactive_dev + round, 1);
         if (!final_pass)
             launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 1);
         tstop(s);
+        if (!final_pass && !s->polish_only) {  // the chunks that converged in this round: their tables, for the variant search
+            tstart(s, JTK_K_PHMM);
+            launch_finalize(st, s->n_reads, reads, chunks, state, hmm2, s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                            s->d_lk.as<double>(), s->max_tmpl, 0, round);
+            tstop(s);
+        }
         if (final_pass) break;
         // commit_kernel has stored the round's count in h_nactive[round] itself (mapped pinned memory): no read-back copy
         HIP_TRY(hipEventRecord(s->ev_round[round & 1], st));
