@@ -51,7 +51,7 @@ PHMM_FLOP_PER_CELL = 17 + 17 + 44
 # mcmc_kernel_light on the slice's stream with mcmc_kernel (the general one, few workgroups) beside it on a second stream
 KERNELS_OF_FAMILY = {
     "mcmc": ["mcmc_kernel_light", "mcmc_kernel", "chain_split_kernel"],
-    "phmm": ["phmm_kernel", "phmm_pair_kernel", "phmm_wide_kernel", "finalize_kernel"],
+    "phmm": ["phmm_kernel", "phmm_pair_kernel", "phmm_wide_kernel", "finalize_kernel", "sum_final_kernel"],
     "polish": ["sum_tables_kernel", "select_edits_kernel", "rethread_kernel", "commit_kernel", "band_prep_kernel"],
     "filter": ["homop_kernel", "chunk_tables_kernel", "column_filter_kernel", "pick_kernel"],
 }
@@ -106,7 +106,8 @@ def cpu_baseline(params, batch, budget_s=100.0):
     for t in ladder:
         if spent > budget_s and t != usable:
             continue
-        n = min(2 if t == 1 else 4 * t, batch.n_chunks, 512)  # a few chunks per thread: start-up and first touch amortised
+        n = min(8 if t == 1 else 4 * t, batch.n_chunks, 512)  # a few chunks per thread: start-up and first touch amortised
+                                                              # (8 on one thread: with 2 the rung was noise, round 4)
         sub = batch.subset(range(n))
         t0 = time.perf_counter()
         r = O.cluster_chunks(po, sub, skip_polish=False, n_threads=t, want_record=True)
@@ -124,7 +125,7 @@ def cpu_baseline(params, batch, budget_s=100.0):
     return dict(value=best["chunks_per_s"], unit="chunks/s", cores=usable, threads_used=best["threads"], kind="port",
                 cpus=dict(os_cpu_count=os.cpu_count(), affinity=n_aff, cgroup_quota=quota),
                 scaling=rows, parallel_efficiency_vs_one_thread=ratio,
-                sample=f"first min(4 T, 512) chunks of the same dataset for T threads (every thread busy; 2 chunks at T = 1), full "
+                sample=f"first min(4 T, 512) chunks of the same dataset for T threads (every thread busy; 8 chunks at T = 1), full "
                        f"path (polish + variant search + clustering); best rung: {best['threads']} threads, {best['chunks']} chunks in "
                        f"{best['seconds']} s, mean RECORD {best['mean_record_ms']:.0f} ms/chunk/thread under that load"
                        + ("" if ratio is None or ratio >= 0.5 else
@@ -216,7 +217,7 @@ def refit_parity(p_refit, batch, raw, n_plain=56):
                 max_abs_dlogpost=float(np.abs(raw["log_post"][rows] - ora["log_post"]).max()))
 
 
-PMC_PROFILE = "r04_pmc_traffic.json"
+PMC_PROFILE = "r05_pmc_traffic.json"
 
 
 def pmc_traffic(workload, sha):
@@ -260,6 +261,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the one-shot (host buffers in, host buffers out) timing")
     ap.add_argument("--no-shard8", action="store_true", help="skip the measurement of one rank's share of an 8-GPU run (N = 1 only)")
+    ap.add_argument("--no-weak-probe", action="store_true", help="N > 1: skip the weak-scaling figure taken after the timed region")
     ap.add_argument("--dump-labels", default="", help="rank 0 writes the whole job's labels, cluster numbers and scores in chunk-id "
                                                       "order to this .npz (tests compare an N-rank run with the 1-rank run)")
     args = ap.parse_args()
@@ -503,6 +505,22 @@ def main():
     serial_launch = dict(klaunch)
     serial_out = state["last"]
     steps_agree = bool(np.array_equal(serial_out["label"], out["label"]))
+    # ---- where the chain kernels' time went on this rank (include/jtk_lc_debug.h): a chain launch lasts as long as its slowest
+    #      chunk, so the line names it -- id, its share of the launch, how many of its proposals could not be stepped over
+    cyc = np.concatenate([s_.chain_profile()[0] for s_ in sessions]).astype(np.float64)
+    evs = np.concatenate([s_.chain_profile()[1] for s_ in sessions]).astype(np.int64)
+    worst = int(np.argmax(cyc)) if len(cyc) else 0
+    my_profile = dict(
+        rank=rank, chunks=int(batch.n_chunks), pair_hmm_ms=serial_k["phmm"], polish_ms=serial_k["polish"], filter_ms=serial_k["filter"],
+        chain_ms_summed_over_slices=serial_k["mcmc"], chain_launch_ms_mean=serial_k["mcmc"] / max(1, serial_launch["mcmc"]),
+        slowest_chunk_id=int(my_ids[worst]) if len(cyc) else None, slowest_chunk_chain_ms=float(cyc[worst] / CLOCK_HZ * 1e3) if len(cyc) else None,
+        slowest_chunk_events=int(evs[worst]) if len(cyc) else None,
+        median_chain_ms=float(np.median(cyc[cyc > 0]) / CLOCK_HZ * 1e3) if (cyc > 0).any() else None,
+        chunks_with_a_chain=int((cyc > 0).sum()), events_total=int(evs.sum()))
+    per_rank_profiles = [my_profile]
+    if dist is not None:
+        per_rank_profiles = [None] * world
+        dist.all_gather_object(per_rank_profiles, my_profile)
 
     # ---- roofline: achieved = chunks/s (whole job) x algorithmic bytes per chunk; frac against 8 TB/s per GPU
     alg_bytes_shard = batch.algorithmic_bytes(k_per_chunk=out["result"]["cluster_num"])
@@ -600,6 +618,7 @@ def main():
                 serial_step_agrees=steps_agree, chunks_ok=ok, lib_sha16=sha,
                 mean_polish_rounds=float(out["result"]["polish_rounds"].mean()),
                 mean_cluster_num=float(out["result"]["cluster_num"].mean()))
+    line["per_rank"] = per_rank_profiles   # (N > 1: every rank's serial-pass breakdown and its slowest chain)
     if gather is not None and rank == 0:
         g = state["gathered"]
         line["gathered_reads"] = int(sum(len(x["label"]) for x in g))
@@ -620,6 +639,47 @@ def main():
 
     for s in sessions:
         s.close()
+    # ---- N > 1: the weak-scaling figure next to the strong one.  Strong scaling of the fixed 2,500-chunk data set ends on each
+    #      shard's slowest chain; a data set that grows with the machine has no such term.  Every rank
+    #      therefore also times a full-size private share: its own shard repeated N times (the same mix of pile-ups, 2,500
+    #      chunks per GPU; nothing new to synthesise), same step, no gather.
+    if world > 1 and args.scaling == "strong" and not args.no_weak_probe:
+        wb = batch.subset(np.tile(np.arange(batch.n_chunks), world))
+        nw = max(1, min(args.streams, wb.n_chunks))
+        bw = [round(i * wb.n_chunks / nw) for i in range(nw + 1)]
+        sess_w = [api.Session(params, wb.subset(range(bw[i], bw[i + 1])), device=local_rank) for i in range(nw)]
+
+        def run_w(k):
+            def w(i):
+                for _ in range(k):
+                    sess_w[i].run(skip_polish=False)
+                    sess_w[i].fetch_results()
+            ths = [threading.Thread(target=w, args=(i,)) for i in range(nw)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+
+        steps_w = max(1, min(args.steps, 3))
+        run_w(1)
+        barrier()
+        tw = time.perf_counter()
+        run_w(steps_w)
+        barrier()
+        el_w = time.perf_counter() - tw
+        tt = torch.tensor([el_w, float(wb.n_chunks)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        line["weak_probe"] = dict(
+            chunks_per_gpu=int(wb.n_chunks), steps=steps_w, ms_per_step=float(mx[0].item()) / steps_w * 1e3,
+            chunks_per_s=float(sm[1].item()) * steps_w / float(mx[0].item()),
+            note="weak scaling beside the strong figure: every rank's own shard repeated n_gpus times (2,500 chunks per GPU, the "
+                 "same mix of pile-ups), same step without the gather, max over ranks; value / this = what the tail of the "
+                 "fixed data set costs at this N")
+        for s in sess_w:
+            s.close()
     # ---- what ONE rank of an 8-GPU run would do (north_star's 8 x MI355X target; the pool gives this process one GPU): shard
     #      0 of the 8-way LPT partition of the same dataset, as slices on this GPU, same step definition.  A measured per-GPU
     #      rate, not a scaling curve: no RCCL, no second device.

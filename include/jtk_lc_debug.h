@@ -17,6 +17,12 @@ JTK_LC_API void jtk_lc_debug_cc_keep_sims(int on);
 /* Copy up to `cap` doubles of the kept matrix into `out`; returns its size. */
 JTK_LC_API size_t jtk_lc_debug_cc_first_sims(double *out, size_t cap);
 
+/* Where the chain kernel's time went, per chunk of a session that has run: cycles[c] = shader-clock cycles the chunk's consumer
+ * wave spent in the kernel (0 for a chunk without a variant column), events[c] = proposals of its table-driven chains that could
+ * not be stepped over (accepted moves, rounding residues, draws inside the guard bands).  A chain launch lasts as long as its
+ * slowest chunk: this is how bench.py names it.  Either pointer may be null. */
+JTK_LC_API int jtk_lc_debug_chain_profile(jtk_lc_session_t *s, uint64_t *cycles, uint32_t *events);
+
 #ifdef __cplusplus
 }
 #endif

@@ -206,6 +206,16 @@ class Session:
             check(rc)
         return dict(rc=rc, label=label, log_post=post, result=result)
 
+    def chain_profile(self):
+        """jtk_lc_debug_chain_profile (include/jtk_lc_debug.h): per chunk, the cycles of its chain and its events"""
+        cyc = np.zeros(self.batch.n_chunks, dtype=np.uint64)
+        ev = np.zeros(self.batch.n_chunks, dtype=np.uint32)
+        f = self._lib.jtk_lc_debug_chain_profile
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+        check(f(self._h, u64p(cyc), u32p(ev)))
+        return cyc, ev
+
     def close(self):
         if self._h:
             self._lib.jtk_lc_session_destroy(self._h)

@@ -72,6 +72,9 @@ struct ChunkState {
     uint32_t k;          // cluster_num
     double score;
     uint64_t draws;      // RNG stream positions the clustering consumed
+    uint64_t chain_cycles;  // shader-clock cycles the chunk's consumer wave spent in the chain kernel (jtk_lc_debug_chain_profile)
+    uint32_t chain_events;  // proposals of its table-driven chains that could not be stepped over
+    uint32_t chain_pad;
 };
 
 struct HmmDev {

@@ -61,7 +61,8 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 #define SEG (1 << JTK_MCMC_SEG_LOG)  // draws per producer lane per superblock
 #define SBLK (64 * SEG)              // draws per superblock
 #define RN (2 * SBLK)                // draws in the ring: two superblocks of the producer
-#define JUMP_TAB_BYTES (128 * 4 * 32) // the producer's jump table (g_jump_tab): 16 KiB
+#define JUMP_TAB_BYTES (128 * 4 * 32) // (what an LDS copy of the round-4 jump table took; the byte table lives in L2)
+#define K2_STAT_SLOTS 24             // counters in LDS per chunk: 16 of the statistics build, [16] events (every build)
 // stream position -> ring slot.  Inside a superblock, draw j of segment g sits at j * 64 + ((g + j) & 63): the
 // producer's 64 lanes (one segment each) and the consumer's 64-draw windows (consecutive j) both hit distinct banks.
 __device__ __forceinline__ uint32_t ring_slot(uint32_t pos) {
@@ -227,7 +228,7 @@ struct Lds {
     uint64_t *ring;      // RN raw draws
     uint32_t *rec;       // RN proposal records of the diploid chain
     ulonglong2 *jump;    // the producer's jump table (JUMP_TAB_BYTES)
-    unsigned long long *k2_stats;  // 16 debug counters (JTK_MCMC_STATS builds only)
+    unsigned long long *k2_stats;  // 16 debug counters (JTK_MCMC_STATS builds only) + [16]: events of the table-driven chains
     double *data;        // n x D
     double *size_to_lk;  // n + 1
     double *lfact;       // n + 1
@@ -302,7 +303,7 @@ __device__ __forceinline__ Lds lds_carve(LdsShape sh_in) {
     m.ring = (uint64_t *)take(sizeof(uint64_t) * RN);
     m.rec = (uint32_t *)take(sizeof(uint32_t) * RN);
     m.jump = sh.jump ? (ulonglong2 *)take(JUMP_TAB_BYTES) : nullptr;
-    m.k2_stats = (unsigned long long *)take(16 * 8);
+    m.k2_stats = (unsigned long long *)take(K2_STAT_SLOTS * 8);
     if (HUGE) lds_left = JTK_HUGE_LDS;  // from here on an array that does not fit goes to the workspace (host twin: mcmc_ws_bytes)
     m.data = (double *)take((size_t)lds_n * lds_d * 8);
     m.size_to_lk = (double *)take((size_t)(lds_n + 1) * 8);
@@ -1543,6 +1544,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
     publish();
     const uint32_t total = 2000u * n;
     uint32_t t = 0, p = 0, since_rebuild = 0;
+    uint32_t n_events = 0;  // (reported per chunk: jtk_lc_debug_chain_profile)
     GenWindow wd;
     gwindow_load(wd, rng, rng.pos, lane);
     uint32_t hopw = hop_words(wd);
@@ -1624,6 +1626,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
         const unsigned long long ev_t0 = __builtin_readcyclecounter();
 #endif
         TS_ADD(1, 1);
+        n_events++;
         const uint32_t old = label_of(idx);
         const uint32_t nw = pick < old ? pick : pick + 1;
         Elem el = {0.0, 0, 0};
@@ -1709,6 +1712,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
                blockIdx.x, K, n, D, total, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], __builtin_readcyclecounter() - ts_t0, ts[7]);
 #endif
 #undef TS_ADD
+    if (lane == 0) m.k2_stats[16] += n_events;
     rng.pos = wd.base + p;
     rng_release(rng, lane);
     wsync();
@@ -1956,7 +1960,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
     pair_up = pair_at(c0 + 1);
     pair_dn = pair_at(c0 > 0 ? c0 - 1 : 0);
     // ---- per read, for the current state: prop_l = get_lk with the read flipped; its entry in LDS: diff = prop_l - lk (the
-    //      quantity `0f64 < diff || rng.gen_bool(diff.exp())` (:736) decides on), the hop-word bits that hold if the draw is
+    //      quantity `0f64 < diff || rng.gen_bool(diff.exp())` (:736) decides on, as f32), the hop-word bits that hold if the draw is
     //      above exp(diff) (.z), and those that hold anyway (.w: gen_bool(1.0) draws nothing, and exp(diff) == 1.0 exactly
     //      when diff >= -2^-54; the residue flag)
     double prop_l[NR];
@@ -1967,8 +1971,8 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
             flipped_lk(sx[r], spk[r], __builtin_amdgcn_inverse_ballot_w64(lab[r]), prop_l[r], pert);
             const double diff = prop_l[r] - lk;
             u32x4_t e;
-            e.x = (uint32_t)__double2loint(diff);
-            e.y = (uint32_t)__double2hiint(diff);
+            e.x = __float_as_uint((float)diff);  // (rounded: within 3e-6 of diff wherever a threshold can lie -- the guard bands are 2e-3)
+            e.y = 0;
             e.z = pert ? HW_REJ : HW_REJ | HW_SKIP;
             e.w = (diff >= -0x1p-54 ? HW_NODRAW : 0u) | (pert ? HW_PERT : 0u);
             if (lane + 64 * r < n) *(lds_vu32x4 *)(uintptr_t)(tab_lds + ((lane + 64 * r) << 4)) = e;
@@ -1977,11 +1981,11 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
     // ---- the window
     uint32_t w_base = 0;          // stream position of lane 0
     uint32_t w_idx = 0, w_w0 = 0; // per lane: the read the proposal starting here picks; nxt in bits 0..5 or HW_OUT
-    double w_lrej = 0.0, w_lacc = 0.0;  // per lane: diff below w_lrej: certainly rejected; above w_lacc: certainly accepted
+    float w_lrej = 0.0f, w_lacc = 0.0f;  // per lane: diff below w_lrej: certainly rejected; above w_lacc: certainly accepted
     uint32_t hopw = 0;
     auto hop_words = [&]() {
         const u32x4_t tv = *(lds_cvu32x4 *)(uintptr_t)(tab_lds + (w_idx << 4));
-        const double diff = __hiloint2double((int)tv.y, (int)tv.x);
+        const float diff = __uint_as_float(tv.x);
         hopw = w_w0 | tv.w | (diff < w_lrej ? tv.z : 0u) | (diff > w_lacc ? HW_ACC : 0u);
     };
     auto window_load = [&](uint32_t base) {
@@ -1996,14 +2000,16 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
         w_idx = r & 127u;
         w_w0 = in_w ? nxt : HW_OUT;
         // The 19 known bits u of the Bernoulli draw (its true value / 2^64 lies in [u, u + 2^-19)) against exp(diff), in the
-        // log domain, with guard bands far wider than the error of the f32 logarithm (< 2e-6 here):
+        // log domain, with guard bands far wider than the errors of the hardware logarithm (v_log_f32: 1 ulp of a number below
+        // 100, then one multiplication: < 2e-5) and of diff's rounding to f32 (< 3e-6 where a threshold can lie):
         //   diff < ln(u - 1.3e-6) - 2e-3  =>  exp(diff) * 1.002 < u - 1.3e-6: the draw is above p: rejected;  below -44.39
-        //                                     exp(diff) * 2^64 < 1, p_int == 0: rejected whatever the draw
+        //                                     exp(diff) * 2^64 < 1 (2^64 = e^44.3614), p_int == 0: rejected whatever the draw
         //   diff > ln(u + 2^-19 + 3e-7) + 2e-3  =>  exp(diff) > 1.002 (u + 2^-19 + 3e-7): the draw is below p: accepted
         const float u = (float)(r >> 13) * 0x1p-19f;
-        const float lr = __logf(fmaxf(u - 1.3e-6f, 1e-30f)) - 2e-3f, la = __logf(u + (0x1p-19f + 3e-7f)) + 2e-3f;
-        w_lrej = in_w ? (double)fmaxf(lr, -44.39f) : -__builtin_inf();
-        w_lacc = in_w ? (double)la : __builtin_inf();
+        const float lr = __builtin_amdgcn_logf(fmaxf(u - 1.3e-6f, 1e-30f)) * 0.6931472f - 2e-3f;  // (operands are normal numbers)
+        const float la = __builtin_amdgcn_logf(u + (0x1p-19f + 3e-7f)) * 0.6931472f + 2e-3f;
+        w_lrej = in_w ? fmaxf(lr, -44.39f) : -__builtin_inff();
+        w_lacc = in_w ? la : __builtin_inff();
     };
     double max = lk;
     unsigned long long argmax[NR];
@@ -2013,6 +2019,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
     const uint32_t total = 2000u * n;
     uint32_t t = 0, p = 0;
     uint32_t load_at = rng.pos, need_load = 1;
+    uint32_t n_events = 0;  // (reported per chunk: jtk_lc_debug_chain_profile)
     ST_T0();
     for (;;) {
         // ---- the walk, across windows, up to the next proposal that cannot be skipped.  An inner loop of its own: it
@@ -2076,6 +2083,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
             }
         }
         ST_MARK(10);
+        n_events++;
         uint32_t accept = (hv & (HW_NODRAW | HW_ACC)) ? 1u : 0u;
         if (!(hv & (HW_NODRAW | HW_ACC | HW_REJ))) {  // inside the guard bands (or a start without a record): the exact test
             rng_wait(rng, pos_v + 1);
@@ -2149,6 +2157,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
     }
     ST_CNT(5, total);
     ST_ADD(0);
+    if (lane == 0) m.k2_stats[16] += n_events;
     rng.pos = w_base + p;
     rng_release(rng, lane);
 #pragma unroll
@@ -2480,7 +2489,8 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     }
     for (uint32_t d = lane; d < D; d += 64) m.prev_used[d] = 0;
     for (uint32_t i = lane; i < n; i += 64) m.accepted[i] = 0;
-    if (lane < 16) m.k2_stats[lane] = 0;
+    if (lane < K2_STAT_SLOTS) m.k2_stats[lane] = 0;
+    const unsigned long long chain_t0 = __builtin_readcyclecounter();
     wsync();
     const uint32_t *vt = vtype_all + 2 * ((uint64_t)ci * JTK_MAX_DIM);
     if (vt_stride_mode) vt = vtype_all + 2 * vt_off_all[ci];
@@ -2564,6 +2574,8 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     if (lane == 0) {
         lds_st32(&m.ctl->quit, 1);
         st->draws = rng.pos;  // stream positions consumed: where the chunk's next clustering() call resumes
+        st->chain_cycles = __builtin_readcyclecounter() - chain_t0;
+        st->chain_events = (uint32_t)m.k2_stats[16];
     }
 #ifdef JTK_MCMC_STATS
     if (lane == 0)
@@ -2671,7 +2683,7 @@ static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
     const size_t npad = (lds_n + 63u) & ~63u;
     return al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) +
-           al(16 * 8) + al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) +
+           al(K2_STAT_SLOTS * 8) + al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) +
            2 * al((size_t)JTK_MAX_COPY * lds_d * 8) + 2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d) +
            al((size_t)lds_k * npad * 8) + al(npad * 4) + al((size_t)lds_k * sizeof(SzEnt)) + al((size_t)lds_d * lds_k * 16) +
            al((size_t)lds_d * 16);
@@ -2687,7 +2699,7 @@ static bool mcmc_jump_in_lds(uint32_t, uint32_t, uint32_t) {
 // bound: everything sized by n, d, k -- lds_carve keeps what fits JTK_HUGE_LDS in LDS)
 static size_t mcmc_lds_fixed() {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    return al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) + al(16 * 8);
+    return al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) + al(K2_STAT_SLOTS * 8);
 }
 size_t mcmc_ws_bytes(uint32_t n, uint32_t d, uint32_t k) {
     k = clamp_k(k);

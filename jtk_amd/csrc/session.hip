@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "device_common.h"
+#include "jtk_lc_debug.h"
 
 #define JTK_POOL_DEVICES 16
 
@@ -962,6 +963,21 @@ int jtk_lc_session_run(jtk_lc_session_t *s, int skip_polish) {
     int rc = run_batch(s, skip_polish);
     if (rc == 0 && s->has_split) rc = run_split(s);
     return rc;
+}
+
+// include/jtk_lc_debug.h: per chunk, the cycles of its chain and the proposals that could not be stepped over
+int jtk_lc_debug_chain_profile(jtk_lc_session_t *s, uint64_t *cycles, uint32_t *events) {
+    g_last_error.clear();
+    if (!s) return fail(JTK_ERR_INVALID_ARG, "null session");
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<ChunkState> state(s->n_chunks);
+    HIP_TRY(hipMemcpyAsync(state.data(), s->d_state.p, state.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (uint32_t c = 0; c < s->n_chunks; c++) {
+        if (cycles) cycles[c] = state[c].chain_cycles;
+        if (events) events[c] = state[c].chain_events;
+    }
+    return JTK_OK;
 }
 
 int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post, jtk_lc_result_t *result,

@@ -3,7 +3,7 @@
 # default bench command, the pair-HMM issue counters, the other BASELINE configurations, the default bench line.
 set -u
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=gpurun_out
 if [ "${PROFILE:-1}" = "1" ]; then   # PROFILE=0: the profiles were taken already on these sources
 bash scripts/profile_bench.sh $TAG > $O/final_profile_$TAG.log 2>&1
@@ -15,5 +15,28 @@ timeout 600 python3 bench.py --workload cfg5_hifi_diploid_2500x40x2kbp --steps 8
 timeout 600 python3 bench.py --workload cfg2_ont_diploid_500x60x2kbp --steps 8 --warmup 2 --no-e2e --no-cpu-baseline --no-shard8 > $O/bench_${TAG}_cfg2.json 2> $O/bench_${TAG}_cfg2.err
 timeout 600 python3 scripts/poisson_coverage_bench.py 500 > $O/poisson_$TAG.log 2>&1
 timeout 1200 python3 bench.py --steps 20 --warmup 5 > $O/bench_${TAG}_final.json 2> $O/bench_${TAG}_final.err   # the driver's command
+# One library, one set of numbers: a bench line whose lib_sha16 is not the hash of the library the committed rocprof / PMC profile was
+# taken on (gpurun_out/prof_libsha_$TAG.txt, written by profile_bench.sh) is set aside as .STALE -- it must not reach profiles/.
+python3 - "$TAG" <<'PY'
+import json, os, sys
+tag = sys.argv[1]
+O = "gpurun_out"
+try:
+    want = open(f"{O}/prof_libsha_{tag}.txt").read().strip()
+except OSError:
+    want = None
+for f in ("cfg4_2500", "cfg5", "cfg2", "final"):
+    path = f"{O}/bench_{tag}_{f}.json"
+    try:
+        got = json.loads(open(path).read().strip().splitlines()[-1]).get("lib_sha16")
+    except (OSError, ValueError, IndexError):
+        print("final_round:", path, "is missing or not a bench line")
+        continue
+    if want is None or got != want:
+        os.replace(path, path + ".STALE")
+        print(f"final_round: {path} was measured on library {got}, the profile on {want}: moved to {path}.STALE")
+    else:
+        print(f"final_round: {path} lib_sha16 {got} == profile's")
+PY
 for f in cfg4_2500 cfg5 cfg2 final; do python3 -c "import json,sys; d=json.load(open('$O/bench_${TAG}_$f.json')); print('$f', round(d['value'],1), round(d['ms_per_step'],1), {k: round(v) for k, v in d['roofline']['serial_pass']['kernel_ms'].items()})" 2>&1 | tail -1; done
 tail -2 $O/poisson_$TAG.log

@@ -25,3 +25,29 @@ def jtk_lib():
     from jtk_amd import build, ffi
     build.build()
     return ffi.lib()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_fixtures():
+    """The oracle's answers for the large cases come from tests/golden/oracle/ (helpers.cached_cluster_chunks).  With
+    JTK_DEVICE_IS_ORACLE=1 (tests/golden/make_oracle_cache.py) the oracle also stands in for the device, so that the fixtures can be
+    regenerated where there is no GPU: the device calls of the listed tests return the oracle's own answer."""
+    import helpers
+    import oracle_ffi
+    if not getattr(oracle_ffi.cluster_chunks, "_cached", False):
+        oracle_ffi.cluster_chunks = helpers.cached_cluster_chunks(oracle_ffi.cluster_chunks)
+        oracle_ffi.cluster_chunks._cached = True
+    if os.environ.get("JTK_DEVICE_IS_ORACLE"):
+        from jtk_amd import api
+
+        def dev_chunks(params, batch, device=0, raise_on_chunk_failure=True, devices=None):
+            out = dict(oracle_ffi.cluster_chunks(helpers.oracle_params(params), batch, skip_polish=False))
+            out.setdefault("rc", 0)
+            return out
+
+        def dev_features(params, feature_chunks, variants, variant_type, post_stride, device=0, **kw):
+            n = int(feature_chunks["n_reads"].sum())
+            return helpers.oracle_cluster_features(helpers.oracle_params(params), feature_chunks, variants, variant_type, post_stride, n)
+        api.cluster_chunks = dev_chunks
+        api.cluster_features = dev_features
+    yield

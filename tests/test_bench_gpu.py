@@ -53,6 +53,10 @@ def test_one_rank_line_has_the_contract_fields(jtk_lib):
     assert cb["threads_used"] in [r["threads"] for r in cb["scaling"]] and cb["scaling"][0]["threads"] == 1
     assert line["parity_on_cpu_sample"]["labels_equal"] and line["parity_on_cpu_sample"]["max_abs_dlogpost"] < 1e-4
     assert line["e2e"]["matches_resident"] and line["e2e"]["chunks_per_s"] > 0
+    # the stage as JTK enters it (refitted model) is checked against the oracle on the same parameters
+    rp = line["parity_on_refit_sample"]
+    assert rp["labels_equal"] and rp["cluster_num_equal"] and rp["score_bits_equal"] and rp["max_abs_dlogpost"] < 1e-4
+    assert line["per_rank"][0]["rank"] == 0 and line["per_rank"][0]["chunks"] == 32
 
 
 def test_two_rank_strong_scaling_path(jtk_lib):
@@ -71,6 +75,16 @@ def test_two_rank_strong_scaling_path(jtk_lib):
     assert line["gather_ok"] and line["gathered_reads"] == 24 * 60
     assert line["roofline"]["peak"] == 16000.0
     assert line["cpu_baseline"] is None
+    # N > 1: the line explains itself -- every rank's serial-pass breakdown with its slowest chain, and the weak-scaling figure
+    pr = line["per_rank"]
+    assert [x["rank"] for x in pr] == [0, 1] and all(x["chunks"] == 12 for x in pr)
+    for x in pr:
+        assert x["pair_hmm_ms"] > 0 and x["chain_ms_summed_over_slices"] >= 0
+        if x["chunks_with_a_chain"]:
+            assert x["slowest_chunk_id"] is not None and 0 <= x["slowest_chunk_id"] < 24
+            assert x["slowest_chunk_chain_ms"] > 0 and x["slowest_chunk_events"] >= 0
+    wp = line["weak_probe"]
+    assert wp["chunks_per_gpu"] == 24 and wp["chunks_per_s"] > 0 and wp["ms_per_step"] > 0
 
 
 def test_eight_rank_run_of_the_full_dataset_matches_the_one_rank_run(jtk_lib, tmp_path):
@@ -81,7 +95,7 @@ def test_eight_rank_run_of_the_full_dataset_matches_the_one_rank_run(jtk_lib, tm
     from jtk_amd import api
     api.trim_cache(0)  # this (pytest) process may still hold pooled workspaces of earlier tests: nine more processes follow
     env = dict(os.environ, JTK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", JTK_LC_POOL_GB="16")
-    common = ["--steps", "1", "--warmup", "0", "--no-e2e", "--no-cpu-baseline", "--no-shard8"]
+    common = ["--steps", "1", "--warmup", "0", "--no-e2e", "--no-cpu-baseline", "--no-shard8", "--no-weak-probe"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-labels", str(tmp_path / "one.npz")]
                          + common, capture_output=True, text=True, cwd=ROOT, env=env, timeout=1500)
     assert one.returncode == 0, one.stderr[-3000:]

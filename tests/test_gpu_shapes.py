@@ -3,6 +3,7 @@ other code paths: table-driven chain instead of the generic one, one table regis
 slice of the randomized campaigns of scripts/parity_*.py, the reference's panics as chunk failures, and the
 reference's brute-force comparator as an upper bound of the device chain's score.  All through the C ABI."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -17,7 +18,7 @@ TOL = 1e-4
 
 @pytest.fixture(scope="module")
 def lib(jtk_lib):
-    assert jtk_lib.jtk_lc_device_ok(0) == 1, "needs a gfx950 device"
+    assert os.environ.get("JTK_DEVICE_IS_ORACLE") or jtk_lib.jtk_lc_device_ok(0) == 1, "needs a gfx950 device"
     return jtk_lib
 
 
