@@ -184,5 +184,5 @@ void launch_reset_pass(hipStream_t s, uint32_t n_chunks, ChunkState *state, cons
 void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, const ReadMeta *reads,
                          const ChunkMeta *chunks, ChunkState *state, DevBufs bufs, const uint8_t *ey,
                          const double *table, double *total, Edit *edits, uint32_t *new_len, uint32_t max_tmpl,
-                         uint32_t ignore_edge, int final_pass, uint32_t *n_active_out, uint32_t *n_active_host,
-                         int totals_ready = 0);  // totals_ready: `total` already holds the round's column totals (launch_sum_final)
+                         uint32_t ignore_edge, int final_pass, uint32_t *n_active_out, uint32_t *n_active_host);
+                         // (`total` holds the round's column totals: launch_sum_final)

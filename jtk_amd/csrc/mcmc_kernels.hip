@@ -1535,7 +1535,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
         return (wd.nxt & 63u) | ((in && wd.u > t) ? 64u : 0u) | (in ? 128u : 0u) | (idx << 8) | (pick << 18) | (old << 21) | (nw << 24);
     };
 #ifdef JTK_MCMC_STATS
-    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // fast, events, accepts, reloads, scalars, cyc rebuild, cyc event, cyc total
+    unsigned long long ts[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // fast, events, accepts, reloads, scalars, cyc rebuild, cyc event, residues, cyc window load, cyc hop words, uncertified columns
     const unsigned long long ts_t0 = __builtin_readcyclecounter();
 #define TS_ADD(k, v) ts[k] += (v)
 #else
@@ -1608,10 +1608,21 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
             pick = (hv >> 18) & 7u;
             pos_v = wd.base + (hv & 63u) - 1;
         } else if (p != 0) {  // the proposal does not end inside this window: move the window there
+#ifdef JTK_MCMC_STATS
+            const unsigned long long w_t0 = __builtin_readcyclecounter();
+#endif
             gwindow_load(wd, rng, wd.base + p, lane);
+#ifdef JTK_MCMC_STATS
+            const unsigned long long w_t1 = __builtin_readcyclecounter();
+#endif
             p = 0;
             hopw = hop_words(wd);
             TS_ADD(3, 1);
+#ifdef JTK_MCMC_STATS
+            ts[8] += w_t1 - w_t0;
+            ts[9] += __builtin_readcyclecounter() - w_t1;
+            ts[10] += (unsigned long long)__popc(nrun);
+#endif
             continue;
         } else {  // not even at the window start: the producer could not parse this one -- scalar draws
             TS_ADD(4, 1);
@@ -1708,8 +1719,8 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
     }
 #ifdef JTK_MCMC_STATS
     if (lane == 0)
-        printf("TABSTAT chunk %u K %d n %u D %u steps %u fast %llu events %llu accepts %llu reloads %llu scalars %llu cyc_rebuild %llu cyc_event %llu cyc_total %llu residues %llu\n",
-               blockIdx.x, K, n, D, total, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], __builtin_readcyclecounter() - ts_t0, ts[7]);
+        printf("TABSTAT chunk %u K %d n %u D %u steps %u fast %llu events %llu accepts %llu reloads %llu scalars %llu cyc_rebuild %llu cyc_event %llu cyc_total %llu residues %llu cyc_wload %llu cyc_hopw %llu uncert %llu\n",
+               blockIdx.x, K, n, D, total, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], __builtin_readcyclecounter() - ts_t0, ts[7], ts[8], ts[9], ts[10]);
 #endif
 #undef TS_ADD
     if (lane == 0) m.k2_stats[16] += n_events;

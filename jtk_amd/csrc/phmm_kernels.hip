@@ -259,7 +259,7 @@ __global__ __launch_bounds__(FIN_TILE) void finalize_kernel(uint32_t n_reads, co
 // ------------------------------------------------------------------------------------------------------
 // A polish round needs only the column totals  total[p][row] = sum over the voting reads, IN READ ORDER, of
 // (table_r[p][row] - lk_r)  -- never the per-read tables of a template that is about to be edited.  This kernel is
-// finalize_kernel's arithmetic (the same staged rows, the same 14 logs per position) with the sum of sum_tables_kernel on top:
+// finalize_kernel's arithmetic (the same staged rows, the same 14 logs per position) with the ordered sum that was sum_tables_kernel (up to round 4) on top:
 // one workgroup per (chunk, tile of 128 positions) walks the reads in order and keeps the 14 totals of its position in
 // registers.  Per read and round it reads the 16 row sums per position once and writes nothing -- finalize + sum_tables wrote
 // the 14-entry table in place and read it back (704 -> 256 bytes per position), and the row sums of a chunk stay intact, so

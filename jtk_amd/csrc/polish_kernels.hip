@@ -1,7 +1,7 @@
 // polish_kernels.hip -- one round of consensus polishing on the device (own specification of kiley
 // `polish_until_converge_antidiagonal`, local_clustering/mod.rs:105-106; see DESIGN.md and oracle/phmm.c).
 //
-//   total[p][row] = sum over the reads of the pile-up, IN READ ORDER, of (table_r - lk_r)      (sum_tables)
+//   total[p][row] = sum over the reads of the pile-up, IN READ ORDER, of (table_r - lk_r)      (sum_final_kernel, phmm_kernels.hip)
 //   scan p = ignore_edge .. L-ignore_edge-1 left to right: first best row; apply if > MIN_GAIN, then skip
 //   the touched bases + inactive(round) positions; build the edited template                    (select_edits)
 //   re-thread every read's ops around the edits and recompute the Match/Mismatch tags           (rethread)
@@ -9,21 +9,6 @@
 #include "device_common.h"
 
 namespace {
-
-__global__ void sum_tables_kernel(const ReadMeta *reads, const ChunkMeta *chunks, const ChunkState *state,
-                                  const double *table_all, double *total_all) {
-    const uint32_t ci = blockIdx.y;
-    const ChunkState st = state[ci];
-    if (st.status != 0 || !st.active) return;
-    const ChunkMeta cm = chunks[ci];
-    const uint32_t cols = JTK_NUM_ROW * (st.tmpl_len + 1);
-    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= cols) return;
-    double s = 0.0;
-    const uint32_t voters = (cm.take_num && cm.take_num < cm.n_reads) ? cm.take_num : cm.n_reads;
-    for (uint32_t r = 0; r < voters; r++) s += table_all[reads[cm.read_first + r].table_off + col];
-    total_all[cm.total_off + col] = s;
-}
 
 __device__ __forceinline__ uint32_t edit_inserted(uint32_t row, uint32_t pos, uint32_t L) {
     if (row >= 4 && row < 8) return 1;
@@ -265,16 +250,12 @@ void launch_reset_pass(hipStream_t s, uint32_t n_chunks, ChunkState *state, cons
 void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, const ReadMeta *reads,
                          const ChunkMeta *chunks, ChunkState *state, DevBufs bufs, const uint8_t *ey,
                          const double *table, double *total, Edit *edits, uint32_t *new_len, uint32_t max_tmpl,
-                         uint32_t ignore_edge, int final_pass, uint32_t *n_active_out, uint32_t *n_active_host,
-                         int totals_ready) {
+                         uint32_t ignore_edge, int final_pass, uint32_t *n_active_out, uint32_t *n_active_host) {
     if (n_chunks == 0) return;
     // n_active_out is this round's own counter (commit_kernel stores it; no fill blit here); n_active_host, if given, is a
     // device-visible pointer into pinned host memory that receives the same number
-    if (!final_pass && !totals_ready) {
-        const uint32_t cols = JTK_NUM_ROW * (max_tmpl + 1);
-        dim3 grid((cols + 255) / 256, n_chunks);
-        sum_tables_kernel<<<grid, 256, 0, s>>>(reads, chunks, state, table, total);
-    }
+    // (`total` holds the round's column totals: launch_sum_final, phmm_kernels.hip)
+    (void)table;
     select_edits_kernel<<<n_chunks, 64, max_tmpl + 64, s>>>(chunks, state, bufs, total, edits, new_len,
                                                             ignore_edge, final_pass);
     if (!final_pass) {

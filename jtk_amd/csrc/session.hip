@@ -886,7 +886,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
         launch_polish_round(st, s->n_chunks, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(),
                             s->d_raw.as<double>(), s->d_total.as<double>(), s->d_edits.as<Edit>(),
                             s->d_newlen.as<uint32_t>(), s->max_tmpl, s->ignore_edge, final_pass,
-                            s->d_nactive.as<uint32_t>() + round, s->h_nactive_dev + round, 1);
+                            s->d_nactive.as<uint32_t>() + round, s->h_nactive_dev + round);
         if (!final_pass)
             launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 1);
         tstop(s);
