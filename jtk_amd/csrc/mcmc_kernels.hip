@@ -1535,7 +1535,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
         return (wd.nxt & 63u) | ((in && wd.u > t) ? 64u : 0u) | (in ? 128u : 0u) | (idx << 8) | (pick << 18) | (old << 21) | (nw << 24);
     };
 #ifdef JTK_MCMC_STATS
-    unsigned long long ts[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // fast, events, accepts, reloads, scalars, cyc rebuild, cyc event, residues, cyc window load, cyc hop words, uncertified columns
+    unsigned long long ts[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // fast, events, accepts, reloads, scalars, cyc rebuild, cyc event, residues, cyc window load, cyc hop words, uncertified columns
     const unsigned long long ts_t0 = __builtin_readcyclecounter();
 #define TS_ADD(k, v) ts[k] += (v)
 #else
@@ -1556,6 +1556,9 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
     while (t < total) {
         uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
         if ((hv & 192u) == 192u && since_rebuild < 65536u) {
+#ifdef JTK_MCMC_STATS
+            const unsigned long long f_t0 = __builtin_readcyclecounter();
+#endif
             // ---- certainly rejected proposals, one after the other: flip + flip back (:739,:746) on the two touched
             //      clusters and nothing else.  The next proposal's hop word and row are fetched before this one's
             //      arithmetic (an LDS round trip costs a lone wave ~100 cycles).
@@ -1599,6 +1602,10 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
             t += done;
             since_rebuild += done;
             TS_ADD(0, done);
+#ifdef JTK_MCMC_STATS
+            ts[11] += __builtin_readcyclecounter() - f_t0;   // cycles inside the rejected-steps block
+            ts[12] += 1;                                      // its entries
+#endif
             continue;
         }
         uint32_t idx, pick, pos_v;
@@ -1719,8 +1726,8 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
     }
 #ifdef JTK_MCMC_STATS
     if (lane == 0)
-        printf("TABSTAT chunk %u K %d n %u D %u steps %u fast %llu events %llu accepts %llu reloads %llu scalars %llu cyc_rebuild %llu cyc_event %llu cyc_total %llu residues %llu cyc_wload %llu cyc_hopw %llu uncert %llu\n",
-               blockIdx.x, K, n, D, total, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], __builtin_readcyclecounter() - ts_t0, ts[7], ts[8], ts[9], ts[10]);
+        printf("TABSTAT chunk %u K %d n %u D %u steps %u fast %llu events %llu accepts %llu reloads %llu scalars %llu cyc_rebuild %llu cyc_event %llu cyc_total %llu residues %llu cyc_wload %llu cyc_hopw %llu uncert %llu cyc_fast %llu fast_entries %llu\n",
+               blockIdx.x, K, n, D, total, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], ts[6], __builtin_readcyclecounter() - ts_t0, ts[7], ts[8], ts[9], ts[10], ts[11], ts[12]);
 #endif
 #undef TS_ADD
     if (lane == 0) m.k2_stats[16] += n_events;
