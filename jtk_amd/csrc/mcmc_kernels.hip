@@ -234,7 +234,7 @@ struct Lds {
     double *lfact;       // n + 1
     double *val;         // K x D staging of the per-(cluster, column) terms
     double *centers;     // K x D
-    double *fbuf;        // n (dists / weights / per-read gains)
+    double *fbuf;        // n (dists / weights / per-read gains)   -- fbuf and cum alias the head of stab (lds_carve)
     double *cum;         // n
     uint8_t *assign;     // n   current labels
     uint8_t *argmax;     // n   best labels seen in this chain
@@ -310,8 +310,6 @@ __device__ __forceinline__ Lds lds_carve(LdsShape sh_in) {
     m.lfact = (double *)take((size_t)(lds_n + 1) * 8);
     m.val = (double *)take((size_t)JTK_MAX_COPY * lds_d * 8);
     m.centers = (double *)take((size_t)JTK_MAX_COPY * lds_d * 8);
-    m.fbuf = (double *)take((size_t)lds_n * 8);
-    m.cum = (double *)take((size_t)lds_n * 8);
     m.assign = (uint8_t *)take(lds_n);
     m.argmax = (uint8_t *)take(lds_n);
     m.best = (uint8_t *)take(lds_n);
@@ -322,6 +320,12 @@ __device__ __forceinline__ Lds lds_carve(LdsShape sh_in) {
     m.tmp_used = (uint8_t *)take(lds_d);
     m.npad = (lds_n + 63u) & ~63u;
     m.stab = (double *)take((size_t)lds_k * m.npad * 8);
+    // The k-means scratch (and, in its place, the diploid chain's 16-byte entries) shares the first 16 n bytes of stab: stab is
+    // rebuilt by the first publish() of every K-way chain (umask starts as "never built") and nothing reads it between chains,
+    // k-means and get_read_lk_gains run only between them.  2.5 KB per chunk at 160 reads -- what a 4-copy pile-up's work area
+    // (55.7 KB) was above a third of a CU's LDS: three chain workgroups per CU instead of two (cfg 4).
+    m.fbuf = m.stab;
+    m.cum = m.stab + lds_n;
     m.nz = (uint32_t *)take((size_t)m.npad * 4);
     m.sz = (SzEnt *)take((size_t)lds_k * sizeof(SzEnt));
     m.st = (u32x4_t *)take((size_t)lds_d * lds_k * 16);
@@ -2702,7 +2706,7 @@ static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
     const size_t npad = (lds_n + 63u) & ~63u;
     return al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) +
            al(K2_STAT_SLOTS * 8) + al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) +
-           2 * al((size_t)JTK_MAX_COPY * lds_d * 8) + 2 * al((size_t)lds_n * 8) + 5 * al(lds_n) + 3 * al(lds_d) +
+           2 * al((size_t)JTK_MAX_COPY * lds_d * 8) + 5 * al(lds_n) + 3 * al(lds_d) +   // (fbuf / cum live inside stab)
            al((size_t)lds_k * npad * 8) + al(npad * 4) + al((size_t)lds_k * sizeof(SzEnt)) + al((size_t)lds_d * lds_k * 16) +
            al((size_t)lds_d * 16);
 }
