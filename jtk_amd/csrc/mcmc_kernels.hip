@@ -55,19 +55,21 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 #define JTK_LIGHT_MAX_READS 127u  // what mcmc_kernel_light takes: diploid pile-ups of <= 127 reads ...
 #endif
 #define JTK_LIGHT_MAX_DIM 2u      // ... with <= 2 variant columns (mcmc_chain_k2<1,..> / <2,..>: 168 registers)
-#ifndef JTK_MCMC_SEG_LOG
-#define JTK_MCMC_SEG_LOG 4
-#endif
-#define SEG (1 << JTK_MCMC_SEG_LOG)  // draws per producer lane per superblock
-#define SBLK (64 * SEG)              // draws per superblock
-#define RN (2 * SBLK)                // draws in the ring: two superblocks of the producer
+// The producer's lanes generate SEG = 2^seg_log consecutive draws each per superblock (64 SEG draws); the ring holds two
+// superblocks (RN draws + RN records).  seg_log is a launch parameter (round 5): 4 in the light kernel and the global-memory one
+// (a 24 KiB ring: the jump is paid once per 1,024 draws), 3 in the general kernel -- a 12 KiB ring is what lets FOUR chain
+// workgroups of a 4-copy pile-up share a CU's LDS (40.7 KB each), and the K-way chains' producer has slack for the extra jumps.
+#define JTK_SEG_LOG_LIGHT 4u
+#define JTK_SEG_LOG_GENERAL 3u
+#define RN_OF(seg_log) (128u << (seg_log))
 #define JUMP_TAB_BYTES (128 * 4 * 32) // (what an LDS copy of the round-4 jump table took; the byte table lives in L2)
 #define K2_STAT_SLOTS 24             // counters in LDS per chunk: 16 of the statistics build, [16] events (every build)
 // stream position -> ring slot.  Inside a superblock, draw j of segment g sits at j * 64 + ((g + j) & 63): the
 // producer's 64 lanes (one segment each) and the consumer's 64-draw windows (consecutive j) both hit distinct banks.
-__device__ __forceinline__ uint32_t ring_slot(uint32_t pos) {
-    const uint32_t o = pos & (RN / 2 - 1), g = o >> JTK_MCMC_SEG_LOG, j = o & (SEG - 1);
-    return (pos & (RN / 2)) | (j * 64 + ((g + j) & 63));
+__device__ __forceinline__ uint32_t ring_slot(uint32_t pos, uint32_t seg_log) {
+    const uint32_t half = 64u << seg_log;  // draws per superblock
+    const uint32_t o = pos & (half - 1), g = o >> seg_log, j = o & ((1u << seg_log) - 1);
+    return (pos & half) | (j * 64 + ((g + j) & 63));
 }
 struct RCtl {
     uint32_t rd, quit;  // written by the consumer (read together, 8-byte aligned)
@@ -89,6 +91,7 @@ struct Rng {
     uint32_t wp_seen;  // record progress last observed
     uint32_t pmode;    // the parse mode last announced (epoch << 16 | mode)
     uint32_t win_base; // stream position of the draw held by lane 0 of `win`
+    uint32_t seg_log;  // the ring's geometry (RN_OF(seg_log) draws)
     uint64_t win;      // per lane: the raw draw at win_base + lane (one LDS read serves 64 sequential draws)
 #ifdef JTK_MCMC_STATS
     uint32_t waits;    // polls of the producer's counters that found nothing new
@@ -143,7 +146,7 @@ __device__ __forceinline__ void rng_refill(Rng &r) {  // the register window: 64
     lds_st32(&r.ctl->rd, r.pos);  // every lane stores the same value: draws before r.pos may be overwritten
     rng_wait(r, r.pos + 64);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    r.win = lds_ld64(&r.ring[ring_slot(r.pos + (threadIdx.x & 63u))]);
+    r.win = lds_ld64(&r.ring[ring_slot(r.pos + (threadIdx.x & 63u), r.seg_log)]);
 }
 __device__ __forceinline__ uint64_t next_u64(Rng &r) {
     if ((uint32_t)(r.pos - r.win_base) >= 64u) rng_refill(r);
@@ -218,7 +221,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // caller its registers and the callee flat loads (and hipcc 7.2 fails with "Subtarget requires even aligned vector
 // registers" when a kernel body has to spill a 64-bit value across a call).
 struct LdsShape {
-    uint32_t n, d, k, jump;  // capacity in reads / columns / clusters; the producer's jump table has a copy in LDS
+    uint32_t n, d, k, seg_log;  // capacity in reads / columns / clusters; the ring's geometry
     uint64_t gws;            // 0, or the address of a global-memory workspace (mcmc_kernel_huge): whatever of the arrays sized
                              // by n / d / k does not fit the JTK_HUGE_LDS bytes of LDS behind the ring goes there, in carve order
 };
@@ -268,7 +271,7 @@ __device__ __forceinline__ Lds lds_carve(LdsShape sh_in) {
     sh.n = uni(sh_in.n);
     sh.d = uni(sh_in.d);
     sh.k = uni(sh_in.k);
-    sh.jump = uni(sh_in.jump);
+    sh.seg_log = uni(sh_in.seg_log);
     sh.gws = uni64(sh_in.gws);
     uint32_t base = 0;
     asm volatile("" : "+s"(base));
@@ -300,9 +303,9 @@ __device__ __forceinline__ Lds lds_carve(LdsShape sh_in) {
     const uint32_t lds_n = sh.n, lds_d = sh.d, lds_k = sh.k;
     Lds m;
     m.ctl = (RCtl *)take(sizeof(RCtl));
-    m.ring = (uint64_t *)take(sizeof(uint64_t) * RN);
-    m.rec = (uint32_t *)take(sizeof(uint32_t) * RN);
-    m.jump = sh.jump ? (ulonglong2 *)take(JUMP_TAB_BYTES) : nullptr;
+    m.ring = (uint64_t *)take(sizeof(uint64_t) * RN_OF(sh.seg_log));
+    m.rec = (uint32_t *)take(sizeof(uint32_t) * RN_OF(sh.seg_log));
+    m.jump = nullptr;
     m.k2_stats = (unsigned long long *)take(K2_STAT_SLOTS * 8);
     if (HUGE) lds_left = JTK_HUGE_LDS;  // from here on an array that does not fit goes to the workspace (host twin: mcmc_ws_bytes)
     m.data = (double *)take((size_t)lds_n * lds_d * 8);
@@ -596,11 +599,10 @@ __device__ __forceinline__ uint32_t choose_pos(Rng &r, uint32_t k) {
 // lane's segment and has to skip the other 63 segments: multiplication of the 256-bit state by the constant matrix
 // M^(63*SEG), done as 128 two-bit look-ups in a 16 KiB table (g_jump_tab, computed once on the host from the step
 // function itself, staged in LDS) XOR-ed together.  The sequence of draws is exactly that of the sequential generator.
-static_assert(RN == 2 * SBLK, "the ring holds two superblocks");
 // [byte of the state][value of that byte] -> 256-bit image under M^(63*SEG): 256 KiB in device memory, read by every producer
 // wave of the machine (L2 resident).  One jump is 32 look-ups of 32 bytes XOR-ed together; up to round 4 the digits had two bits
 // (128 look-ups in a 16 KiB table): 12 cycles per draw, as much as parsing the proposals -- now 4.
-__device__ ulonglong2 g_jump_tab[32 * 256 * 2];
+__device__ ulonglong2 g_jump_tab[2][32 * 256 * 2];  // [seg_log - 3]: M^(63 * 8), M^(63 * 16)
 
 struct Xo {
     uint64_t s0, s1, s2, s3;
@@ -617,8 +619,8 @@ __device__ __forceinline__ void xo_step(Xo &x) {
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 // The loop is compact on purpose: fully unrolled it is kilobytes of straight-line code executed once per superblock, and
 // this kernel is large.  Eight look-ups (16 loads) are in flight at a time.
-__device__ __forceinline__ void xo_jump(Xo &x, const ulonglong2 *) {
-    const u64x2 *tab = reinterpret_cast<const u64x2 *>(g_jump_tab);
+__device__ __forceinline__ void xo_jump(Xo &x, uint32_t seg_log) {
+    const u64x2 *tab = reinterpret_cast<const u64x2 *>(g_jump_tab[seg_log - 3u]);
     uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll 1
     for (int q = 0; q < 4; q++) {
@@ -657,13 +659,14 @@ __device__ __forceinline__ void xo_jump(Xo &x, const ulonglong2 *) {
 // a lone wave pays ~8 cycles for a dependent instruction and ~4 for an independent one.
 #define PKEEP 48
 template <int R>
-__device__ __forceinline__ void producer_parse(const uint64_t *ring, uint32_t *rec, uint32_t base, uint32_t n, uint32_t lane) {
+__device__ __forceinline__ void producer_parse(const uint64_t *ring, uint32_t *rec, uint32_t base, uint32_t n, uint32_t lane,
+                                               uint32_t seg_log) {
     const uint64_t zone = ((uint64_t)n << __clzll((long long)n)) - 1;
     uint64_t draw[R];
     uint32_t hi[R], pi[R], pv[R], idx[R], vhi[R];
     bool ok[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) draw[r] = lds_ld64(&ring[ring_slot(base + r * PKEEP + lane)]);
+    for (int r = 0; r < R; r++) draw[r] = lds_ld64(&ring[ring_slot(base + r * PKEEP + lane, seg_log)]);
 #pragma unroll
     for (int r = 0; r < R; r++) {
         hi[r] = (uint32_t)__umul64hi(draw[r], (uint64_t)n);
@@ -683,7 +686,7 @@ __device__ __forceinline__ void producer_parse(const uint64_t *ring, uint32_t *r
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint32_t v = ok[r] ? (idx[r] | ((pv[r] + 1 - lane) << 7) | (vhi[r] & 0xffffe000u)) : 0u;
-        if (lane < PKEEP) lds_st32(&rec[(base + r * PKEEP + lane) & (RN - 1)], v);
+        if (lane < PKEEP) lds_st32(&rec[(base + r * PKEEP + lane) & (RN_OF(seg_log) - 1)], v);
     }
 }
 // Records of the general chain (any K).  A proposal is gen_range(0..n) -- the first draw at or after its start whose
@@ -694,9 +697,9 @@ __device__ __forceinline__ void producer_parse(const uint64_t *ring, uint32_t *r
 // rec == 0: not parsed (needs more look-ahead than the window gives).  `keep` positions are kept per round, so every kept
 // start had 64 - keep draws of look-ahead.
 __device__ __forceinline__ void producer_parse_gen(const uint64_t *ring, uint32_t *rec, uint32_t base, uint32_t n, uint32_t K,
-                                                   uint32_t keep, uint32_t lane) {
+                                                   uint32_t keep, uint32_t lane, uint32_t seg_log) {
     const uint64_t zone = ((uint64_t)n << __clzll((long long)n)) - 1;
-    const uint64_t draw = lds_ld64(&ring[ring_slot(base + lane)]);
+    const uint64_t draw = lds_ld64(&ring[ring_slot(base + lane, seg_log)]);
     const uint32_t v32 = (uint32_t)(draw >> 32);
     const uint32_t hi = (uint32_t)__umul64hi(draw, (uint64_t)n);
     const unsigned long long ok0 = __ballot(draw * (uint64_t)n <= zone);
@@ -719,10 +722,11 @@ __device__ __forceinline__ void producer_parse_gen(const uint64_t *ring, uint32_
     good = good && pv < 64u;
     const uint32_t vhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pv & 63u) << 2), (int)v32);
     const uint32_t v = good ? (idx | (pick << 10) | ((pv + 1u - lane) << 13) | (vhi & 0xfff80000u)) : 0u;
-    if (lane < keep) lds_st32(&rec[(base + lane) & (RN - 1)], v);
+    if (lane < keep) lds_st32(&rec[(base + lane) & (RN_OF(seg_log) - 1)], v);
 }
-__device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_t *rec, const ulonglong2 *jump, uint64_t seed,
+__device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_t *rec, uint32_t seg_log, uint64_t seed,
                                               const uint64_t *resume, uint32_t lane) {
+    const uint32_t SEG = 1u << seg_log, SBLK = 64u << seg_log, RN = RN_OF(seg_log);
     uint64_t z = seed;
     Xo x;
     if (resume) {  // a later clustering() call of the same chunk continues the stream (clustering_recursive, mod.rs:158)
@@ -773,15 +777,15 @@ __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_
             while ((int32_t)(wr - (wp + 64)) >= 0) {
                 if (mode == PM_K2) {
                     if ((int32_t)(wr - (wp + 3 * PKEEP + 64)) >= 0) {
-                        producer_parse<4>(ring, rec, wp, parse_n, lane);
+                        producer_parse<4>(ring, rec, wp, parse_n, lane, seg_log);
                         wp += 4 * PKEEP;
                     } else {
-                        producer_parse<1>(ring, rec, wp, parse_n, lane);
+                        producer_parse<1>(ring, rec, wp, parse_n, lane, seg_log);
                         wp += PKEEP;
                     }
                 } else {
                     const uint32_t keep = mode <= 4u ? 44u : 32u;  // K - 1 more rejection loops need more look-ahead
-                    producer_parse_gen(ring, rec, wp, parse_n, mode, keep, lane);
+                    producer_parse_gen(ring, rec, wp, parse_n, mode, keep, lane, seg_log);
                     wp += keep;
                 }
                 parsed = true;
@@ -794,7 +798,7 @@ __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_
             st_parse += __builtin_readcyclecounter() - tq0;
 #endif
         }
-        if ((int32_t)(wr + SBLK - (uint32_t)c) > RN) {
+        if ((int32_t)(wr + SBLK - (uint32_t)c) > (int32_t)RN) {
 #ifdef JTK_MCMC_STATS
             st_sleeps++;
 #endif
@@ -821,7 +825,7 @@ __device__ __forceinline__ void producer_main(RCtl *ctl, uint64_t *ring, uint32_
 #ifdef JTK_MCMC_STATS
         const unsigned long long tp2 = __builtin_readcyclecounter();
 #endif
-        xo_jump(x, jump);
+        xo_jump(x, seg_log);
 #ifdef JTK_MCMC_STATS
         st_jump += __builtin_readcyclecounter() - tp2;
 #endif
@@ -1254,7 +1258,7 @@ __device__ __forceinline__ void gwindow_load(GenWindow &wd, Rng &rng, uint32_t b
     rng_wait_rec(rng, base + 64);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     wd.base = base;
-    const uint32_t r = lds_ld32(&rng.rec[(base + lane) & (RN - 1)]);
+    const uint32_t r = lds_ld32(&rng.rec[(base + lane) & (RN_OF(rng.seg_log) - 1)]);
     const uint32_t len = (r >> 13) & 63u;
     wd.ip = r & 0x1fffu;
     wd.nxt = (len != 0 && lane + len < 64) ? lane + len : 255u;
@@ -1284,6 +1288,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
     rng.wr_seen = uni(rng_io->wr_seen);
     rng.wp_seen = uni(rng_io->wp_seen);
     rng.win_base = uni(rng_io->win_base);
+    rng.seg_log = uni(rng_io->seg_log);
     rng.pmode = uni(rng_io->pmode);
     rng.win = rng_io->win;
 #ifdef JTK_MCMC_STATS
@@ -1677,7 +1682,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
                 accept = false;
             } else if (!ubool(in_range && u + 0x1p-13f < pe * 0.999f - 3e-7f)) {
                 rng_wait(rng, pos_v + 1);
-                accept = ubool(bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), diff));
+                accept = ubool(bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v, rng.seg_log)])), diff));
             }
         }
         if (accept) {
@@ -1854,6 +1859,8 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
     rng.wp_seen = uni(rng.wp_seen);
     rng.pmode = uni(rng.pmode);
     rng.win_base = uni(rng.win_base);
+    rng.seg_log = uni(rng.seg_log);
+    const uint32_t rn_mask = RN_OF(rng.seg_log) - 1u;
     rng.ctl = uni_ptr(rng.ctl);
     rng.ring = uni_ptr(rng.ring);
     rng.rec = uni_ptr(rng.rec);
@@ -2016,7 +2023,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
         rng_wait_rec(rng, base + 64);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         w_base = base;
-        const uint32_t r = *(lds_vu32 *)(uintptr_t)(rec_lds + (((base + lane) & (RN - 1)) << 2));
+        const uint32_t r = *(lds_vu32 *)(uintptr_t)(rec_lds + (((base + lane) & rn_mask) << 2));
         const uint32_t len = (r >> 7) & 63u, nxt = lane + len;
         const bool in_w = len != 0 && nxt < 64;
         w_idx = r & 127u;
@@ -2109,7 +2116,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
         uint32_t accept = (hv & (HW_NODRAW | HW_ACC)) ? 1u : 0u;
         if (!(hv & (HW_NODRAW | HW_ACC | HW_REJ))) {  // inside the guard bands (or a start without a record): the exact test
             rng_wait(rng, pos_v + 1);
-            accept = ubool(bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v)])), proposed - lk)) ? 1u : 0u;  // (an out-of-line call returns in a vector register)
+            accept = ubool(bernoulli_exact(uni64(lds_ld64(&rng.ring[ring_slot(pos_v, rng.seg_log)])), proposed - lk)) ? 1u : 0u;  // (an out-of-line call returns in a vector register)
             ST_CNT(15, 1);
         }
         ST_MARK(11);
@@ -2424,7 +2431,7 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
                                                   const uint32_t *vtype_all, const uint64_t *vt_off_all,
                                                   uint32_t vt_stride_mode, uint32_t *label_all, double *post_all,
                                                   uint32_t post_stride, double *lg_all, const uint64_t *lg_off,
-                                                  uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, uint32_t jump_in_lds,
+                                                  uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, uint32_t seg_log_in,
                                                   uint32_t flags, const uint64_t *rng_resume, const uint32_t *order,
                                                   const uint32_t *order_count, unsigned char *ws_base = nullptr,
                                                   const uint64_t *ws_off = nullptr) {
@@ -2433,6 +2440,7 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     // long chain that started late.  `order_count`, if given, is the device-side length of the list (the grid is the
     // upper bound the host knows).
     if (order_count && blockIdx.x >= uni(*order_count)) return;
+    const uint32_t seg_log = uni(seg_log_in);  // the ring's geometry: JTK_SEG_LOG_LIGHT / _GENERAL
     const uint32_t ci = order ? order[blockIdx.x] : blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     ChunkState *st = &state[ci];
     if (st->status != 0) return;
@@ -2463,7 +2471,7 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     // ---- LDS carve (again after every out-of-line call: the pointers are cheaper to re-make than to keep alive across it)
     (void)flags;
     // (mcmc_kernel_huge: lds_n / lds_d / lds_k are this chunk's own sizes and size its slice of the global workspace)
-    const LdsShape shape = {HUGE ? n : lds_n, HUGE ? D : lds_d, HUGE ? (copy_num < 2 ? 2u : copy_num) : lds_k, jump_in_lds,
+    const LdsShape shape = {HUGE ? n : lds_n, HUGE ? D : lds_d, HUGE ? (copy_num < 2 ? 2u : copy_num) : lds_k, seg_log,
                             HUGE ? (uint64_t)(uintptr_t)(ws_base + ws_off[blockIdx.x]) : 0ull};
     Lds m = lds_carve<HUGE>(shape);
     if (threadIdx.x == 0) {
@@ -2479,7 +2487,7 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (wave == 1) {  // Xoshiro256StarStar::seed_from_u64(chunk.id * 3490)  (local_clustering/mod.rs:97)
-        producer_main(m.ctl, m.ring, m.rec, m.jump, uni64(cm.chunk_id) * 3490ULL,
+        producer_main(m.ctl, m.ring, m.rec, seg_log, uni64(cm.chunk_id) * 3490ULL,
                       rng_resume ? rng_resume + 4 * (uint64_t)ci : nullptr, lane);
         return;
     }
@@ -2523,6 +2531,7 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     rng.wp_seen = 0;
     rng.pmode = 0;
     rng.win_base = 0xffffff00u;  // nothing held yet
+    rng.seg_log = seg_log;
     rng.win = 0;
 #ifdef JTK_MCMC_STATS
     rng.waits = 0;
@@ -2643,11 +2652,11 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     const ChunkMeta *chunks, ChunkState *state, const jtk_lc_params_t *params, const double *feat_all,                      \
         const uint32_t *vtype_all, const uint64_t *vt_off_all, uint32_t vt_stride_mode, uint32_t *label_all,                \
         double *post_all, uint32_t post_stride, double *lg_all, const uint64_t *lg_off, uint32_t lds_n, uint32_t lds_d,     \
-        uint32_t lds_k, uint32_t jump_in_lds, uint32_t flags, const uint64_t *rng_resume, const uint32_t *order,            \
+        uint32_t lds_k, uint32_t seg_log, uint32_t flags, const uint64_t *rng_resume, const uint32_t *order,                \
         const uint32_t *order_count
 #define MCMC_KERNEL_ARGS                                                                                                    \
     chunks, state, params, feat_all, vtype_all, vt_off_all, vt_stride_mode, label_all, post_all, post_stride, lg_all,       \
-        lg_off, lds_n, lds_d, lds_k, jump_in_lds, flags, rng_resume, order, order_count
+        lg_off, lds_n, lds_d, lds_k, seg_log, flags, rng_resume, order, order_count
 __global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(MCMC_KERNEL_PARAMS) { mcmc_body<false>(MCMC_KERNEL_ARGS); }
 // Pile-ups whose work area does not fit a CU's LDS, or of more than JTK_MAX_PILEUP reads: the per-read arrays live in a
 // global-memory workspace (ws_base + ws_off[block]), the chain is the one-proposal-per-iteration one.  One wave per SIMD: the
@@ -2701,9 +2710,10 @@ __global__ __launch_bounds__(64) void chain_split_kernel(uint32_t count, const u
 }  // namespace
 
 // LDS work area of one chunk (the producer's 16 KiB jump table comes from global memory unless JTK_MCMC_JUMP_LDS is set).
-static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
+static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, uint32_t seg_log = JTK_SEG_LOG_LIGHT) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
     const size_t npad = (lds_n + 63u) & ~63u;
+    const size_t RN = RN_OF(seg_log);
     return al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) +
            al(K2_STAT_SLOTS * 8) + al((size_t)lds_n * lds_d * 8) + 2 * al((size_t)(lds_n + 1) * 8) +
            2 * al((size_t)JTK_MAX_COPY * lds_d * 8) + 5 * al(lds_n) + 3 * al(lds_d) +   // (fbuf / cum live inside stab)
@@ -2711,26 +2721,20 @@ static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
            al((size_t)lds_d * 16);
 }
 static uint32_t clamp_k(uint32_t lds_k) { return lds_k < 2 ? 2 : (lds_k > JTK_MAX_COPY ? JTK_MAX_COPY : lds_k); }
-static bool mcmc_jump_in_lds(uint32_t, uint32_t, uint32_t) {
-    // The producer's jump table is read from global memory (L2-resident: every workgroup reads the same table).  Up to round 4
-    // the 16 KiB two-bit table could be staged in LDS (JTK_MCMC_JUMP_LDS); the 256 KiB byte table cannot, and LDS is what the
-    // kernels that overlap with the chain need.
-    return false;
-}
 // mcmc_kernel_huge: the LDS in front of the sized arrays (ring + control block) and the global workspace of one chunk (an upper
 // bound: everything sized by n, d, k -- lds_carve keeps what fits JTK_HUGE_LDS in LDS)
 static size_t mcmc_lds_fixed() {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t RN = RN_OF(JTK_SEG_LOG_LIGHT);
     return al(sizeof(RCtl)) + al(sizeof(uint64_t) * RN) + al(sizeof(uint32_t) * RN) + al(K2_STAT_SLOTS * 8);
 }
 size_t mcmc_ws_bytes(uint32_t n, uint32_t d, uint32_t k) {
     k = clamp_k(k);
     return ((mcmc_lds_core(n, d, k) - mcmc_lds_fixed()) + 255) & ~(size_t)255;
 }
-size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) {
-    lds_k = clamp_k(lds_k);
-    return mcmc_lds_core(lds_n, lds_d, lds_k) + (mcmc_jump_in_lds(lds_n, lds_d, lds_k) ? JUMP_TAB_BYTES : 0);
-}
+// (the session sorts chunks into launch classes by this number: the 24 KiB ring of the light kernel; the general kernel is
+// launched with 12 KiB less, launch_mcmc)
+size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) { return mcmc_lds_core(lds_n, lds_d, clamp_k(lds_k)); }
 
 // ---- host: the byte-digit table of M^(63*SEG), from nothing but the generator's own step function
 namespace {
@@ -2761,7 +2765,7 @@ V256 m_apply(const M256 &a, const V256 &v) {
 void m_mul(const M256 &a, const M256 &b, M256 &out) {  // out = a * b
     for (int i = 0; i < 256; i++) out.col[i] = m_apply(a, b.col[i]);
 }
-std::vector<uint64_t> build_jump_table() {
+std::vector<uint64_t> build_jump_table(uint32_t SEG) {
     std::vector<uint64_t> tab;
     auto *m = new M256, *acc = new M256, *tmp = new M256;
     for (int b = 0; b < 256; b++) {
@@ -2792,7 +2796,12 @@ std::vector<uint64_t> build_jump_table() {
     return tab;
 }
 const std::vector<uint64_t> &jump_table_host() {  // sessions run on several host threads: initialised exactly once
-    static const std::vector<uint64_t> tab = build_jump_table();
+    static const std::vector<uint64_t> tab = [] {  // [seg_log - 3]: the tables of M^(63 * 8) and M^(63 * 16), back to back
+        std::vector<uint64_t> t = build_jump_table(1u << JTK_SEG_LOG_GENERAL);
+        const std::vector<uint64_t> u = build_jump_table(1u << JTK_SEG_LOG_LIGHT);
+        t.insert(t.end(), u.begin(), u.end());
+        return t;
+    }();
     return tab;
 }
 std::mutex g_jump_mutex;
@@ -2823,14 +2832,14 @@ int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, Chunk
                 const uint32_t *order, uint32_t *split, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (n_chunks == 0) return 0;
     lds_k = clamp_k(lds_k);
-    const size_t lds = mcmc_lds_bytes(lds_n, lds_d, lds_k);
+    const size_t lds = mcmc_lds_core(lds_n, lds_d, lds_k, JTK_SEG_LOG_GENERAL);  // the general kernel: a 12 KiB ring
     if (mcmc_upload_jump_table(s) != 0) return -1;  // the caller fails the call: nothing was launched
     const uint32_t flags = 0u;  // (reserved)
     static const bool no_split = getenv("JTK_MCMC_SPLIT") && atoi(getenv("JTK_MCMC_SPLIT")) == 0;
     if (!split || no_split || flags || rng_resume) {
         mcmc_kernel<<<n_chunks, 128, lds, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
                                               post_stride, lg, lg_off, lds_n, lds_d, lds_k,
-                                              mcmc_jump_in_lds(lds_n, lds_d, lds_k) ? 1u : 0u, flags, rng_resume, order, nullptr);
+                                              JTK_SEG_LOG_GENERAL, flags, rng_resume, order, nullptr);
         return 0;
     }
     chain_split_kernel<<<1, 64, 0, s>>>(n_chunks, order, chunks, state, split);
@@ -2840,12 +2849,12 @@ int launch_mcmc(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, Chunk
         hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess)
         hs = side;
     mcmc_kernel<<<n_chunks, 128, lds, hs>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post, post_stride,
-                                           lg, lg_off, lds_n, lds_d, lds_k, mcmc_jump_in_lds(lds_n, lds_d, lds_k) ? 1u : 0u, 0u,
+                                           lg, lg_off, lds_n, lds_d, lds_k, JTK_SEG_LOG_GENERAL, 0u,
                                            nullptr, split + 2 + n_chunks, split + 1);
     const uint32_t ln = std::min<uint32_t>(lds_n, JTK_LIGHT_MAX_READS), ld = std::min<uint32_t>(lds_d, JTK_LIGHT_MAX_DIM);
     mcmc_kernel_light<<<n_chunks, 128, mcmc_lds_bytes(ln, ld, 2), s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode,
                                                                        label, post, post_stride, lg, lg_off, ln, ld, 2u,
-                                                                       mcmc_jump_in_lds(ln, ld, 2) ? 1u : 0u, 0u, nullptr,
+                                                                       JTK_SEG_LOG_LIGHT, 0u, nullptr,
                                                                        split + 2, split);
     if (hs != s) {
         if (hipEventRecord(ev_join, hs) != hipSuccess || hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return -1;
@@ -2862,7 +2871,7 @@ int launch_mcmc_huge(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, 
     if (n_chunks == 0) return 0;
     if (mcmc_upload_jump_table(s) != 0) return -1;
     mcmc_kernel_huge<<<n_chunks, 128, mcmc_lds_fixed() + JTK_HUGE_LDS, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
-                                                             post_stride, lg, lg_off, max_n, max_d, clamp_k(max_k), 0u, 0u,
+                                                             post_stride, lg, lg_off, max_n, max_d, clamp_k(max_k), JTK_SEG_LOG_LIGHT, 0u,
                                                              rng_resume, order, nullptr, ws, ws_off);
     return 0;
 }
