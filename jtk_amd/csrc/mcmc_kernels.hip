@@ -1557,57 +1557,90 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
     GenWindow wd;
     gwindow_load(wd, rng, rng.pos, lane);
     uint32_t hopw = hop_words(wd);
+    const uint32_t row_lane_addr = (uint32_t)(uintptr_t)data_l + (lane < D ? lane : 0u) * 8u;  // (the rejected steps' hand-issued loads)
     auto row_of = [&](uint32_t hvv) -> double {  // the column values of the read a hop word names (lanes >= D: 0.0)
         uint32_t i = (hvv >> 8) & 1023u;
         i = i < n1 ? i : n1;  // a word that is not a proposal may hold anything
         return lane < D ? data_l[i * D + lane] : 0.0;
     };
-    while (t < total) {
-        uint32_t hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
+    for (;;) {
+        // ---- the quiet part, a loop of its own: blocks of certainly rejected proposals and window moves follow one another
+        //      without passing the event's code (whose many live values the compiler would otherwise merge at every back edge:
+        //      a chain spends ~8 steps per window and ~70 steps per event at K = 3)
+        uint32_t hv = 0;
+        bool finished = false;
+        for (;;) {
+        if (t >= total) {
+            finished = true;
+            break;
+        }
+        hv = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)p));
         if ((hv & 192u) == 192u && since_rebuild < 65536u) {
 #ifdef JTK_MCMC_STATS
             const unsigned long long f_t0 = __builtin_readcyclecounter();
 #endif
             // ---- certainly rejected proposals, one after the other: flip + flip back (:739,:746) on the two touched
             //      clusters and nothing else.  The next proposal's hop word and row are fetched before this one's
-            //      arithmetic (an LDS round trip costs a lone wave ~100 cycles).
-            double x = row_of(hv);
+            //      arithmetic (an LDS round trip costs a lone wave ~100 cycles).  Round 5, from the ISA of the round-4 loop:
+            //      (a) `x = xn` at the back edge made every step wait for the row it had just asked for -- the loop is unrolled
+            //      twice over two row registers, a step waits for the OLDER load only; (b) 2 K scalar compare-and-branch pairs
+            //      picked the two touched sums -- now every cluster's sum takes (s + m) - m with m = x * {-1, +1, 0} (a scalar
+            //      factor): x * -1 and x * 1 are exact, (s + -x) - -x is (s - x) + x bit for bit, and m = +-0 leaves s as it is
+            //      (no sum is ever -0: they grow from +0 by additions), so the bits are the reference's and nothing branches.
             uint32_t budget = total - t;
             if (budget > 65536u - since_rebuild) budget = 65536u - since_rebuild;
             uint32_t done = 0;
-            do {
-                const uint32_t pn = hv & 63u;
-                const uint32_t hn = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)pn));
-                const double xn = row_of(hn);
-                const uint32_t old = (hv >> 21) & 7u, nw = (hv >> 24) & 7u;
+            auto rejected_step = [&](uint32_t hvv, double x) {
+                const uint32_t old = (hvv >> 21) & 7u, nw = (hvv >> 24) & 7u;
 #ifdef JTK_MCMC_STATS
                 bool st_res = false;
 #endif
 #pragma unroll
                 for (int c = 0; c < K; c++) {
-                    if ((uint32_t)c == old) {
-                        asm volatile("" : "+v"(tg[c]));  // keep this a branch: only two of the K sums move
+                    const uint32_t hi = (uint32_t)c == old ? 0xBFF00000u : ((uint32_t)c == nw ? 0x3FF00000u : 0u);
+                    const double mc = x * __hiloint2double((int)hi, 0);
 #ifdef JTK_MCMC_STATS
-                        st_res = st_res || (tg[c] - x) + x != tg[c];
+                    st_res = st_res || (tg[c] + mc) - mc != tg[c];
 #endif
-                        tg[c] = (tg[c] - x) + x;
-                    }
-                    if ((uint32_t)c == nw) {
-                        asm volatile("" : "+v"(tg[c]));
-#ifdef JTK_MCMC_STATS
-                        st_res = st_res || (tg[c] + x) - x != tg[c];
-#endif
-                        tg[c] = (tg[c] + x) - x;
-                    }
+                    tg[c] = (tg[c] + mc) - mc;
                 }
 #ifdef JTK_MCMC_STATS
                 TS_ADD(7, __ballot(st_res) != 0ull ? 1 : 0);  // rejected steps that leave a rounding residue in some sum
 #endif
+            };
+            // The rows travel through hand-issued ds_read_b64 with hand-placed waits: the compiler's own scoreboard waits with
+            // lgkmcnt(0) in this loop -- i.e. for the row it has just asked for as well -- where "all but the youngest load"
+            // (lgkmcnt(1): LDS loads return in order) is what hides the round trip.  No other LDS access happens between the
+            // first load and the drain behind the loop; lanes >= D read column 0 and keep their zero sums ((0 + m) - m == +0).
+            auto row_issue = [&](uint32_t hvv) -> double {
+                uint32_t i = (hvv >> 8) & 1023u;
+                i = i < n1 ? i : n1;  // a word that is not a proposal may hold anything
+                double v;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(row_lane_addr + i * (D * 8u)));
+                return v;
+            };
+            double xa = row_issue(hv), xb;
+            for (;;) {
+                uint32_t pn = hv & 63u;
+                uint32_t hn = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)pn));
+                xb = row_issue(hn);
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xa));  // the older of the two rows in flight
+                rejected_step(hv, xa);
                 p = pn;
                 hv = hn;
-                x = xn;
                 done++;
-            } while ((hv & 192u) == 192u && done < budget);
+                if (!((hv & 192u) == 192u && done < budget)) break;
+                pn = hv & 63u;
+                hn = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)pn));
+                xa = row_issue(hn);
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xb));
+                rejected_step(hv, xb);
+                p = pn;
+                hv = hn;
+                done++;
+                if (!((hv & 192u) == 192u && done < budget)) break;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa), "+v"(xb));  // the row fetched for a step that did not run
             t += done;
             since_rebuild += done;
             TS_ADD(0, done);
@@ -1617,13 +1650,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
 #endif
             continue;
         }
-        uint32_t idx, pick, pos_v;
-        bool reload = false;
-        if (hv & 128u) {
-            idx = (hv >> 8) & 1023u;
-            pick = (hv >> 18) & 7u;
-            pos_v = wd.base + (hv & 63u) - 1;
-        } else if (p != 0) {  // the proposal does not end inside this window: move the window there
+        if (!(hv & 128u) && p != 0) {  // the proposal does not end inside this window: move the window there
 #ifdef JTK_MCMC_STATS
             const unsigned long long w_t0 = __builtin_readcyclecounter();
 #endif
@@ -1640,6 +1667,16 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
             ts[10] += (unsigned long long)__popc(nrun);
 #endif
             continue;
+        }
+        break;
+        }
+        if (finished) break;
+        uint32_t idx, pick, pos_v;
+        bool reload = false;
+        if (hv & 128u) {
+            idx = (hv >> 8) & 1023u;
+            pick = (hv >> 18) & 7u;
+            pos_v = wd.base + (hv & 63u) - 1;
         } else {  // not even at the window start: the producer could not parse this one -- scalar draws
             TS_ADD(4, 1);
             rng.pos = wd.base;
@@ -2486,6 +2523,12 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+#ifdef JTK_MCMC_PRIO_PRODUCER  // experiments: wave priority of the two halves of a chain workgroup (s_setprio 0..3)
+    if (wave == 1) __builtin_amdgcn_s_setprio(JTK_MCMC_PRIO_PRODUCER);
+#endif
+#ifdef JTK_MCMC_PRIO_CONSUMER
+    if (wave == 0) __builtin_amdgcn_s_setprio(JTK_MCMC_PRIO_CONSUMER);
+#endif
     if (wave == 1) {  // Xoshiro256StarStar::seed_from_u64(chunk.id * 3490)  (local_clustering/mod.rs:97)
         producer_main(m.ctl, m.ring, m.rec, seg_log, uni64(cm.chunk_id) * 3490ULL,
                       rng_resume ? rng_resume + 4 * (uint64_t)ci : nullptr, lane);

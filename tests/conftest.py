@@ -10,6 +10,41 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "changes_env: the test sets process environment variables (runs before tests/prefetch.py's threads start)")
+
+
+@pytest.hookimpl(trylast=True)   # (after -m / -k have deselected)
+def pytest_collection_modifyitems(config, items):
+    # tests that setenv go first: the threads of tests/prefetch.py (whose library calls getenv) start after the last of them
+    first = [it for it in items if it.get_closest_marker("changes_env")]
+    if first:
+        items[:] = first + [it for it in items if not it.get_closest_marker("changes_env")]
+    config._jtk_selected = [it.nodeid for it in items]
+
+
+def pytest_runtest_setup(item):
+    """GPU runs only: once the environment-changing tests are through, the suite's slowest device calls start on other host
+    threads (tests/prefetch.py) and the tests that need them pick the results up."""
+    if item.get_closest_marker("gpu") is None or item.get_closest_marker("changes_env") is not None:
+        return
+    if os.environ.get("JTK_DEVICE_IS_ORACLE") or os.environ.get("JTK_NO_PREFETCH"):
+        return
+    import prefetch
+    if prefetch._pool is not None:
+        return
+    from jtk_amd import ffi
+    try:
+        if ffi.lib().jtk_lc_device_ok(0) != 1:
+            return
+    except Exception:
+        return
+    prefetch.install()
+    prefetch.start(getattr(item.config, "_jtk_selected", None))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if "prefetch" in sys.modules:
+        sys.modules["prefetch"].stop()
 
 
 @pytest.fixture(scope="session")

@@ -123,6 +123,52 @@ def random_feature_problem(rng, n, dim, k_true):
     return x, vt, lab
 
 
+def feature_inputs(specs, seed):
+    """the feature-level problems of a list of (n_reads, dim, k_true, copy_num): jtk_lc_feature_chunk_t records, the matrices and
+    variant types back to back, the posterior stride, the read count, the planted labels"""
+    from jtk_amd import ffi
+    rng = np.random.default_rng(seed)
+    chunks = np.zeros(len(specs), dtype=ffi.FEATURE_CHUNK_DT)
+    var, vts, truth = [], [], []
+    voff = vtoff = rfirst = 0
+    for i, (n, dim, k_true, copy_num) in enumerate(specs):
+        x, vt, lab = random_feature_problem(rng, n, dim, k_true)
+        chunks[i] = (1000 + 17 * i, copy_num, n, dim, 0, voff, vtoff, rfirst, n / copy_num)
+        var.append(x.ravel())
+        vts.append(vt.ravel())
+        truth.append(lab)
+        voff += n * dim
+        vtoff += dim
+        rfirst += n
+    return chunks, np.concatenate(var), np.concatenate(vts).astype(np.uint32), max(s[3] for s in specs), rfirst, truth
+
+
+# ---- inputs of the suite's slowest device calls (single chain workgroups that run for a minute or two): the tests build them
+#      here so that tests/prefetch.py can start the same calls on other host threads while the rest of the suite runs
+RECURSIVE_SPLIT_CASES = [(600, 10, 2e-2, 8, 9), (800, 10, 2e-2, 10, 12), (400, 33, 2e-2, 8, 8)]   # (last: 264 reads, LDS-table chain)
+LARGE_PILEUP_SPECS = ([(256, 4, 2, 2), (300, 6, 3, 3), (511, 3, 2, 2), (255, 4, 3, 3), (540, 6, 4, 4), (1023, 3, 2, 2)], 19)
+HUGE_PILEUP_SPECS = ([(1024, 3, 2, 2), (60, 2, 2, 2), (1100, 4, 3, 3)], 23)
+
+
+def recursive_split_inputs(tmpl_len, rph, div, n_haps, copy_num):
+    b, cfg, p = small_batch(config="ont_4copy", n_chunks=4, tmpl_len=tmpl_len, reads_per_hap=rph,
+                            n_haps=n_haps, copy_num=copy_num, divergence=div, min_variants=3)
+    b.chunks["copy_num"][3] = 2
+    return b, p
+
+
+def full_path_1100_inputs():
+    b, cfg, p = small_batch(config="ont_diploid", n_chunks=1, tmpl_len=300, reads_per_hap=550, first=91, min_variants=1)
+    return b, p
+
+
+def pileup_540_inputs():
+    cfg_big = dict(synth.CONFIGS["ont_4copy"], tmpl_len=260, reads_per_hap=60, n_haps=9, copy_num=9, divergence=2.5e-2)
+    cfg_small = dict(synth.CONFIGS["ont_diploid"], tmpl_len=260, reads_per_hap=12)
+    b = jb.pack([synth.make_pileup(4200, cfg_small), synth.make_pileup(4100, cfg_big, min_variants=3)])
+    return b, jb.default_params(haploid_coverage=60.0, band_frac=cfg_big["band_frac"])
+
+
 def correction_problem(seed, n_chunks=6, n_reads=40, window=(3, 6), noise=1.2, flat=0.15, wrong=0.0, single=(), cluster_dt=None, node_dt=None):
     """A small DataSet as phmm_likelihood_correction.rs sees it: two haplotypes over a chain of chunks (ids 0..n_chunks-1),
     each read covering a window of consecutive chunks on either strand; every node carries ln-posteriors over its chunk's

@@ -50,6 +50,7 @@ def test_correction_matches_oracle(seed, kw):
     assert np.array_equal(och, gch)
 
 
+@pytest.mark.changes_env
 def test_correction_in_several_device_batches_matches_oracle(monkeypatch):
     """jtk_lc_correct_clustering runs its jobs through the device in batches bounded by the bytes of their similarity matrices
     (a genome-scale DataSet must not need all of them at once): with a budget of one matrix per batch the result is unchanged"""

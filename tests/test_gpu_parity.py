@@ -180,22 +180,7 @@ def random_feature_problem(rng, n, dim, k_true, cid=0, copy_num=2):
 
 
 def run_features_both(p, specs, seed):
-    rng = np.random.default_rng(seed)
-    chunks = np.zeros(len(specs), dtype=ffi.FEATURE_CHUNK_DT)
-    var, vts, truth = [], [], []
-    voff = vtoff = rfirst = 0
-    for i, (n, dim, k_true, copy_num) in enumerate(specs):
-        x, vt, lab = random_feature_problem(rng, n, dim, k_true, i, copy_num)
-        chunks[i] = (1000 + 17 * i, copy_num, n, dim, 0, voff, vtoff, rfirst, n / copy_num)
-        var.append(x.ravel())
-        vts.append(vt.ravel())
-        truth.append(lab)
-        voff += n * dim
-        vtoff += dim
-        rfirst += n
-    var = np.concatenate(var)
-    vts = np.concatenate(vts).astype(np.uint32)
-    stride = max(s[3] for s in specs)
+    chunks, var, vts, stride, rfirst, truth = helpers.feature_inputs(specs, seed)
     ora = helpers.oracle_cluster_features(helpers.oracle_params(p), chunks, var, vts, stride, rfirst)   # (large cases: a fixture)
     assert ora["rc"] == 0
     dev = api.cluster_features(p, chunks, var, vts, stride)
@@ -284,16 +269,13 @@ def test_edge_cases(lib):
     assert np.abs(dev["log_post"] - ora["log_post"]).max() < TOL
 
 
-@pytest.mark.parametrize("tmpl_len,rph,div,n_haps,copy_num", [(600, 10, 2e-2, 8, 9), (800, 10, 2e-2, 10, 12),
-                                                              (400, 33, 2e-2, 8, 8)])   # 264 reads: LDS-table chain
+@pytest.mark.parametrize("tmpl_len,rph,div,n_haps,copy_num", helpers.RECURSIVE_SPLIT_CASES)
 def test_recursive_split_matches_oracle(lib, tmpl_len, rph, div, n_haps, copy_num):
     """copy_num >= 8: clustering_recursive's split branch (mod.rs:138-189) -- a 4-way clustering, then per group a
     consensus polish and a clustering with the group's share of the copies, all on one RNG stream per chunk;
     copy_num 12 nests a second split.  The last chunk keeps its reads but is declared diploid, so that split and
     plain chunks share a batch."""
-    b, cfg, p = helpers.small_batch(config="ont_4copy", n_chunks=4, tmpl_len=tmpl_len, reads_per_hap=rph,
-                                    n_haps=n_haps, copy_num=copy_num, divergence=div, min_variants=3)
-    b.chunks["copy_num"][3] = 2
+    b, p = helpers.recursive_split_inputs(tmpl_len, rph, div, n_haps, copy_num)
     ora = O.cluster_chunks(helpers.oracle_params(p), b)
     assert ora["rc"] == 0
     assert ora["result"]["cluster_num"][:3].max() > 4, "the inputs must exercise the merge of sub-clusterings"
@@ -348,6 +330,7 @@ def test_concurrent_sessions_match_one_shot(lib):
         s.close()
 
 
+@pytest.mark.changes_env
 @pytest.mark.parametrize("n_slices", [2, 3, 7])
 def test_one_shot_slicing_does_not_change_results(lib, monkeypatch, n_slices):
     """jtk_lc_cluster_chunks runs a large batch as up to four slices on their own streams and host threads (>= 500
@@ -406,8 +389,8 @@ def test_large_pileups_match_oracle(lib):
     per-read and per-size tables in LDS instead of registers; 256 and 1023 (10-bit read indices) are the edges of that
     mode, 540 reads is a 9-copy pile-up at 60x"""
     p = jb.default_params(haploid_coverage=40.0)
-    specs = [(256, 4, 2, 2), (300, 6, 3, 3), (511, 3, 2, 2), (255, 4, 3, 3), (540, 6, 4, 4), (1023, 3, 2, 2)]
-    dev, ora, truth = run_features_both(p, specs, seed=19)
+    specs, seed = helpers.LARGE_PILEUP_SPECS
+    dev, ora, truth = run_features_both(p, specs, seed=seed)
     assert np.array_equal(dev["result"]["status"], np.zeros(len(specs), np.int32))
     assert np.array_equal(dev["label"], ora["label"])
     assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])
@@ -420,8 +403,8 @@ def test_pileups_beyond_1023_reads_match_oracle(lib):
     table-driven chains) or a CU's LDS, a pile-up runs in mcmc_kernel_huge: work area in global memory, one proposal per
     iteration -- slow, and bit-exact: 1,024 and 1,100 reads, K = 2 and 3, next to an ordinary pile-up in the same call"""
     p = jb.default_params(haploid_coverage=40.0)
-    specs = [(1024, 3, 2, 2), (60, 2, 2, 2), (1100, 4, 3, 3)]
-    dev, ora, truth = run_features_both(p, specs, seed=23)
+    specs, seed = helpers.HUGE_PILEUP_SPECS
+    dev, ora, truth = run_features_both(p, specs, seed=seed)
     assert np.array_equal(dev["result"]["status"], np.zeros(len(specs), np.int32))
     assert np.array_equal(dev["label"], ora["label"])
     assert np.array_equal(dev["result"]["cluster_num"], ora["result"]["cluster_num"])

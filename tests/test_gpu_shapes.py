@@ -241,7 +241,7 @@ def test_full_path_pileup_of_1100_reads_matches_oracle(lib):
     """the whole stage path on a pile-up deeper than the table-driven chains take (1,100 reads x 300 bp, diploid): polish,
     tables, filter on the ordinary kernels, the chain in mcmc_kernel_huge (session class 2) -- no JTK_ERR_UNSUPPORTED for a read
     count any more"""
-    b, cfg, p = helpers.small_batch(config="ont_diploid", n_chunks=1, tmpl_len=300, reads_per_hap=550, first=91, min_variants=1)
+    b, p = helpers.full_path_1100_inputs()
     assert int(b.chunks["n_reads"][0]) == 1100
     dev = api.cluster_chunks(p, b)
     ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
@@ -375,10 +375,7 @@ def test_heterogeneous_batch_keeps_class_0_below_80_kib(lib):
 def test_pileup_beyond_511_reads_matches_oracle(lib):
     """a 9-copy pile-up at 60x (540 reads) next to a diploid one: the big chunk's first pass (K = 4 on 540 reads) runs in the
     chain kernel's second launch class (LDS work area above 80 KiB), the diploid chunk in the first; both bit-exact"""
-    cfg_big = dict(synth.CONFIGS["ont_4copy"], tmpl_len=260, reads_per_hap=60, n_haps=9, copy_num=9, divergence=2.5e-2)
-    cfg_small = dict(synth.CONFIGS["ont_diploid"], tmpl_len=260, reads_per_hap=12)
-    b = jb.pack([synth.make_pileup(4200, cfg_small), synth.make_pileup(4100, cfg_big, min_variants=3)])
-    p = jb.default_params(haploid_coverage=60.0, band_frac=cfg_big["band_frac"])
+    b, p = helpers.pileup_540_inputs()
     assert int(b.chunks["n_reads"].max()) == 540
     ora = O.cluster_chunks(helpers.oracle_params(p), b, n_threads=2)
     assert ora["rc"] == 0
