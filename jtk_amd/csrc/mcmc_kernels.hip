@@ -1558,6 +1558,33 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
     gwindow_load(wd, rng, rng.pos, lane);
     uint32_t hopw = hop_words(wd);
     const uint32_t row_lane_addr = (uint32_t)(uintptr_t)data_l + (lane < D ? lane : 0u) * 8u;  // (the rejected steps' hand-issued loads)
+    // K <= 4 clusters of <= 16 columns (every BASELINE shape): during the quiet part of the chain the K sums of a column travel in
+    // ONE register, lane 16 c + d = cluster c / column d, so that a rejected step is one multiplication and two additions for all
+    // clusters, its factor picked per lane (two compares) instead of per cluster (four scalar instructions each).  The exact step
+    // and publish() keep their register per cluster: packed on the way into the first block after an event, unpacked before the
+    // next event (2 K ds_bpermute each way, against ~4,000 cycles of event).
+    const bool packable = K <= 4 && D <= 16u;
+    const uint32_t grp = lane >> 4, col16 = lane & 15u;
+    const uint32_t row_lane_addr_pk = (uint32_t)(uintptr_t)data_l + (col16 < D ? col16 : 0u) * 8u;
+    double tgp = 0.0;
+    bool is_packed = false;
+    auto pack_sums = [&]() {
+        tgp = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            const double v = __shfl(tg[c], (int)col16, 64);  // (lanes >= D of tg[c] hold +0)
+            tgp = grp == (uint32_t)c ? v : tgp;
+        }
+        is_packed = true;
+    };
+    auto unpack_sums = [&]() {
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            const double v = __shfl(tgp, (int)(16u * (uint32_t)c + col16), 64);
+            tg[c] = lane < D ? v : 0.0;
+        }
+        is_packed = false;
+    };
     auto row_of = [&](uint32_t hvv) -> double {  // the column values of the read a hop word names (lanes >= D: 0.0)
         uint32_t i = (hvv >> 8) & 1023u;
         i = i < n1 ? i : n1;  // a word that is not a proposal may hold anything
@@ -1590,11 +1617,20 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
             uint32_t budget = total - t;
             if (budget > 65536u - since_rebuild) budget = 65536u - since_rebuild;
             uint32_t done = 0;
-            auto rejected_step = [&](uint32_t hvv, double x) {
+            auto rejected_step = [&](uint32_t hvv, double x, auto use_packed) {
                 const uint32_t old = (hvv >> 21) & 7u, nw = (hvv >> 24) & 7u;
 #ifdef JTK_MCMC_STATS
                 bool st_res = false;
 #endif
+                if (decltype(use_packed)::value) {
+                    const uint32_t hi = grp == old ? 0xBFF00000u : (grp == nw ? 0x3FF00000u : 0u);
+                    const double mc = x * __hiloint2double((int)hi, 0);
+#ifdef JTK_MCMC_STATS
+                    TS_ADD(7, __ballot((tgp + mc) - mc != tgp) != 0ull ? 1 : 0);
+#endif
+                    tgp = (tgp + mc) - mc;
+                    return;
+                }
 #pragma unroll
                 for (int c = 0; c < K; c++) {
                     const uint32_t hi = (uint32_t)c == old ? 0xBFF00000u : ((uint32_t)c == nw ? 0x3FF00000u : 0u);
@@ -1612,35 +1648,53 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
             // lgkmcnt(0) in this loop -- i.e. for the row it has just asked for as well -- where "all but the youngest load"
             // (lgkmcnt(1): LDS loads return in order) is what hides the round trip.  No other LDS access happens between the
             // first load and the drain behind the loop; lanes >= D read column 0 and keep their zero sums ((0 + m) - m == +0).
-            auto row_issue = [&](uint32_t hvv) -> double {
-                uint32_t i = (hvv >> 8) & 1023u;
-                i = i < n1 ? i : n1;  // a word that is not a proposal may hold anything
+            auto row_issue = [&](uint32_t hvv, auto use_packed) -> double {
+                const uint32_t i = (hvv >> 8) & 1023u;  // (hop_words clamps the index of a position that is not a proposal)
                 double v;
-                asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(row_lane_addr + i * (D * 8u)));
+                asm volatile("ds_read_b64 %0, %1" : "=v"(v)
+                             : "v"((decltype(use_packed)::value ? row_lane_addr_pk : row_lane_addr) + i * (D * 8u)));
                 return v;
             };
-            double xa = row_issue(hv), xb;
-            for (;;) {
-                uint32_t pn = hv & 63u;
-                uint32_t hn = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)pn));
-                xb = row_issue(hn);
-                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xa));  // the older of the two rows in flight
-                rejected_step(hv, xa);
-                p = pn;
-                hv = hn;
-                done++;
-                if (!((hv & 192u) == 192u && done < budget)) break;
-                pn = hv & 63u;
-                hn = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)pn));
-                xa = row_issue(hn);
-                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xb));
-                rejected_step(hv, xb);
-                p = pn;
-                hv = hn;
-                done++;
-                if (!((hv & 192u) == 192u && done < budget)) break;
+            // A window holds at most 21 proposals (three draws each at least): with 24 steps of budget left -- always, but at
+            // the very end of a chain and once per 65,536 steps -- the block ends with the window and nothing counts steps
+            // against the budget (three scalar instructions per step less).
+            auto run_block = [&](auto watch_budget, auto use_packed) {
+                double xa = row_issue(hv, use_packed), xb;
+                for (;;) {
+                    uint32_t pn = hv & 63u;
+                    uint32_t hn = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)pn));
+                    xb = row_issue(hn, use_packed);
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xa));  // the older of the two rows in flight
+                    rejected_step(hv, xa, use_packed);
+                    p = pn;
+                    hv = hn;
+                    done++;
+                    if ((hv & 192u) != 192u) break;
+                    if (decltype(watch_budget)::value && done >= budget) break;
+                    pn = hv & 63u;
+                    hn = uni((uint32_t)__builtin_amdgcn_readlane((int)hopw, (int)pn));
+                    xa = row_issue(hn, use_packed);
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xb));
+                    rejected_step(hv, xb, use_packed);
+                    p = pn;
+                    hv = hn;
+                    done++;
+                    if ((hv & 192u) != 192u) break;
+                    if (decltype(watch_budget)::value && done >= budget) break;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa), "+v"(xb));  // the row fetched for a step that did not run
+            };
+            if (packable) {
+                if (!is_packed) pack_sums();
+                if (budget >= 24u)
+                    run_block(std::false_type(), std::true_type());
+                else
+                    run_block(std::true_type(), std::true_type());
+            } else if (budget >= 24u) {
+                run_block(std::false_type(), std::false_type());
+            } else {
+                run_block(std::true_type(), std::false_type());
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa), "+v"(xb));  // the row fetched for a step that did not run
             t += done;
             since_rebuild += done;
             TS_ADD(0, done);
@@ -1670,6 +1724,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
         }
         break;
         }
+        if (is_packed) unpack_sums();
         if (finished) break;
         uint32_t idx, pick, pos_v;
         bool reload = false;
