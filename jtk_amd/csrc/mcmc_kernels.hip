@@ -1375,15 +1375,9 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
         }
         return S;
     };
-    double sz0[K], szm[K], szp[K];
-    auto size_terms = [&](int c) {
-        const uint32_t x = (uint32_t)cl[c];
-        sz0[c] = size_lk(x);
-        szm[c] = x > 0 ? size_lk(x - 1) : 0.0;
-        szp[c] = x < n ? size_lk(x + 1) : 0.0;
-    };
-#pragma unroll
-    for (int c = 0; c < K; c++) size_terms(c);
+    // (the size terms of the K clusters -- size_to_lk of the size and of its two neighbours -- are looked up where they are
+    // used, in publish(): kept in registers across the chain they were 3 K wave-uniform doubles, i.e. 6 K of the ~100 scalar
+    // registers, and the chain's loop spilled scalars around every event)
     double lk = get_lk(tg, np, w, cl);
     double max = lk;
     // ---- thresholds (see the header comment).  Per-column constants first: the largest |x| and, per read, the columns
@@ -1418,6 +1412,14 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
         bool alloff = true, frag = false;
         double G = 0.0;
         uint32_t nr[K], pm[K];
+        double sz0[K], szm[K], szp[K];  // (the same value in every lane: LDS broadcast reads)
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            const uint32_t x = (uint32_t)cl[c];
+            sz0[c] = m.size_to_lk[x];
+            szm[c] = x > 0 ? m.size_to_lk[x - 1] : 0.0;
+            szp[c] = x < n ? m.size_to_lk[x + 1] : 0.0;
+        }
 #pragma unroll
         for (int c = 0; c < K; c++) {
             const bool pos = 0.0 < tg[c];
@@ -1784,7 +1786,6 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
                 np[c] = P[c];
                 w[c] = W[c];
                 cl[c] = ncl[c];
-                if ((uint32_t)c == old || (uint32_t)c == nw) size_terms(c);
             }
             if (lane == 0) m.assign[idx] = (uint8_t)nw;
             wsync();
