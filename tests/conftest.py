@@ -27,6 +27,8 @@ def pytest_runtest_setup(item):
     threads (tests/prefetch.py) and the tests that need them pick the results up."""
     if item.get_closest_marker("gpu") is None or item.get_closest_marker("changes_env") is not None:
         return
+    if os.path.basename(str(item.fspath)) == "test_bench_gpu.py":
+        return   # bench.py's child processes (up to eight ranks on this one GPU) get the device to themselves
     if os.environ.get("JTK_DEVICE_IS_ORACLE") or os.environ.get("JTK_NO_PREFETCH"):
         return
     import prefetch
