@@ -7,14 +7,19 @@ TAG=${1:-r05}
 O=gpurun_out
 if [ "${PROFILE:-1}" = "1" ]; then   # PROFILE=0: the profiles were taken already on these sources
 bash scripts/profile_bench.sh $TAG > $O/final_profile_$TAG.log 2>&1
-bash scripts/pmc_phmm.sh $TAG > $O/final_pmc_$TAG.log 2>&1
+# (PMC_PHMM=1: the pair-HMM issue counters as well -- six more rocprofv3 passes; phmm_sweep.hip / phmm_pair.hip / phmm_wide.hip did
+# not change in round 5, profiles/r04_pmc_issue_phmm.txt describes the kernels as they are)
+[ "${PMC_PHMM:-0}" = "1" ] && bash scripts/pmc_phmm.sh $TAG > $O/final_pmc_$TAG.log 2>&1
 fi
 cd ${GRAFT_REPO_ROOT:-/root/repo}
+# the bench lines below carry roofline.traffic from THIS profile (bench.py matches it by the hash of the kernel sources)
+[ -s $O/prof_traffic_$TAG.json ] && cp $O/prof_traffic_$TAG.json profiles/${TAG}_pmc_traffic.json
+# (the default line first: it is the one the driver repeats; the other configurations after it)
+timeout 1200 python3 bench.py --steps 20 --warmup 5 > $O/bench_${TAG}_final.json 2> $O/bench_${TAG}_final.err   # the driver's command
 timeout 1500 python3 bench.py --workload cfg4_ont_4copy_2500x160x2kbp --steps 1 --warmup 0 --no-e2e --no-cpu-baseline --no-shard8 > $O/bench_${TAG}_cfg4_2500.json 2> $O/bench_${TAG}_cfg4_2500.err
 timeout 600 python3 bench.py --workload cfg5_hifi_diploid_2500x40x2kbp --steps 8 --warmup 2 --no-e2e --no-cpu-baseline --no-shard8 > $O/bench_${TAG}_cfg5.json 2> $O/bench_${TAG}_cfg5.err
 timeout 600 python3 bench.py --workload cfg2_ont_diploid_500x60x2kbp --steps 8 --warmup 2 --no-e2e --no-cpu-baseline --no-shard8 > $O/bench_${TAG}_cfg2.json 2> $O/bench_${TAG}_cfg2.err
 timeout 600 python3 scripts/poisson_coverage_bench.py 500 > $O/poisson_$TAG.log 2>&1
-timeout 1200 python3 bench.py --steps 20 --warmup 5 > $O/bench_${TAG}_final.json 2> $O/bench_${TAG}_final.err   # the driver's command
 # One library, one set of numbers: a bench line whose lib_sha16 is not the hash of the library the committed rocprof / PMC profile was
 # taken on (gpurun_out/prof_libsha_$TAG.txt, written by profile_bench.sh) is set aside as .STALE -- it must not reach profiles/.
 python3 - "$TAG" <<'PY'

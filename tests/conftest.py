@@ -13,12 +13,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "changes_env: the test sets process environment variables (runs before tests/prefetch.py's threads start)")
 
 
+def _prefetching():
+    """JTK_PREFETCH=1 turns tests/prefetch.py on (off by default: see its header)."""
+    return os.environ.get("JTK_PREFETCH") == "1" and not os.environ.get("JTK_DEVICE_IS_ORACLE")
+
+
 @pytest.hookimpl(trylast=True)   # (after -m / -k have deselected)
 def pytest_collection_modifyitems(config, items):
-    # tests that setenv go first: the threads of tests/prefetch.py (whose library calls getenv) start after the last of them
-    first = [it for it in items if it.get_closest_marker("changes_env")]
-    if first:
-        items[:] = first + [it for it in items if not it.get_closest_marker("changes_env")]
+    if not _prefetching():
+        return   # the suite in its plain order, one device call at a time
+    # bench.py's multi-rank tests first, while this process has not touched the GPU (eight child processes beside a parent that
+    # holds device memory and hardware queues did not finish in 20 minutes); then the tests that setenv (the threads of
+    # tests/prefetch.py, whose library calls getenv, start after the last of them); then the rest
+    def rank(it):
+        if os.path.basename(str(it.fspath)) == "test_bench_gpu.py":
+            return 0
+        return 1 if it.get_closest_marker("changes_env") else 2
+    items[:] = sorted(items, key=rank)   # (stable: the order inside each group stays)
     config._jtk_selected = [it.nodeid for it in items]
 
 
@@ -29,7 +40,7 @@ def pytest_runtest_setup(item):
         return
     if os.path.basename(str(item.fspath)) == "test_bench_gpu.py":
         return   # bench.py's child processes (up to eight ranks on this one GPU) get the device to themselves
-    if os.environ.get("JTK_DEVICE_IS_ORACLE") or os.environ.get("JTK_NO_PREFETCH"):
+    if not _prefetching():
         return
     import prefetch
     if prefetch._pool is not None:

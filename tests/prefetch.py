@@ -6,7 +6,13 @@ concurrent callers (own stream and workspaces per call; tests/test_gpu_parity.py
 calls are started on a small thread pool as soon as the tests that change the process environment have run (setenv must not overlap
 another thread's getenv), and the test that needs a result finds it -- by CONTENT: the key is the sha256 of everything the call was
 given, so a test whose inputs differ from what was started here simply makes its own call.  The result a test receives is the
-return value of the same jtk_amd.api function it would have called itself."""
+return value of the same jtk_amd.api function it would have called itself.
+
+OFF unless JTK_PREFETCH=1 (tests/conftest.py).  Measured with it on: the 24 K-way / chain cases of the suite (five of the seven calls
+among them) in 240 s, every case green, the prefetched calls gone from the list of slowest tests.  The whole suite has not been timed
+with it: two attempts of round 5 ended in bench.py's eight-rank test, which does not finish when the pytest process has touched the
+GPU before it starts its eight child processes (prefetch threads running, or merely four GPU tests run first) -- with the switch on,
+the bench tests therefore run first.  The default is the plain order the driver's run has always used."""
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
