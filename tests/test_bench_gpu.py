@@ -25,6 +25,21 @@ def last_json(stdout):
     return json.loads([l for l in stdout.splitlines() if l.startswith("{")][-1])
 
 
+def run_bounded(cmd, env, timeout):
+    """subprocess.run(capture_output=True, text=True) in a process group of its own: when the limit passes, the launcher AND its
+    ranks are killed (ranks left behind would keep their share of the GPU for the rest of the suite) and the test fails with what
+    the ranks printed."""
+    import signal
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        pytest.fail("%s ... did not finish in %d s:\n%s" % (" ".join(cmd[:6]), timeout, err[-4000:]))
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+
+
 def test_one_rank_line_has_the_contract_fields(jtk_lib):
     assert jtk_lib.jtk_lc_device_ok(0) == 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--chunks", "32", "--steps", "2", "--warmup", "1",
@@ -96,13 +111,13 @@ def test_eight_rank_run_of_the_full_dataset_matches_the_one_rank_run(jtk_lib, tm
     api.trim_cache(0)  # this (pytest) process may still hold pooled workspaces of earlier tests: nine more processes follow
     env = dict(os.environ, JTK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", JTK_LC_POOL_GB="16")
     common = ["--steps", "1", "--warmup", "0", "--no-e2e", "--no-cpu-baseline", "--no-shard8", "--no-weak-probe"]
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-labels", str(tmp_path / "one.npz")]
-                         + common, capture_output=True, text=True, cwd=ROOT, env=env, timeout=1500)
+    # (the two runs take under a minute together when nothing else holds device memory: eight ranks map 8 x ~30 GB of the 288)
+    one = run_bounded([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-labels", str(tmp_path / "one.npz")]
+                      + common, env, 400)
     assert one.returncode == 0, one.stderr[-3000:]
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
-                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "8", "--streams", "2", "--dump-labels", str(tmp_path / "eight.npz")] + common,
-                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=1500)
+    r = run_bounded([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                     "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                     "--gpus", "8", "--streams", "2", "--dump-labels", str(tmp_path / "eight.npz")] + common, env, 400)
     assert r.returncode == 0, "8-rank run failed:\n" + r.stderr[-6000:]
     line = last_json(r.stdout)
     assert line["n_gpus"] == 8 and line["config"]["chunks_total"] == 2500 and line["gather_ok"]
