@@ -1,4 +1,6 @@
 #!/bin/bash
+# (rounds 1-4: the ring size was the compile-time JTK_MCMC_SEG_LOG; since round 5 it is a launch parameter -- JTK_SEG_LOG_LIGHT /
+# JTK_SEG_LOG_GENERAL in mcmc_kernels.hip, one jump table per length -- and this probe needs those two edited instead)
 # Diagnostic (GPU box): the chain kernel's ring size (JTK_MCMC_SEG_LOG: 5 = 4096 draws / 70 KB of LDS per workgroup,
 # 4 = 2048 draws / 24 KB of ring, 3 = 1024 draws / 12 KB) against parity, the serial step and the 4-in-flight throughput.
 set -u
