@@ -86,7 +86,16 @@ def _oracle_fixtures():
         oracle_ffi.cluster_chunks = helpers.cached_cluster_chunks(oracle_ffi.cluster_chunks)
         oracle_ffi.cluster_chunks._cached = True
     if os.environ.get("JTK_DEVICE_IS_ORACLE"):
-        from jtk_amd import api
+        from jtk_amd import api, ffi
+        # a generator switch for machines WITHOUT a GPU: on a box that has one it would turn every large parity test into
+        # oracle-vs-oracle and report green, so it is refused there
+        try:
+            has_device = ffi.lib().jtk_lc_device_ok(0) == 1
+        except Exception:
+            has_device = False
+        if has_device:
+            pytest.exit("JTK_DEVICE_IS_ORACLE is set on a machine with a gfx950 device: the GPU tests would compare the oracle with "
+                        "itself.  Unset it (it exists for tests/golden/make_oracle_cache.py on CPU-only machines).", returncode=3)
 
         def dev_chunks(params, batch, device=0, raise_on_chunk_failure=True, devices=None):
             out = dict(oracle_ffi.cluster_chunks(helpers.oracle_params(params), batch, skip_polish=False))

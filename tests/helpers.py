@@ -42,16 +42,42 @@ def bits(a):
 # ---- the oracle's answers for the LARGE cases, as committed fixtures -------------------------------------------------------
 # The oracle needs about a second per 60-read chunk and thread (minutes for a 540-read pile-up): run inside every GPU pass it was
 # most of the suite's 820 s.  Its cluster_chunks / cluster_features results are therefore looked up in tests/golden/oracle/ first,
-# by CONTENT: the file name is the sha256 of everything the oracle was given (inputs, parameters, flags), so a fixture can only ever
-# answer the question it was made for, and a test whose inputs change simply runs the oracle live again.  The small cases have no
+# by CONTENT: the file name is the sha256 of the oracle's own sources (oracle_sources_sha) and of everything the oracle was given
+# (inputs, parameters, flags), so a fixture can only ever answer the question it was made for BY THE ORACLE THAT IS IN THE TREE, and a
+# test whose inputs change -- or an oracle that changes -- simply runs the oracle live again.  tests/test_oracle_fixtures.py re-runs
+# the live oracle on two fixtures a day (CPU) and compares.  The small cases have no
 # fixture: one oracle-in-the-loop case per kernel family stays in every pass.  tests/golden/make_oracle_cache.py regenerates the
 # directory (it runs the listed tests with the oracle standing in for the device: no GPU needed).
 ORACLE_CACHE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle")
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_oracle_sha = None
+
+
+def oracle_sources_sha():
+    """sha256 over everything that decides what the oracle answers: oracle/*.c, oracle/jtk_oracle.h, oracle/Makefile (its flags)
+    and the arithmetic headers it shares with the device (include/jtk_math.h, include/jtk_eigen.h) -- names and contents.  It is
+    part of every fixture's key (round 6; before, a fixture was keyed on the oracle's INPUTS only and a later fix to the oracle
+    would have left the large GPU tests green against the old oracle's answers): change the oracle and every fixture misses,
+    the tests fall back to the live oracle, and tests/golden/make_oracle_cache.py regenerates the directory."""
+    global _oracle_sha
+    if _oracle_sha is None:
+        import hashlib
+        od = os.path.join(_ROOT, "oracle")
+        files = sorted(os.path.join(od, f) for f in os.listdir(od) if f.endswith(".c") or f in ("jtk_oracle.h", "Makefile"))
+        files += [os.path.join(_ROOT, "include", f) for f in ("jtk_math.h", "jtk_eigen.h")]
+        h = hashlib.sha256()
+        for f in files:
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+        _oracle_sha = h.hexdigest()
+    return _oracle_sha
 
 
 def _cache_key(parts):
     import hashlib
     h = hashlib.sha256()
+    h.update(oracle_sources_sha().encode())
     for a in parts:
         h.update(a if isinstance(a, (bytes, bytearray)) else np.ascontiguousarray(a).tobytes())
     return h.hexdigest()[:32]
@@ -72,7 +98,7 @@ def oracle_cache_put(key, out, fields):
     np.savez_compressed(os.path.join(ORACLE_CACHE_DIR, key + ".npz"), rc=np.array([int(out.get("rc", 0))]),
                         **{k: out[k] for k in fields})
     with open(os.path.join(ORACLE_CACHE_DIR, "INDEX.txt"), "a") as fh:
-        fh.write("%s %s\n" % (key, os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]))
+        fh.write("%s %s oracle=%s\n" % (key, os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], oracle_sources_sha()[:16]))
 
 
 def cached_cluster_chunks(orig):
@@ -92,6 +118,7 @@ def cached_cluster_chunks(orig):
             fields += ("ops_out", "ops_out_off")
         oracle_cache_put(key, dict(out, cons=out["cons"][:n], ops_out=out["ops_out"][:m]), fields)
         return out
+    wrapper._orig = orig   # (tests/test_oracle_fixtures.py runs the live oracle beside the fixture)
     return wrapper
 
 
@@ -148,6 +175,26 @@ def feature_inputs(specs, seed):
 RECURSIVE_SPLIT_CASES = [(600, 10, 2e-2, 8, 9), (800, 10, 2e-2, 10, 12), (400, 33, 2e-2, 8, 8)]   # (last: 264 reads, LDS-table chain)
 LARGE_PILEUP_SPECS = ([(256, 4, 2, 2), (300, 6, 3, 3), (511, 3, 2, 2), (255, 4, 3, 3), (540, 6, 4, 4), (1023, 3, 2, 2)], 19)
 HUGE_PILEUP_SPECS = ([(1024, 3, 2, 2), (60, 2, 2, 2), (1100, 4, 3, 3)], 23)
+
+
+def shape_sweep_inputs(only=None):
+    """the ten batches of test_random_shape_sweep_matches_oracle (a fixed-seed slice of scripts/parity_sweep_full.py): random
+    configuration, template length, depth and chunk ids; every fifth batch goes through clustering_recursive's split.  Yields
+    (iteration, batch, params); `only` = the iterations wanted (the generator state is advanced for the others all the same)."""
+    rng = np.random.default_rng(77)
+    for it in range(10):
+        config = str(rng.choice(["ont_diploid", "ont_diploid", "ont_noisy", "hifi_diploid", "ont_4copy"]))
+        L = int(rng.integers(130, 1400))
+        rph = int(rng.integers(3, 12))
+        first = int(rng.integers(0, 1 << 40))
+        kw = {}
+        if it % 5 == 4:
+            config, L, rph = "ont_4copy", int(rng.integers(400, 900)), int(rng.integers(6, 12))
+            kw = dict(n_haps=int(rng.integers(6, 11)), copy_num=int(rng.integers(8, 15)), divergence=2e-2, min_variants=3)
+        if only is not None and it not in only:
+            continue
+        b, cfg, p = small_batch(config=config, n_chunks=3, tmpl_len=L, reads_per_hap=rph, first=first, **kw)
+        yield it, b, p
 
 
 def recursive_split_inputs(tmpl_len, rph, div, n_haps, copy_num):

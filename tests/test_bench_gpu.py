@@ -81,7 +81,8 @@ def test_two_rank_strong_scaling_path(jtk_lib):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--chunks", "24", "--steps", "2", "--warmup", "1", "--streams", "2", "--no-e2e"],
+                        "--gpus", "2", "--chunks", "24", "--steps", "2", "--warmup", "1", "--streams", "2", "--no-e2e",
+                        "--weak-probe"],
                        capture_output=True, text=True, cwd=ROOT, env=env, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     line = last_json(r.stdout)

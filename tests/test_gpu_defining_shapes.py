@@ -63,6 +63,36 @@ def test_cfg3_refit_golden_32_chunks(jtk_lib):
     assert (g["result"]["n_variants"] >= 1).sum() >= 16   # the refitted model does let columns through
 
 
+def test_cfg5_golden_32_chunks(jtk_lib):
+    """tests/golden/cfg5_32.npz (made by the oracle, tests/golden/make_cfg5_32.py): BASELINE cfg 5 -- HiFi reads, band radius 10,
+    the configuration that runs on phmm_pair_kernel (two reads per wave) -- with no oracle in the loop: labels, k, score and
+    posterior bits, consensus AND the re-threaded ops (the next round's band follows them)"""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_cfg5_32 as mk
+    g = np.load(os.path.join(HERE, "golden", "cfg5_32.npz"))
+    b, cfg, p = mk.make_inputs()
+    assert mk.inputs_digest(b) == str(g["inputs_sha256"][0]), "the generator no longer produces the golden's inputs"
+    assert int(b.chunks["n_reads"][0]) == 40 and p.band_frac == 0.01
+    dev = api.cluster_chunks(p, b)
+    check_equal(dev, dict(result=g["result"], label=g["label"], log_post=g["log_post"], cons=g["cons"], cons_off=g["cons_off"]), b)
+    m = int(g["ops_out_off"][-1])
+    assert np.array_equal(dev["ops_out_off"], g["ops_out_off"]) and np.array_equal(dev["ops_out"][:m], g["ops_out"])
+    assert (g["result"]["polish_rounds"] >= 2).sum() >= 8   # templates that were edited, i.e. bands that moved
+
+
+def test_32_more_chunks_of_cfg5_match_the_oracle(jtk_lib, oracle):
+    """32 other cfg-5 pile-ups with the live oracle in the loop (RNG streams, error patterns and band paths the golden does not hold)"""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_cfg5_32 as mk
+    b, cfg, p = mk.make_inputs(first=5400, count=32)
+    dev = api.cluster_chunks(p, b)
+    ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
+    assert ora["rc"] == 0
+    check_equal(dev, ora, b)
+    m = int(ora["ops_out_off"][-1])
+    assert np.array_equal(dev["ops_out_off"], ora["ops_out_off"]) and np.array_equal(dev["ops_out"][:m], ora["ops_out"][:m])
+
+
 def test_refit_stage_matches_the_oracle(jtk_lib, oracle):
     """the same stage (refit + gains + clustering) with the oracle in the loop, on sixteen other chunks of cfg 3: RNG streams and
     band paths the golden does not hold; parameters from the device's refit, oracle run on exactly those"""

@@ -96,17 +96,7 @@ def test_headline_shape_random_ids_match_oracle(lib):
 def test_random_shape_sweep_matches_oracle(lib):
     """a fixed-seed slice of scripts/parity_sweep_full.py: random configuration, template length, depth and chunk ids;
     every fifth batch goes through clustering_recursive's split"""
-    rng = np.random.default_rng(77)
-    for it in range(10):
-        config = str(rng.choice(["ont_diploid", "ont_diploid", "ont_noisy", "hifi_diploid", "ont_4copy"]))
-        L = int(rng.integers(130, 1400))
-        rph = int(rng.integers(3, 12))
-        first = int(rng.integers(0, 1 << 40))
-        kw = {}
-        if it % 5 == 4:
-            config, L, rph = "ont_4copy", int(rng.integers(400, 900)), int(rng.integers(6, 12))
-            kw = dict(n_haps=int(rng.integers(6, 11)), copy_num=int(rng.integers(8, 15)), divergence=2e-2, min_variants=3)
-        b, cfg, p = helpers.small_batch(config=config, n_chunks=3, tmpl_len=L, reads_per_hap=rph, first=first, **kw)
+    for it, b, p in helpers.shape_sweep_inputs():
         dev = api.cluster_chunks(p, b, raise_on_chunk_failure=False)
         ora = O.cluster_chunks(helpers.oracle_params(p), b, skip_polish=False)
         assert_full_parity(dev, ora, b)
