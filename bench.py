@@ -261,7 +261,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the one-shot (host buffers in, host buffers out) timing")
     ap.add_argument("--no-shard8", action="store_true", help="skip the measurement of one rank's share of an 8-GPU run (N = 1 only)")
-    ap.add_argument("--no-weak-probe", action="store_true", help="N > 1: skip the weak-scaling figure taken after the timed region")
+    ap.add_argument("--weak-probe", action="store_true",
+                    help="N > 1: also take a weak-scaling figure after the strong line is safe (opt-in since round 6: it builds a "
+                         "second set of full-size sessions per rank)")
+    ap.add_argument("--no-weak-probe", action="store_true", help="(accepted for older command lines; the probe is off by default)")
+    ap.add_argument("--fetch", default="all", choices=("all", "results"),
+                    help="what a step copies to the host: all = labels, posteriors, records, consensus AND re-threaded ops (every "
+                         "output SURVEY 8(d)'s byte formula counts; default since round 6), results = without consensus / ops")
     ap.add_argument("--dump-labels", default="", help="rank 0 writes the whole job's labels, cluster numbers and scores in chunk-id "
                                                       "order to this .npz (tests compare an N-rank run with the 1-rank run)")
     args = ap.parse_args()
@@ -427,6 +433,7 @@ def main():
     ktime = {n: 0.0 for n in ffi.KERNEL_NAMES}
     klaunch = {n: 0 for n in ffi.KERNEL_NAMES}
     state = dict(dev_ms=0.0, gathered=None, last=None)
+    fetch_bufs = [None] * n_streams   # a slice's output arrays, allocated by its first fetch and overwritten by the later ones
 
     def run_steps(n_steps, timed, serial=False):
         """n_steps passes over the shard.  serial: the slices run one after another (kernel breakdown pass)."""
@@ -439,8 +446,13 @@ def main():
                 for s in range(n_steps):
                     sessions[i].run(skip_polish=False)   # returns when the device has finished this slice's pass
                     t = api.last_timing()                # thread-local: the pass this thread just ran
-                    out = sessions[i].fetch_results()    # labels, posteriors, k, score -> host (inside the step)
-                    done.put((s, i, t, out))
+                    if args.fetch == "all":              # every output of the drop-in call -> host (inside the step)
+                        fetch_bufs[i] = out = sessions[i].fetch(out=fetch_bufs[i])
+                    else:                                # labels, posteriors, k, score only (rounds 1-5)
+                        out = sessions[i].fetch_results()
+                    done.put((s, i, t, dict(label=out["label"].copy(), log_post=out["log_post"].copy(), result=out["result"].copy(),
+                                            cons_bytes=int(out["cons_off"][-1]) if "cons_off" in out else 0,
+                                            ops_bytes=int(out["ops_out_off"][-1]) if "ops_out_off" in out else 0)))
             except BaseException as e:  # noqa: BLE001 -- handed to the main thread
                 done.put((-1, i, e, None))
 
@@ -468,7 +480,8 @@ def main():
                 del pending[s]
                 merged = dict(label=np.concatenate([o["label"] for o in outs]),
                               log_post=np.concatenate([o["log_post"] for o in outs]),
-                              result=np.concatenate([o["result"] for o in outs]))
+                              result=np.concatenate([o["result"] for o in outs]),
+                              cons_bytes=sum(o["cons_bytes"] for o in outs), ops_bytes=sum(o["ops_bytes"] for o in outs))
                 state["last"] = merged
                 if gather is not None:                   # the only exchange of the path: one all-gather per step
                     state["gathered"] = gather.gather(merged["label"], merged["log_post"],
@@ -613,7 +626,12 @@ def main():
                             copy_num=int(cfg["copy_num"]), band_frac=cfg["band_frac"],
                             sharding=(f"{args.scaling}: chunks dealt LPT to {world} ranks, one all-gather of "
                                       "(label, log_post, k, score) per step over RCCL") if world > 1 else "1 gpu",
-                            slices_in_flight=n_streams, step="one pass over the dataset incl. fetch of the results"),
+                            slices_in_flight=n_streams,
+                            step=("one pass over the dataset incl. the copy of EVERY output to the host: labels, posteriors, k, score, "
+                                  "consensus and re-threaded ops" if args.fetch == "all" else
+                                  "one pass over the dataset incl. fetch of labels, posteriors, k, score (no consensus / ops)"),
+                            fetched_bytes_per_step=dict(consensus=int(out.get("cons_bytes", 0)), ops=int(out.get("ops_bytes", 0)),
+                                                        labels=int(out["label"].nbytes), log_post=int(out["log_post"].nbytes))),
                 roofline=roofline, slice_pass_latency_ms=overl_slice_ms,
                 serial_step_agrees=steps_agree, chunks_ok=ok, lib_sha16=sha,
                 mean_polish_rounds=float(out["result"]["polish_rounds"].mean()),
@@ -643,43 +661,72 @@ def main():
     #      shard's slowest chain; a data set that grows with the machine has no such term.  Every rank
     #      therefore also times a full-size private share: its own shard repeated N times (the same mix of pile-ups, 2,500
     #      chunks per GPU; nothing new to synthesise), same step, no gather.
-    if world > 1 and args.scaling == "strong" and not args.no_weak_probe:
-        wb = batch.subset(np.tile(np.arange(batch.n_chunks), world))
-        nw = max(1, min(args.streams, wb.n_chunks))
-        bw = [round(i * wb.n_chunks / nw) for i in range(nw + 1)]
-        sess_w = [api.Session(params, wb.subset(range(bw[i], bw[i + 1])), device=local_rank) for i in range(nw)]
+    if world > 1 and args.scaling == "strong" and args.weak_probe and not args.no_weak_probe:
+        # The strong-scaling line above is complete; nothing here may lose it.  Every rank says whether it could build its sessions
+        # BEFORE the first timed barrier (an all-reduced flag: one rank out of memory must not leave the others waiting in a
+        # collective), and any exception becomes line["weak_probe"] = {"error": ...}.
+        sess_w = []
+        try:
+            api.trim_cache(local_rank)   # the strong run's workspaces may still sit in the block pool
+            ok_w, err_w = 1.0, None
+            try:
+                wb = batch.subset(np.tile(np.arange(batch.n_chunks), world))
+                nw = max(1, min(args.streams, wb.n_chunks))
+                bw = [round(i * wb.n_chunks / nw) for i in range(nw + 1)]
+                sess_w = [api.Session(params, wb.subset(range(bw[i], bw[i + 1])), device=local_rank) for i in range(nw)]
+            except Exception as e:  # noqa: BLE001
+                ok_w, err_w = 0.0, repr(e)
+            flag = torch.tensor([ok_w], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) < 1.0:
+                line["weak_probe"] = dict(error=err_w or "another rank could not build its sessions")
+            else:
+                def run_w(k):
+                    errs = []
 
-        def run_w(k):
-            def w(i):
-                for _ in range(k):
-                    sess_w[i].run(skip_polish=False)
-                    sess_w[i].fetch_results()
-            ths = [threading.Thread(target=w, args=(i,)) for i in range(nw)]
-            for th in ths:
-                th.start()
-            for th in ths:
-                th.join()
+                    def w(i):
+                        try:
+                            for _ in range(k):
+                                sess_w[i].run(skip_polish=False)
+                                sess_w[i].fetch_results()
+                        except Exception as e:  # noqa: BLE001
+                            errs.append(repr(e))
+                    ths = [threading.Thread(target=w, args=(i,)) for i in range(nw)]
+                    for th in ths:
+                        th.start()
+                    for th in ths:
+                        th.join()
+                    return errs
 
-        steps_w = max(1, min(args.steps, 3))
-        run_w(1)
-        barrier()
-        tw = time.perf_counter()
-        run_w(steps_w)
-        barrier()
-        el_w = time.perf_counter() - tw
-        tt = torch.tensor([el_w, float(wb.n_chunks)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        mx = tt.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tt.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        line["weak_probe"] = dict(
-            chunks_per_gpu=int(wb.n_chunks), steps=steps_w, ms_per_step=float(mx[0].item()) / steps_w * 1e3,
-            chunks_per_s=float(sm[1].item()) * steps_w / float(mx[0].item()),
-            note="weak scaling beside the strong figure: every rank's own shard repeated n_gpus times (2,500 chunks per GPU, the "
-                 "same mix of pile-ups), same step without the gather, max over ranks; value / this = what the tail of the "
-                 "fixed data set costs at this N")
+                steps_w = max(1, min(args.steps, 3))
+                errs = run_w(1)
+                barrier()
+                tw = time.perf_counter()
+                errs += run_w(steps_w)
+                barrier()
+                el_w = time.perf_counter() - tw
+                tt = torch.tensor([el_w, float(wb.n_chunks), float(len(errs))], dtype=torch.float64,
+                                  device="cuda" if backend == "nccl" else "cpu")
+                mx = tt.clone()
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                sm = tt.clone()
+                dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+                if float(sm[2].item()) > 0:
+                    line["weak_probe"] = dict(error="; ".join(errs) or "a step failed on another rank")
+                else:
+                    line["weak_probe"] = dict(
+                        chunks_per_gpu=int(wb.n_chunks), steps=steps_w, ms_per_step=float(mx[0].item()) / steps_w * 1e3,
+                        chunks_per_s=float(sm[1].item()) * steps_w / float(mx[0].item()),
+                        note="weak scaling beside the strong figure: every rank's own shard repeated n_gpus times (2,500 chunks per "
+                             "GPU, the same mix of pile-ups), same step without the gather, max over ranks; value / this = what the "
+                             "tail of the fixed data set costs at this N")
+        except Exception as e:  # noqa: BLE001 -- e.g. a collective that failed: the strong line still goes out
+            line["weak_probe"] = dict(error=repr(e))
         for s in sess_w:
-            s.close()
+            try:
+                s.close()
+            except Exception:  # noqa: BLE001
+                pass
     # ---- what ONE rank of an 8-GPU run would do (north_star's 8 x MI355X target; the pool gives this process one GPU): shard
     #      0 of the 8-way LPT partition of the same dataset, as slices on this GPU, same step definition.  A measured per-GPU
     #      rate, not a scaling curve: no RCCL, no second device.
@@ -729,10 +776,10 @@ def main():
     if not args.no_e2e:
         api.trim_cache(local_rank)
         t1 = time.perf_counter()
-        api.cluster_chunks(params, batch, device=local_rank)
+        one = api.cluster_chunks(params, batch, device=local_rank)
         cold = time.perf_counter() - t1
         t2 = time.perf_counter()
-        one = api.cluster_chunks(params, batch, device=local_rank)
+        one = api.cluster_chunks(params, batch, device=local_rank, out=one)   # (a host keeps its output buffers between calls)
         warm = time.perf_counter() - t2
         tm = api.last_timing()
         line["e2e"] = dict(chunks_per_s=batch.n_chunks / warm, seconds=warm, first_call_seconds=cold, fresh_process=fresh,
@@ -743,7 +790,7 @@ def main():
         api.trim_cache(local_rank)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         cold_ph, _, _, _ = stage_e2e(params, batch, cfg, local_rank)
-        warm_ph, st_out, p_refit, st_raw = stage_e2e(params, batch, cfg, local_rank, os.path.join(ROOT, "gpurun_out", "record_r05.tsv"))
+        warm_ph, st_out, p_refit, st_raw = stage_e2e(params, batch, cfg, local_rank, os.path.join(ROOT, "gpurun_out", "record_r06.tsv"))
         line["stage_e2e"] = dict(
             cold=cold_ph, warm=warm_ph, chunks_per_s_warm=batch.n_chunks / (warm_ph["total_ms"] / 1e3),
             chunks_ok=int((st_out["result"]["status"] == 0).sum()),

@@ -23,11 +23,12 @@ def _outputs(batch):
                 ops_out_off=ops_out_off)
 
 
-def cluster_chunks(params, batch, device=0, raise_on_chunk_failure=True, devices=None):
+def cluster_chunks(params, batch, device=0, raise_on_chunk_failure=True, devices=None, out=None):
     """jtk_lc_cluster_chunks: polish + variant search + clustering for every chunk of `batch`;
-    devices=[...]: jtk_lc_cluster_chunks_multi over that list of GPUs."""
+    devices=[...]: jtk_lc_cluster_chunks_multi over that list of GPUs; out = the output arrays of an earlier call on a batch of
+    this shape, to be overwritten (a host that enters the stage several times keeps its buffers)."""
     L = ffi.lib()
-    o = _outputs(batch)
+    o = out if out is not None else _outputs(batch)
     args = (C.byref(params), batch.n_chunks, batch.chunks.ctypes.data, u8p(batch.tmpl_bases),
             u8p(batch.read_bases), u64p(batch.read_off), u8p(batch.ops), u64p(batch.ops_off),
             u8p(batch.strand), u32p(o["label"]), f64p(o["log_post"]), batch.post_stride,
@@ -184,8 +185,10 @@ class Session:
     def run(self, skip_polish=False):
         check(self._lib.jtk_lc_session_run(self._h, int(skip_polish)))
 
-    def fetch(self, raise_on_chunk_failure=True):
-        o = _outputs(self.batch)
+    def fetch(self, raise_on_chunk_failure=True, out=None):
+        """every output of the stage call: labels, log-posteriors, per-chunk records, consensus and re-threaded ops (out = the
+        arrays of an earlier fetch, overwritten)"""
+        o = out if out is not None else _outputs(self.batch)
         rc = self._lib.jtk_lc_session_fetch(self._h, u32p(o["label"]), f64p(o["log_post"]), o["result"].ctypes.data,
                                             u8p(o["cons"]), u64p(o["cons_off"]), len(o["cons"]), u8p(o["ops_out"]),
                                             u64p(o["ops_out_off"]), len(o["ops_out"]))

@@ -14,7 +14,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXPORTS_MAP = os.path.join(CSRC, "exports.map")  # only jtk_lc_* leaves the library
 
 SOURCES = ["phmm_kernels.hip", "phmm_sweep.hip", "phmm_pair.hip", "phmm_wide.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip", "session.hip", "gains.hip", "correction.hip",
-           "host_api.cpp"]
+           "io_kernels.hip", "host_api.cpp"]
 SYNTH_SOURCES = ["synth.cpp"]
 # -ffp-contract=off: device f64 arithmetic must round exactly like the reference (no implicit fma);
 # the pair-HMM specification uses explicit fma() where it wants one.
@@ -86,7 +86,7 @@ def build_experiment(name, extra_flags):
 
 
 PROFILED_SOURCES = ["phmm_kernels.hip", "phmm_sweep.hip", "phmm_pair.hip", "phmm_wide.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip",
-                    "session.hip", "device_common.h"]
+                    "session.hip", "io_kernels.hip", "device_common.h"]
 
 
 def source_sha16():

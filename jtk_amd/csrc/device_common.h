@@ -177,6 +177,16 @@ void launch_phmm_counts(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, 
                         const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
                         double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
                         double *counts, double *lk, uint32_t max_tmpl, uint32_t max_read);
+// io_kernels.hip: the raw reads / ops of a batch recoded on the device (flags: bit 1 = non-ACGT base, bit 2 = op code > 3), and
+// the variable-length results packed for the copy back (lengths first, then consensus as ASCII + ops at prefix-summed offsets)
+void launch_encode_reads(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const uint8_t *raw_bases,
+                         const uint64_t *raw_base_off, const uint8_t *raw_ops, const uint64_t *raw_ops_off, uint8_t *ey,
+                         uint8_t *ops, uint32_t *flags);
+void launch_out_len(hipStream_t s, uint32_t n_reads, uint32_t n_chunks, const ReadMeta *reads, const ChunkState *state,
+                    DevBufs bufs, uint32_t *ops_len_out, uint32_t *cons_len_out);
+void launch_gather(hipStream_t s, uint32_t n_reads, uint32_t n_chunks, const ReadMeta *reads, const ChunkMeta *chunks,
+                   const ChunkState *state, DevBufs bufs, const uint64_t *ops_out_off, const uint64_t *cons_off,
+                   uint8_t *ops_out, uint8_t *cons_out);
 // polish_kernels.hip
 #define JTK_NACTIVE_SLOTS (JTK_POLISH_MAX_ROUNDS + 3)  // one "chunks still active" counter per polish round of a pass
 void launch_reset_pass(hipStream_t s, uint32_t n_chunks, ChunkState *state, const ChunkState *state0, uint32_t *n_active,

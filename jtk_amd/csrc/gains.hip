@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "device_common.h"
@@ -241,53 +242,84 @@ double nth(std::vector<double> xs, size_t k) {  // select_nth_unstable_by(k).1: 
     return xs[k];
 }
 
-// gain_of (likelihood_gains.rs:253-315) for one (length, type) profile
-int gain_of(const jtk_lc_params_t &params, uint64_t seed, uint32_t seq_len, uint32_t band, uint32_t len, int diff_type,
-            int device, jtk_gain_profile_t *out) {
-    const int SAMPLE_NUM = 100, SEQ_NUM = 50;  // likelihood_gains.rs:261-264
+// gain_of (likelihood_gains.rs:253-315) for a LIST of (length, type) profiles.  The reference calls gain_of once per profile
+// (estimate_gain :170-181: 3 types x max homopolymer length, each 100 simulations x 2 haplotypes x 100 reads); the profiles are
+// independent -- every simulation seeds its own generator (:269) -- so since round 6 they are simulated side by side on host
+// threads, aligned by ONE edit_ops launch and scored by ONE likelihood session (rounds 2-5: nine sequential round trips of
+// ~13 ms each through the device for 20,000 reads of 100 bases at a time; 119 of the stage's 371 ms of preambles).
+struct GainJob {
+    uint32_t len;
+    int diff_type;
+    jtk_gain_profile_t *out;
+    // the simulations.  Per simulation i: templates [tmpl, diff]; reads 0..49 drawn from diff, 50..99 from tmpl
+    std::vector<std::string> tmpls, reads;
+    uint32_t max_len = 0;
+};
+const int GAIN_SAMPLE_NUM = 100, GAIN_SEQ_NUM = 50;  // likelihood_gains.rs:261-264
+
+void simulate_gain_job(const jtk_lc_params_t &params, uint64_t seed, uint32_t seq_len, GainJob &job) {
+    const int SAMPLE_NUM = GAIN_SAMPLE_NUM, SEQ_NUM = GAIN_SEQ_NUM;
     const size_t half = seq_len / 2, cap = 3 * (2 * half + 64) + 16;
-    // ---- host: the simulations.  Per simulation: templates [tmpl, diff]; reads 0..49 drawn from diff, 50..99 from tmpl
-    std::vector<std::string> tmpls(2 * SAMPLE_NUM), reads((size_t)2 * SEQ_NUM * SAMPLE_NUM);
+    job.tmpls.assign(2 * SAMPLE_NUM, std::string());
+    job.reads.assign((size_t)2 * SEQ_NUM * SAMPLE_NUM, std::string());
     uint32_t max_len = 0;
     for (int i = 0; i < SAMPLE_NUM; i++) {
         Xoshiro rng((uint64_t)i + seed);  // likelihood_gains.rs:269
         std::string seg1, seg2, h1, h2;
         generate_seq(rng, half, seg1);
         generate_seq(rng, half, seg2);
-        gen_diff_haplotypes(rng, len, diff_type, h1, h2);
-        tmpls[2 * i] = seg1 + h1 + seg2;
-        tmpls[2 * i + 1] = seg1 + h2 + seg2;
+        gen_diff_haplotypes(rng, job.len, job.diff_type, h1, h2);
+        job.tmpls[2 * i] = seg1 + h1 + seg2;
+        job.tmpls[2 * i + 1] = seg1 + h2 + seg2;
         for (int t = 0; t < 2 * SEQ_NUM; t++) {
             const jtk_hmm_t &h = (t % 2 == 0) ? params.forward : params.reverse;  // :272-275 (SEQ_NUM is even)
-            phmm_gen(h, tmpls[2 * i + (t < SEQ_NUM ? 1 : 0)], rng, cap, reads[(size_t)i * 2 * SEQ_NUM + t]);
-            max_len = std::max<uint32_t>(max_len, (uint32_t)reads[(size_t)i * 2 * SEQ_NUM + t].size());
+            phmm_gen(h, job.tmpls[2 * i + (t < SEQ_NUM ? 1 : 0)], rng, cap, job.reads[(size_t)i * 2 * SEQ_NUM + t]);
+            max_len = std::max<uint32_t>(max_len, (uint32_t)job.reads[(size_t)i * 2 * SEQ_NUM + t].size());
         }
-        max_len = std::max<uint32_t>(max_len, (uint32_t)std::max(tmpls[2 * i].size(), tmpls[2 * i + 1].size()));
+        max_len = std::max<uint32_t>(max_len, (uint32_t)std::max(job.tmpls[2 * i].size(), job.tmpls[2 * i + 1].size()));
     }
+    job.max_len = max_len;
+}
+
+int gains_of(const jtk_lc_params_t &params, uint64_t seed, uint32_t seq_len, uint32_t band, std::vector<GainJob> &jobs, int device) {
+    const int SAMPLE_NUM = GAIN_SAMPLE_NUM, SEQ_NUM = GAIN_SEQ_NUM;
+    // ---- host: the simulations, one thread per profile
+    {
+        std::vector<std::thread> th;
+        for (size_t q = 1; q < jobs.size(); q++) th.emplace_back([&, q]() { simulate_gain_job(params, seed, seq_len, jobs[q]); });
+        if (!jobs.empty()) simulate_gain_job(params, seed, seq_len, jobs[0]);
+        for (auto &t : th) t.join();
+    }
+    uint32_t max_len = 0;
+    for (const GainJob &job : jobs) max_len = std::max(max_len, job.max_len);
     if (max_len > EDIT_MAX_LEN) {
         jtk_internal_set_error("estimate_gain: simulated sequence longer than 250 bases");
         return JTK_ERR_UNSUPPORTED;
     }
-    // ---- the batch: chunk 2i = (tmpl_i, its 100 reads), chunk 2i+1 = (diff_i, the same reads)
-    const size_t n_chunks = (size_t)2 * SAMPLE_NUM, per = (size_t)2 * SEQ_NUM, n_reads = n_chunks * per;
+    // ---- the batch: per profile, chunk 2i = (tmpl_i, its 100 reads), chunk 2i+1 = (diff_i, the same reads)
+    const size_t chunks_per_job = (size_t)2 * SAMPLE_NUM, per = (size_t)2 * SEQ_NUM, n_chunks = chunks_per_job * jobs.size(),
+                 n_reads = n_chunks * per;
     std::vector<jtk_lc_chunk_t> chunks(n_chunks);
     std::vector<uint8_t> tb, rb, strand(n_reads);
     std::vector<uint64_t> roff(1, 0);
     std::vector<PairMeta> pairs(n_reads);
+    roff.reserve(n_reads + 1);
     for (size_t c = 0; c < n_chunks; c++) {
+        const GainJob &job = jobs[c / chunks_per_job];
+        const size_t cj = c % chunks_per_job;
         memset(&chunks[c], 0, sizeof chunks[c]);
         chunks[c].chunk_id = c;
         chunks[c].copy_num = 2;
         chunks[c].n_reads = (uint32_t)per;
         chunks[c].tmpl_off = tb.size();
-        chunks[c].tmpl_len = tmpls[c].size();
+        chunks[c].tmpl_len = job.tmpls[cj].size();
         chunks[c].read_first = c * per;
-        tb.insert(tb.end(), tmpls[c].begin(), tmpls[c].end());
+        tb.insert(tb.end(), job.tmpls[cj].begin(), job.tmpls[cj].end());
         for (size_t t = 0; t < per; t++) {
-            const std::string &r = reads[(c / 2) * per + t];
+            const std::string &r = job.reads[(cj / 2) * per + t];
             PairMeta &pm = pairs[c * per + t];
             pm.tmpl_off = (uint32_t)chunks[c].tmpl_off;
-            pm.tmpl_len = (uint32_t)tmpls[c].size();
+            pm.tmpl_len = (uint32_t)job.tmpls[cj].size();
             pm.read_off = (uint32_t)rb.size();
             pm.read_len = (uint32_t)r.size();
             rb.insert(rb.end(), r.begin(), r.end());
@@ -302,6 +334,12 @@ int gain_of(const jtk_lc_params_t &params, uint64_t seed, uint32_t seq_len, uint
     if (rc) return rc;
     std::vector<uint8_t> ops;
     std::vector<uint64_t> ooff(1, 0);
+    ooff.reserve(n_reads + 1);
+    {
+        size_t total = 0;
+        for (size_t g = 0; g < n_reads; g++) total += ops_len[g];
+        ops.reserve(total);
+    }
     for (size_t g = 0; g < n_reads; g++) {
         ops.insert(ops.end(), ops_strided.begin() + g * EDIT_OPS_STRIDE, ops_strided.begin() + g * EDIT_OPS_STRIDE + ops_len[g]);
         ooff.push_back(ops.size());
@@ -310,21 +348,24 @@ int gain_of(const jtk_lc_params_t &params, uint64_t seed, uint32_t seq_len, uint
     rc = jtk_internal_likelihoods(&params, n_chunks, chunks.data(), tb.data(), rb.data(), roff.data(), ops.data(), ooff.data(),
                                   strand.data(), band, device, lk.data());
     if (rc) return rc;
-    // ---- host: likelihood_gains.rs:276-314
-    std::vector<double> medians(SAMPLE_NUM), probs(SAMPLE_NUM);
-    for (int i = 0; i < SAMPLE_NUM; i++) {
-        const double *base = &lk[(size_t)(2 * i) * per], *dif = &lk[(size_t)(2 * i + 1) * per];
-        std::vector<double> lk_diff(SEQ_NUM);
-        for (int t = 0; t < SEQ_NUM; t++) lk_diff[t] = dif[t] - base[t];
-        const double expected_gain = nth(lk_diff, SEQ_NUM / 2);
-        const double min_gain = diff_type == JTK_DIFF_SUBST ? expected_gain / 10.0 : 0.0001;
-        int null_cnt = 0;
-        for (int t = SEQ_NUM; t < 2 * SEQ_NUM; t++) null_cnt += (base[t] + min_gain < dif[t]) ? 1 : 0;
-        medians[i] = expected_gain;
-        probs[i] = (double)null_cnt / (double)SEQ_NUM;
+    // ---- host: likelihood_gains.rs:276-314, per profile
+    for (size_t q = 0; q < jobs.size(); q++) {
+        const double *lkq = lk.data() + q * chunks_per_job * per;
+        std::vector<double> medians(SAMPLE_NUM), probs(SAMPLE_NUM);
+        for (int i = 0; i < SAMPLE_NUM; i++) {
+            const double *base = &lkq[(size_t)(2 * i) * per], *dif = &lkq[(size_t)(2 * i + 1) * per];
+            std::vector<double> lk_diff(SEQ_NUM);
+            for (int t = 0; t < SEQ_NUM; t++) lk_diff[t] = dif[t] - base[t];
+            const double expected_gain = nth(lk_diff, SEQ_NUM / 2);
+            const double min_gain = jobs[q].diff_type == JTK_DIFF_SUBST ? expected_gain / 10.0 : 0.0001;
+            int null_cnt = 0;
+            for (int t = SEQ_NUM; t < 2 * SEQ_NUM; t++) null_cnt += (base[t] + min_gain < dif[t]) ? 1 : 0;
+            medians[i] = expected_gain;
+            probs[i] = (double)null_cnt / (double)SEQ_NUM;
+        }
+        jobs[q].out->gain = nth(medians, SAMPLE_NUM / 10);
+        jobs[q].out->prob = std::max(nth(probs, SAMPLE_NUM * 2 / 3), 0.000000001);
     }
-    out->gain = nth(medians, SAMPLE_NUM / 10);
-    out->prob = std::max(nth(probs, SAMPLE_NUM * 2 / 3), 0.000000001);
     return 0;
 }
 
@@ -475,11 +516,19 @@ int jtk_lc_estimate_gains(const jtk_hmm_t *forward, const jtk_hmm_t *reverse, ui
     out->max_homopolymer_len = homop_len;
     const int types[3] = {JTK_DIFF_SUBST, JTK_DIFF_DEL, JTK_DIFF_INS};  // likelihood_gains.rs:170-181
     jtk_gain_profile_t *dst[3] = {out->subst, out->deletions, out->insertions};
+    std::vector<GainJob> jobs;
     for (int ty = 0; ty < 3; ty++)
         for (uint32_t len = 1; len <= homop_len; len++) {
-            const int rc = gain_of(params, seed, seq_len, band, len, types[ty], device, &dst[ty][len - 1]);
-            if (rc) return rc;
+            GainJob j;
+            j.len = len;
+            j.diff_type = types[ty];
+            j.out = &dst[ty][len - 1];
+            jobs.push_back(std::move(j));
         }
+    {
+        const int rc = gains_of(params, seed, seq_len, band, jobs, device);
+        if (rc) return rc;
+    }
     return 0;
 }
 

@@ -59,7 +59,9 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 // superblocks (RN draws + RN records).  seg_log is a launch parameter (round 5): 4 in the light kernel and the global-memory one
 // (a 24 KiB ring: the jump is paid once per 1,024 draws), 3 in the general kernel -- a 12 KiB ring is what lets FOUR chain
 // workgroups of a 4-copy pile-up share a CU's LDS (40.7 KB each), and the K-way chains' producer has slack for the extra jumps.
+#ifndef JTK_SEG_LOG_LIGHT
 #define JTK_SEG_LOG_LIGHT 4u
+#endif
 #define JTK_SEG_LOG_GENERAL 3u
 #define RN_OF(seg_log) (128u << (seg_log))
 #define JUMP_TAB_BYTES (128 * 4 * 32) // (what an LDS copy of the round-4 jump table took; the byte table lives in L2)

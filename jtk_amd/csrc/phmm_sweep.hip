@@ -47,6 +47,9 @@ namespace {
 #ifndef JTK_PHMM_FWD_PREFETCH
 #define JTK_PHMM_FWD_PREFETCH 1     // the forward sweep's fast steps do the same (and load a half group's read bytes a step early)
 #endif
+#ifndef JTK_PHMM_BASE_CMPX
+#define JTK_PHMM_BASE_CMPX 1        // the row sums split by read base through v_cmpx (0: v_cmp + s_and_saveexec, rounds 3-5)
+#endif
 #ifndef JTK_PHMM_REPLAY_PREFETCH
 #define JTK_PHMM_REPLAY_PREFETCH 1  // the replayed steps fetch their emission entries one step ahead (0: when they need them)
 #endif
@@ -82,6 +85,19 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
     return (uint64_t)(uint32_t)uni((int)(uint32_t)(v >> 32)) << 32 | (uint32_t)uni((int)(uint32_t)v);
 }
 __device__ __forceinline__ double uni_f64(double v) { return jtk_bits_f64(uni64(jtk_f64_bits(v))); }
+// v with lane l (uniform, a scalar register) replaced by the scalar x: v_writelane_b32 ignores EXEC, so one lane's state changes
+// without a saveexec / branch / restore around it
+__device__ __forceinline__ __attribute__((unused)) int wlane(int x, int l, int v) {
+    x = __builtin_amdgcn_readfirstlane(x);  // (a uniform value the compiler keeps in a vector register is not an "s" operand)
+    l = __builtin_amdgcn_readfirstlane(l);
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(x), "s"(l) : "m0");  // (two SGPRs: the select goes through M0)
+    return v;
+}
+__device__ __forceinline__ __attribute__((unused)) double wl_zero(double v, int l) {  // v with lane l set to +0.0
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    asm("v_writelane_b32 %0, 0, %2\n\tv_writelane_b32 %1, 0, %2" : "+v"(lo), "+v"(hi) : "s"(l));
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ uint64_t rotl64(uint64_t m, int s) { return (m << (s & 63)) | (m >> ((64 - s) & 63)); }
 __device__ __forceinline__ bool lanes(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 // A block that must run under an EXEC mask (and not be turned into selects over everything it assigns): an empty volatile
@@ -107,6 +123,41 @@ __device__ __forceinline__ bool lanes(uint64_t m) { return __builtin_amdgcn_inve
             : [y8] "v"(y8v), [xa] "v"(x_sub), [xb] "v"(x_ins), [vm] "v"(vmv), [q8] "n"(8 * (Q))                      \
             : "vcc", "scc");                                                                                               \
     }
+#if defined(JTK_PHMM_X_NOBASE)   // timing-only probe: no split by read base
+#define BASE_FMAS(xs_, xi_, vmv, y8v) { acc[0] = fma(xs_, vmv, acc[0]); acc[5] = fma(xi_, vmv, acc[5]); }
+#elif JTK_PHMM_BASE_CMPX  // v_cmpx writes EXEC itself: 4 instructions per base instead of 5 (round 6: -1.3 % of a pass)
+#define BASE_FMAS(xs_, xi_, vmv, y8v)                                                                               \
+    {                                                                                                               \
+        uint64_t sv_;                                                                                               \
+        asm("s_mov_b64 %[sv], exec\n\t"                                                                             \
+            "v_cmpx_eq_u32_e32 0, %[y8]\n\t"                                                                        \
+            "v_fmac_f64_e32 %[a0], %[xa], %[vm]\n\t"                                                                \
+            "v_fmac_f64_e32 %[b0], %[xb], %[vm]\n\t"                                                                \
+            "s_mov_b64 exec, %[sv]\n\t"                                                                             \
+            "v_cmpx_eq_u32_e32 8, %[y8]\n\t"                                                                        \
+            "v_fmac_f64_e32 %[a1], %[xa], %[vm]\n\t"                                                                \
+            "v_fmac_f64_e32 %[b1], %[xb], %[vm]\n\t"                                                                \
+            "s_mov_b64 exec, %[sv]\n\t"                                                                             \
+            "v_cmpx_eq_u32_e32 16, %[y8]\n\t"                                                                       \
+            "v_fmac_f64_e32 %[a2], %[xa], %[vm]\n\t"                                                                \
+            "v_fmac_f64_e32 %[b2], %[xb], %[vm]\n\t"                                                                \
+            "s_mov_b64 exec, %[sv]\n\t"                                                                             \
+            "v_cmpx_eq_u32_e32 24, %[y8]\n\t"                                                                       \
+            "v_fmac_f64_e32 %[a3], %[xa], %[vm]\n\t"                                                                \
+            "v_fmac_f64_e32 %[b3], %[xb], %[vm]\n\t"                                                                \
+            "s_mov_b64 exec, %[sv]"                                                                                 \
+            : [a0] "+v"(acc[0]), [b0] "+v"(acc[5]), [a1] "+v"(acc[1]), [b1] "+v"(acc[6]), [a2] "+v"(acc[2]),        \
+              [b2] "+v"(acc[7]), [a3] "+v"(acc[3]), [b3] "+v"(acc[8]), [sv] "=&s"(sv_)                              \
+            : [y8] "v"(y8v), [xa] "v"(xs_), [xb] "v"(xi_), [vm] "v"(vmv)                                            \
+            : "vcc", "scc");                                                                                        \
+    }
+#else
+#define BASE_FMAS(xs_, xi_, vmv, y8v)                 \
+    BASE_FMA(0, acc[0], acc[5], xs_, xi_, vmv, y8v)   \
+    BASE_FMA(1, acc[1], acc[6], xs_, xi_, vmv, y8v)   \
+    BASE_FMA(2, acc[2], acc[7], xs_, xi_, vmv, y8v)   \
+    BASE_FMA(3, acc[3], acc[8], xs_, xi_, vmv, y8v)
+#endif
 // acc = fma(y, vd, fma(x, hM, acc)) where the x term only counts on lanes with rowv >= thr_x and the y term on lanes with
 // rowv >= thr_y (the del-3 source row i-4 must lie inside the band of ITS diagonal: the one case the three spare lanes of
 // the lane ring cannot tell apart)
@@ -145,7 +196,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
     // band move and in the generic steps only, so they can afford the unpacking; a byte per code cost a twelfth wave per CU)
     auto xs_of = [&](int i) -> uint32_t {  // 32 * code(x[i-1]): the eM row of template row i, in bytes
         const uint32_t q = (uint32_t)(i - 1 + PAD);
-        return ((uint32_t)smem[S_XS + (q >> 2)] >> (2u * (q & 3u)) & 3u) << 5;
+        return ((uint32_t)(*(__attribute__((address_space(3))) const uint8_t *)(uintptr_t)(S_XS + (q >> 2))) >> (2u * (q & 3u)) & 3u) << 5;
     };
     const uint32_t EY0 = S_EY + PAD;      // smem[EY0 + j] = 8 * (y[j-1] | ctx(j) << 2): the eI entry of read column j, in bytes
     uint64_t *s_delta = reinterpret_cast<uint64_t *>(smem + S_DELTA);
@@ -156,10 +207,36 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
     uint32_t RK[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) RK[k] = (uint32_t)((lane + k - 4) & 63) * 16;
-    auto lds_f64 = [&](uint32_t a) -> double { return *reinterpret_cast<const double *>(smem + a); };
-    auto lds_u8 = [&](uint32_t a) -> uint32_t { return smem[a]; };
-    auto lds_u32 = [&](uint32_t a) -> uint32_t { return *reinterpret_cast<const uint32_t *>(smem + a); };
-    auto ring_at = [&](uint32_t slot, uint32_t off) -> double2 * { return reinterpret_cast<double2 *>(smem + slot * RS + off); };
+    // The hot LDS accesses address the work area by its byte offset through LDS-address-space pointers (round 6): the kernel has
+    // no static __shared__ object, so the dynamic area starts at LDS address 0 (checked below), and an access through `smem + a`
+    // costs a `v_add_u32 v, 0, v` per computed address -- the array's base is a link-time constant the compiler cannot fold
+    // (40 of them per group of 8 anti-diagonals).
+    typedef __attribute__((address_space(3))) const double lds_cf64_t;
+    typedef __attribute__((address_space(3))) const uint8_t lds_cu8_t;
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32_t;
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2d_t lds_v2d_t;
+    struct RingRef {   // a ring entry: reads and writes as one 16-byte LDS access
+        lds_v2d_t *p;
+        __device__ __forceinline__ operator double2() const {
+            const v2d_t v = *p;
+            return make_double2(v.x, v.y);
+        }
+        __device__ __forceinline__ void operator=(const double2 &v) const {
+            v2d_t w;
+            w.x = v.x;
+            w.y = v.y;
+            *p = w;
+        }
+    };
+    auto lds_f64 = [&](uint32_t a) -> double { return *(lds_cf64_t *)(uintptr_t)a; };
+    auto lds_u8 = [&](uint32_t a) -> uint32_t { return *(lds_cu8_t *)(uintptr_t)a; };
+    auto lds_u32 = [&](uint32_t a) -> uint32_t { return *(lds_cu32_t *)(uintptr_t)a; };
+    // (the slot -- a constant in the unrolled groups -- is added as POINTER arithmetic: that is what ends up in the DS instruction's
+    // offset field; added to the integer it becomes a v_or_b32 per access)
+    typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+    auto ring_at = [&](uint32_t slot, uint32_t off) -> RingRef { return RingRef{(lds_v2d_t *)((lds_byte_t *)(uintptr_t)off + slot * RS)}; };
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();  // (never: see above)
     // four bytes smem[a .. a+3] as one dword (a need not be aligned)
     auto window4 = [&](uint32_t a) -> uint32_t {
         const uint32_t al = a & ~3u;
@@ -343,14 +420,26 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 const double pM = rot_from_prev(toM_2), pD = rot_from_prev(toD_1);
                 toM_2 = toM_1;  // every lane: a lane outside the band shifts its zeros along
                 if ((db >> u) & 1) {  // the band moves up: row c - r leaves it, its lane is spare for the next three moves
+#if defined(JTK_PHMM_X_WLANE)
+                    toM_1 = wl_zero(toM_1, lo6);
+                    toI_1 = wl_zero(toI_1, lo6);
+                    toD_1 = wl_zero(toD_1, lo6);
+                    row = wlane(c - r + 64, lo6, row);
+                    xrow = (uint32_t)wlane((int)(S_EM + (((uint32_t)c & 3u) << 5)), lo6, (int)xrow);
+#else
                     if (lanes(1ull << lo6)) {
                         KEEP_MASKED;
                         toM_1 = 0.0;
                         toI_1 = 0.0;
                         toD_1 = 0.0;
                         row += 64;
+#ifdef JTK_PHMM_X_NOXS
+                        xrow = S_EM + (((uint32_t)row & 3u) << 5);
+#else
                         xrow = S_EM + xs_of(row);
+#endif
                     }
+#endif
                     lo6 = (lo6 + 1) & 63;
                     c += 1;
                     band = (band << 1) | (band >> 63);
@@ -360,8 +449,13 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 {
                     if ((u & 3) == 3) Wn = window4(EY0 + (uint32_t)(t + u + 1 - row));
                     const uint32_t bnext = ((u & 3) == 3 ? Wn : W >> (8 * ((u & 3) + 1))) & 0xffu;
+#ifdef JTK_PHMM_X_NOEM
+                    eMn = jtk_bits_f64(0x3fd0000000000000ull | bnext);
+                    eIn = jtk_bits_f64(0x3fd0000000000000ull | xrow);
+#else
                     eMn = lds_f64(xrow | (bnext & 24u));
                     eIn = lds_f64(S_EI + bnext);
+#endif
                 }
 #else
                 const uint32_t byte = (W >> (8 * (u & 3))) & 0xffu;
@@ -463,12 +557,12 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
         return fast_pow2(uni(s_EF[d >> 6]) - uni(s_EF[blk]));
     };
     // ring: slot s & 7 holds P_s, in the scale of the block of the step that reads it
-    *ring_at((T + 2) & 7, lane16) = make_double2(0.0, 0.0);
+    ring_at((T + 2) & 7, lane16) = make_double2(0.0, 0.0);
     for (int ss = T + 1; ss >= T - 4; ss--) {
         double2 v = scratch[(int64_t)ss * 64 + lane];
         v.x *= rel(ss - 1, T >> 6);
         v.y *= rel(ss, T >> 6);
-        *ring_at(ss & 7, lane16) = v;
+        ring_at(ss & 7, lane16) = v;
     }
     int EFcur = uni(s_EF[T >> 6]);  // forward exponent of the block the sweep is in
     // the row sums of a row: acc[0..3] sub by read base (toM part), acc[4] sub (toD part), acc[5..8] ins, acc[9] ins (toD),
@@ -528,10 +622,10 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                     const double f = fast_pow2(EFabove - EFcur);
 #pragma unroll
                     for (int sl = 0; sl < 8; sl++) {
-                        double2 v = *ring_at(sl, lane16);
+                        double2 v = ring_at(sl, lane16);
                         v.x *= f;
                         v.y *= f;
-                        *ring_at(sl, lane16) = v;
+                        ring_at(sl, lane16) = v;
                     }
                 }
                 const int dn = t < T ? delta_bit(t + 1) : 0;
@@ -552,7 +646,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                         v.x *= rel(t - 6, t >> 6);
                         v.y *= rel(t - 5, t >> 6);
                     }
-                    *ring_at((t - 5) & 7, lane16) = v;
+                    ring_at((t - 5) & 7, lane16) = v;
                 }
                 double vm, vi, vd;
                 if (t == T) {
@@ -590,10 +684,10 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 Gprev = G;
                 {
                     const uint32_t s0 = (uint32_t)t;
-                    double2 a_m4 = *ring_at((s0 - 4) & 7, RK[0]);
-                    const double2 a_m3 = *ring_at((s0 - 3) & 7, RK[1]), a_m2 = *ring_at((s0 - 2) & 7, RK[2]),
-                                  a_m1 = *ring_at((s0 - 1) & 7, RK[3]), a_0 = *ring_at(s0 & 7, RK[4]),
-                                  a_p1 = *ring_at((s0 + 1) & 7, RK[5]), a_p2 = *ring_at((s0 + 2) & 7, RK[6]);
+                    double2 a_m4 = ring_at((s0 - 4) & 7, RK[0]);
+                    const double2 a_m3 = ring_at((s0 - 3) & 7, RK[1]), a_m2 = ring_at((s0 - 2) & 7, RK[2]),
+                                  a_m1 = ring_at((s0 - 1) & 7, RK[3]), a_0 = ring_at(s0 & 7, RK[4]),
+                                  a_p1 = ring_at((s0 + 1) & 7, RK[5]), a_p2 = ring_at((s0 + 2) & 7, RK[6]);
                     // the only source row the 3 spare lanes cannot disambiguate
                     if (!(i - 4 >= c5 - r)) a_m4.x = 0.0;
                     if (!(i - 4 >= c4 - r)) a_m4.y = 0.0;
@@ -682,6 +776,14 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
     const double eMv = lds_f64(xrowf | (byte & 24u)), eIv = lds_f64(S_EI + byte);
 #endif
                     if ((w16 >> (3 + k)) & 1u) {
+#if defined(JTK_PHMM_X_WLANE)
+                        fM1 = wl_zero(fM1, lo6f);
+                        fI1 = wl_zero(fI1, lo6f);
+                        fD1 = wl_zero(fD1, lo6f);
+                        rowf = wlane(lof + k + 64, lo6f, rowf);
+                        yb = (uint32_t)wlane((int)(EY0 + (uint32_t)(tb - 12 - lof - k - 64)), lo6f, (int)yb);
+                        xrowf = (uint32_t)wlane((int)(S_EM + (((uint32_t)lo6f & 3u) << 5)), lo6f, (int)xrowf);
+#else
                         if (lanes(1ull << lo6f)) {
                             KEEP_MASKED;
                             fM1 = 0.0;
@@ -689,15 +791,25 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                             fD1 = 0.0;
                             rowf += 64;
                             yb -= 64;
+#ifdef JTK_PHMM_X_NOXS
+                            xrowf = S_EM + (((uint32_t)rowf & 3u) << 5);
+#else
                             xrowf = S_EM + xs_of(rowf);
+#endif
                         }
+#endif
                         lo6f = (lo6f + 1) & 63;
                         bandf = (bandf << 1) | (bandf >> 63);
                     }
 #if JTK_PHMM_REPLAY_PREFETCH
                     if (k < 7) {
+#ifdef JTK_PHMM_X_NOEM
+                        eMn = jtk_bits_f64(0x3fd0000000000000ull | bn);
+                        eIn = jtk_bits_f64(0x3fd0000000000000ull | xrowf);
+#else
                         eMn = lds_f64(xrowf | (bn & 24u));
                         eIn = lds_f64(S_EI + bn);
+#endif
                         if (k < 6) bn = lds_u8(yb + (uint32_t)(k + 2));
                     }
 #endif
@@ -748,10 +860,10 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                     const double f = fast_pow2(EFabove - EFcur);
 #pragma unroll
                     for (int sl = 0; sl < 8; sl++) {
-                        double2 v = *ring_at(sl, lane16);
+                        double2 v = ring_at(sl, lane16);
                         v.x *= f;
                         v.y *= f;
-                        *ring_at(sl, lane16) = v;
+                        ring_at(sl, lane16) = v;
                     }
                 }
                 const double xm = rot_from_next(hM_2), xd = rot_from_next(bD_1);
@@ -759,6 +871,14 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 const int dn = u == 0 ? carry : (int)((w16 >> (16 - u)) & 1u);  // c[t+1] - c[t]
                 if (dn) {  // the band moves down: row c + r leaves it, final
                     const int hi6 = (lo6 + 2 * r) & 63;
+#if defined(JTK_PHMM_X_WLANE)
+                    hM_1 = wl_zero(hM_1, hi6);
+                    hI_1 = wl_zero(hI_1, hi6);
+                    bD_1 = wl_zero(bD_1, hi6);
+                    rowG = wlane(Gprev, hi6, rowG);
+                    row = wlane(c + r - 64, hi6, row);
+                    xrow = (uint32_t)wlane((int)(S_EM + (((uint32_t)c & 3u) << 5)), hi6, (int)xrow);
+#else
                     if (lanes(1ull << hi6)) {
                         KEEP_MASKED;
                         hM_1 = 0.0;
@@ -766,8 +886,13 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                         bD_1 = 0.0;
                         rowG = Gprev;
                         row -= 64;
+#ifdef JTK_PHMM_X_NOXS
+                        xrow = S_EM + (((uint32_t)row & 3u) << 5);
+#else
                         xrow = S_EM + xs_of(row);
+#endif
                     }
+#endif
                     left |= 1ull << hi6;
                     lo6 = (lo6 - 1) & 63;
                     c -= 1;
@@ -795,7 +920,7 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                         v.x *= Fsp;
                         if (u >= 3) v.y *= Fsp;
                     }
-                    *ring_at((7 - u - 5) & 7, lane16) = v;
+                    ring_at((7 - u - 5) & 7, lane16) = v;
                 }
                 const bool in_band = lanes(band);
                 const uint32_t byte = (W >> (8 * (3 - (u & 3)))) & 0xffu;
@@ -803,14 +928,11 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 const int thr_x = c5 - r + 4, thr_y = c4 - r + 4;  // the del-3 source row i-4 must be >= c[t-5]-r / c[t-4]-r
 #define BWD_PRODUCTS(vmv, vdv, hMv)                                                                                          \
 {                                                                                                                        \
-    const double2 a_m4 = *ring_at((7 - u - 4) & 7, RK[0]);                                                               \
-    const double2 a_m3 = *ring_at((7 - u - 3) & 7, RK[1]), a_m2 = *ring_at((7 - u - 2) & 7, RK[2]),                       \
-                  a_m1 = *ring_at((7 - u - 1) & 7, RK[3]), a_0 = *ring_at((7 - u) & 7, RK[4]),                           \
-                  a_p1 = *ring_at((7 - u + 1) & 7, RK[5]), a_p2 = *ring_at((7 - u + 2) & 7, RK[6]);                       \
-    BASE_FMA(0, acc[0], acc[5], a_m1.x, a_0.x, vmv, y8)                                                                  \
-    BASE_FMA(1, acc[1], acc[6], a_m1.x, a_0.x, vmv, y8)                                                                  \
-    BASE_FMA(2, acc[2], acc[7], a_m1.x, a_0.x, vmv, y8)                                                                  \
-    BASE_FMA(3, acc[3], acc[8], a_m1.x, a_0.x, vmv, y8)                                                                  \
+    const double2 a_m4 = ring_at((7 - u - 4) & 7, RK[0]);                                                               \
+    const double2 a_m3 = ring_at((7 - u - 3) & 7, RK[1]), a_m2 = ring_at((7 - u - 2) & 7, RK[2]),                       \
+                  a_m1 = ring_at((7 - u - 1) & 7, RK[3]), a_0 = ring_at((7 - u) & 7, RK[4]),                           \
+                  a_p1 = ring_at((7 - u + 1) & 7, RK[5]), a_p2 = ring_at((7 - u + 2) & 7, RK[6]);                       \
+    BASE_FMAS(a_m1.x, a_0.x, vmv, y8)                                                                                    \
     ROW_SUMS_PLAIN(a_m3, a_m2, a_m1, a_0, a_p1, a_p2, vdv, hMv)                                                          \
     DEL3_FMA(acc[15], a_m4.x, a_m4.y, hMv, vdv, row, thr_x, thr_y)                                                       \
 }
@@ -860,7 +982,11 @@ __device__ __forceinline__ void sweep_read(const int L, const int n, const int r
                 } else {
                     if (in_band) {
                         KEEP_MASKED;
+#ifdef JTK_PHMM_X_NOEM
+                        const double eMv = jtk_bits_f64(0x3fd0000000000000ull | y8), eIv = jtk_bits_f64(0x3fd0000000000000ull | xrow);
+#else
                         const double eMv = lds_f64(xrow | y8), eIv = lds_f64(S_EI + byte);
+#endif
                         const double vm = fma(aMD, xd, fma(aMI, hI_1, aMM * xm));
                         const double vi = fma(aID, xd, fma(aII, hI_1, aIM * xm));
                         const double vd = fma(aDD, xd, fma(aDI, hI_1, aDM * xm));

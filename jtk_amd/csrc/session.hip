@@ -21,6 +21,7 @@
 #include <map>
 #include <functional>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -93,7 +94,11 @@ HmmDev to_dev(const jtk_hmm_t &h) {
 // freed before (the driver scrubs it) -- more than the kernels take.  Nothing relies on the contents of a fresh
 // block.  jtk_lc_trim_cache() returns everything to the driver.
 struct BlockPool {
-    static const size_t MIN_BYTES = 1u << 20;           // smaller blocks are not worth keeping
+    // Small blocks are kept too (round 6): a session holds ~40 of them (metadata, counters, offsets), hipFree of each one
+    // synchronises EVERY stream of the device, and the model refit creates ten sessions in a row.  Below 1 MiB a request is
+    // rounded up to a power of two (dev_alloc), so the few size classes match exactly.
+    static const size_t MIN_BYTES = 256;
+    static const size_t SMALL_BYTES = 1u << 20;
     // per device: JTK_LC_POOL_GB (default 32: the pool must not starve torch / RCCL / another library in the same process;
     // blocks beyond the cap go straight back to the driver), 0 disables pooling
     static size_t max_cached() {
@@ -111,7 +116,7 @@ struct BlockPool {
         std::lock_guard<std::mutex> lock(m);
         auto &b = blocks[dev];
         auto it = b.lower_bound(bytes);
-        if (it == b.end() || it->first > bytes + bytes / 4 + MIN_BYTES) return nullptr;
+        if (it == b.end() || it->first > bytes + bytes / 4 + (bytes < SMALL_BYTES ? 0 : SMALL_BYTES)) return nullptr;
         void *p = it->second;
         *cap = it->first;
         cached[dev] -= it->first;
@@ -275,6 +280,9 @@ struct jtk_lc_session {
     uint64_t wide_stride = 0;
     DevPtr d_wide_scratch, d_wide_counter;
     DevPtr d_state0;                     // pristine per-chunk state: a pass begins with a device-side copy of it
+    // the variable-length outputs of a fetch, packed on the device (io_kernels.hip): lengths per read / chunk, their prefix sums,
+    // the re-threaded ops and the consensus as the caller gets them; allocated by the first fetch that asks for them
+    DevPtr d_out_len, d_out_off, d_out_ops, d_out_cons;
     // host mirrors of the never-reset device ticket counters of the work queues (device_common.h): d_counter[0] phmm_kernel,
     // d_counter[1] phmm_pair_kernel, d_wide_counter[0] phmm_wide_kernel
     uint32_t tk_phmm = 0, tk_pair = 0, tk_wide = 0;
@@ -283,13 +291,17 @@ struct jtk_lc_session {
     hipEvent_t ev_round[2] = {nullptr, nullptr};
     // the chain launch: light / general chunk lists made on the device (mcmc_kernels.hip), the general kernel on its own stream
     DevPtr d_chain_split;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_chain[2] = {nullptr, nullptr};
+    hipStream_t side = nullptr, chain_main = nullptr;   // chain_main: experiment JTK_CHAIN_CUS (CU-masked chain streams)
+    hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr};
     ~jtk_lc_session() {
         if (stream) (void)hipStreamSynchronize(stream);  // blocks go back to the pool, not through hipFree's implicit sync
         if (side) {
             (void)hipStreamSynchronize(side);
             (void)hipStreamDestroy(side);
+        }
+        if (chain_main) {
+            (void)hipStreamSynchronize(chain_main);
+            (void)hipStreamDestroy(chain_main);
         }
         for (auto &e : ev_chain)
             if (e) (void)hipEventDestroy(e);
@@ -308,7 +320,12 @@ namespace {
 
 template <typename T>
 int dev_alloc(DevPtr &d, size_t count) {
-    const size_t bytes = (count ? count : 1) * sizeof(T);
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    if (bytes < BlockPool::SMALL_BYTES) {   // size classes for the small blocks (see BlockPool)
+        size_t cls = BlockPool::MIN_BYTES;
+        while (cls < bytes) cls <<= 1;
+        bytes = cls;
+    }
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev >= 0 && dev < JTK_POOL_DEVICES && bytes >= BlockPool::MIN_BYTES) {
@@ -396,7 +413,7 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
     s->h_chunks.resize(n_chunks);
     s->h_reads.resize(n_reads);
     s->h_state0.resize(n_chunks);
-    std::vector<uint8_t> h_tmpl, h_ops, h_ey;
+    std::vector<uint8_t> h_tmpl;
     std::vector<uint32_t> h_opslen(n_reads);
     std::vector<uint64_t> h_homop_off(n_chunks), h_aux_off(n_chunks), h_lg_off(n_chunks);
     uint64_t tmpl_off = 0, ops_cap_off = 0, ey_off = 0, delta_off = 0, table_off = 0, raw_off = 0, row_off = 0,
@@ -485,58 +502,24 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         aux_off += (uint64_t)3 * H * (ch.n_reads + 1) + (ch.n_reads + 1) + (JTK_MAX_COPY + 2);
         lg_off += (uint64_t)ch.n_reads * (JTK_MAX_COPY + 1);
     }
-    // ---- per-base encoding (2-bit template codes, read codes with their context, op validation): the layout above
-    //      fixed every offset, so the chunks are encoded side by side on the host's cores
+    // ---- per-base encoding.  Templates (a few MB) are recoded here; the reads and their ops -- the bulk of a stage call's input --
+    //      cross the bus as the caller holds them and are validated and recoded by encode_reads_kernel (io_kernels.hip), below.
     h_tmpl.assign(tmpl_off, 0);
-    h_ey.assign(ey_off, 0);
-    h_ops.assign(ops_cap_off, 0);
     {
-        std::atomic<int> bad(0);
-        std::atomic<size_t> next(0);
-        auto encode = [&]() {
-            for (size_t c = next.fetch_add(1); c < n_chunks && !bad.load(std::memory_order_relaxed); c = next.fetch_add(1)) {
-                const jtk_lc_chunk_t &ch = chunks[c];
-                const ChunkMeta &cm = s->h_chunks[c];
-                for (uint64_t p = 0; p < ch.tmpl_len; p++) {
-                    const int code = base_code(tmpl_bases[ch.tmpl_off + p]);
-                    if (code < 0) bad = 1;
-                    h_tmpl[cm.tmpl_off + p] = (uint8_t)(code & 3);
-                }
-                for (uint32_t r = 0; r < ch.n_reads; r++) {
-                    const uint64_t g = cm.read_first + r;
-                    const ReadMeta &rm = s->h_reads[g];
-                    const uint8_t *rb = read_bases + read_off[g];
-                    uint8_t *ey = h_ey.data() + rm.ey_off;
-                    int prev = 4;
-                    for (uint32_t j = 0; j < rm.read_len; j++) {
-                        const int code = base_code(rb[j]);
-                        if (code < 0) bad = 2;
-                        ey[j + 1] = (uint8_t)((code & 3) | (prev << 2));
-                        prev = code & 3;
-                    }
-                    const uint8_t *src = ops + ops_off[g];
-                    uint8_t *dst = h_ops.data() + rm.ops_off;
-                    uint8_t worst = 0;
-                    for (uint32_t k = 0; k < h_opslen[g]; k++) {
-                        dst[k] = src[k];
-                        worst |= src[k];
-                    }
-                    if (worst > JTK_OP_DEL) bad = 3;   // op codes are 0..3
-                }
+        int bad = 0;
+        for (size_t c = 0; c < n_chunks; c++) {
+            const jtk_lc_chunk_t &ch = chunks[c];
+            const ChunkMeta &cm = s->h_chunks[c];
+            for (uint64_t p = 0; p < ch.tmpl_len; p++) {
+                const int code = base_code(tmpl_bases[ch.tmpl_off + p]);
+                if (code < 0) bad = 1;
+                h_tmpl[cm.tmpl_off + p] = (uint8_t)(code & 3);
             }
-        };
-        const unsigned hw = std::thread::hardware_concurrency();
-        const size_t n_workers = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), std::max<size_t>(n_chunks / 16, 1));
-        std::vector<std::thread> workers;
-        for (size_t w = 1; w < n_workers; w++) workers.emplace_back(encode);
-        encode();
-        for (auto &w : workers) w.join();
+        }
         if (bad == 1) return fail(JTK_ERR_INVALID_ARG, "non-ACGT base in a template");
-        if (bad == 2) return fail(JTK_ERR_INVALID_ARG, "non-ACGT base in a read");
-        if (bad == 3) return fail(JTK_ERR_INVALID_ARG, "bad op code");
     }
     s->tmpl_bytes = h_tmpl.size();
-    s->ops_bytes = h_ops.size();
+    s->ops_bytes = ops_cap_off;
     if (s->has_split) {  // the sub-problems of the split branch are encoded from these again
         s->h_read_bases.assign(read_bases, read_bases + read_off[n_reads]);
         s->h_read_off.assign(read_off, read_off + n_reads + 1);
@@ -638,19 +621,48 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
     if ((rc = dev_upload(s, s->d_reads, s->h_reads))) return rc;
     if ((rc = dev_alloc<ChunkState>(s->d_state, n_chunks))) return rc;
     if ((rc = dev_upload(s, s->d_tmpl_init, h_tmpl))) return rc;
-    if ((rc = dev_upload(s, s->d_ops_init, h_ops))) return rc;
+    if ((rc = dev_alloc<uint8_t>(s->d_ops_init, ops_cap_off))) return rc;
     if ((rc = dev_upload(s, s->d_opslen_init, h_opslen))) return rc;
     // (+8: the polish kernels fetch templates / reads in aligned 8-byte blocks)
     if ((rc = dev_alloc<uint8_t>(s->d_tmpl0, h_tmpl.size() + 8))) return rc;
     if ((rc = dev_alloc<uint8_t>(s->d_tmpl1, h_tmpl.size() + 8))) return rc;
-    if ((rc = dev_alloc<uint8_t>(s->d_ops0, h_ops.size()))) return rc;
-    if ((rc = dev_alloc<uint8_t>(s->d_ops1, h_ops.size()))) return rc;
+    if ((rc = dev_alloc<uint8_t>(s->d_ops0, ops_cap_off))) return rc;
+    if ((rc = dev_alloc<uint8_t>(s->d_ops1, ops_cap_off))) return rc;
     if ((rc = dev_alloc<uint32_t>(s->d_opslen0, n_reads))) return rc;
     if ((rc = dev_alloc<uint32_t>(s->d_opslen1, n_reads))) return rc;
-    h_ey.resize(h_ey.size() + 8, 0);
-    if ((rc = dev_upload(s, s->d_ey, h_ey))) return rc;
+    if ((rc = dev_alloc<uint8_t>(s->d_ey, ey_off + 8))) return rc;
+    HIP_TRY(hipMemsetAsync(s->d_ey.as<uint8_t>() + ey_off, 0, 8, s->stream));   // (the polish kernels fetch aligned 8-byte blocks)
     if ((rc = dev_alloc<uint64_t>(s->d_delta, delta_off))) return rc;
     if ((rc = dev_alloc<double>(s->d_raw, raw_off))) return rc;
+    if (n_reads) {
+        // The reads and their ops, as the caller holds them (ASCII bases, one op per byte, back to back), straight from the
+        // caller's memory into the workspace the row sums will occupy later (296 KB per read against ~4 KB of input), then
+        // validated and recoded on the device: no recoded copy on the host, no first-touch of fresh host vectors.
+        const uint64_t rb0 = read_off[0], rb_bytes = read_off[n_reads] - rb0, ob0 = ops_off[0], ob_bytes = ops_off[n_reads] - ob0;
+        const uint64_t o_bases = 0, o_ops = (rb_bytes + 15) & ~15ull, o_boff = o_ops + ((ob_bytes + 15) & ~15ull),
+                       o_ooff = o_boff + (n_reads + 1) * 8, o_flag = o_ooff + (n_reads + 1) * 8, need = o_flag + 16;
+        DevPtr tmp;   // (only when the row sums' block is too small for it: pile-ups of very short templates)
+        uint8_t *stage = s->d_raw.as<uint8_t>();
+        if (need > raw_off * 8) {
+            if ((rc = dev_alloc<uint8_t>(tmp, need))) return rc;
+            stage = tmp.as<uint8_t>();
+        }
+        HIP_TRY(hipMemsetAsync(stage + o_flag, 0, 16, s->stream));
+        if (rb_bytes) HIP_TRY(hipMemcpyAsync(stage + o_bases, read_bases + rb0, rb_bytes, hipMemcpyHostToDevice, s->stream));
+        if (ob_bytes) HIP_TRY(hipMemcpyAsync(stage + o_ops, ops + ob0, ob_bytes, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(stage + o_boff, read_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(stage + o_ooff, ops_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, s->stream));
+        launch_encode_reads(s->stream, (uint32_t)n_reads, s->d_reads.as<ReadMeta>(), stage + o_bases,
+                            reinterpret_cast<const uint64_t *>(stage + o_boff), stage + o_ops,
+                            reinterpret_cast<const uint64_t *>(stage + o_ooff), s->d_ey.as<uint8_t>(), s->d_ops_init.as<uint8_t>(),
+                            reinterpret_cast<uint32_t *>(stage + o_flag));
+        uint32_t flags = 0;
+        HIP_TRY(hipMemcpyAsync(&flags, stage + o_flag, 4, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));   // (also: `tmp` may go back to the pool)
+        HIP_TRY(hipGetLastError());
+        if (flags & 2u) return fail(JTK_ERR_INVALID_ARG, "non-ACGT base in a read");
+        if (flags & 4u) return fail(JTK_ERR_INVALID_ARG, "bad op code");
+    }
     if ((rc = dev_alloc<int>(s->d_rawG, row_off))) return rc;
     if ((rc = dev_alloc<double>(s->d_lk, n_reads))) return rc;
     (void)table_off;  // no buffer of its own: the tables live where the row sums were (d_raw)
@@ -668,6 +680,24 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         const char *force = getenv("JTK_LC_SIDE_STREAM");
         const bool on = force ? atoi(force) != 0 : (g_queues_by_library || g_host_queues >= 8);
         if (on) {
+            // experiment (JTK_CHAIN_CUS=n): the chain's two kernels on streams confined to n CUs, so that their long-lived
+            // waves do not take wave slots all over the device (the light kernel then runs on `chain_main`, the general one on `side`)
+            static const int chain_cus = getenv("JTK_CHAIN_CUS") ? atoi(getenv("JTK_CHAIN_CUS")) : 0;
+            if (chain_cus > 0) {
+                hipDeviceProp_t prop;
+                HIP_TRY(hipGetDeviceProperties(&prop, device));
+                const int n_cu = prop.multiProcessorCount;
+                std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+                static const int spread = getenv("JTK_CHAIN_CUS_SPREAD") ? atoi(getenv("JTK_CHAIN_CUS_SPREAD")) : 1;
+                for (int k = 0; k < chain_cus && k < n_cu; k++) {
+                    const int cu = spread ? (int)((int64_t)k * n_cu / chain_cus) : k;   // spread over the device, or the first n
+                    mask[cu / 32] |= 1u << (cu % 32);
+                }
+                HIP_TRY(hipExtStreamCreateWithCUMask(&s->side, (uint32_t)mask.size(), mask.data()));
+                HIP_TRY(hipExtStreamCreateWithCUMask(&s->chain_main, (uint32_t)mask.size(), mask.data()));
+                HIP_TRY(hipEventCreateWithFlags(&s->ev_chain[2], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&s->ev_chain[3], hipEventDisableTiming));
+            } else
             HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&s->ev_chain[0], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&s->ev_chain[1], hipEventDisableTiming));
@@ -914,9 +944,18 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
     tstop(s);
     tstart(s, JTK_K_MCMC);
     int mcmc_rc = 0;
+    hipStream_t st_main = st;
+    if (s->chain_main) {   // (experiment) the chain on its CU-masked stream: fork here, join after the launches
+        HIP_TRY(hipEventRecord(s->ev_chain[2], st));
+        HIP_TRY(hipStreamWaitEvent(s->chain_main, s->ev_chain[2], 0));
+        st = s->chain_main;
+    }
+    // measurement only (scripts/overlap_probe_r6.sh): a pass without its chain kernels -- what the chain's share of the CUs' LDS
+    // and issue slots costs the pair-HMM family when slices overlap.  Labels / posteriors are then whatever the buffers held.
+    static const bool x_nochain = getenv("JTK_X_NOCHAIN") != nullptr;
     for (int j = 0; j < 2; j++) {
         const ChainClass &cc = s->chain_class[j];
-        if (cc.count == 0 || mcmc_rc != 0) continue;
+        if (cc.count == 0 || mcmc_rc != 0 || x_nochain) continue;
         // the class's own stretch of the split scratch: 2 + 2 * count words from 2 * first + 4 * j
         mcmc_rc = launch_mcmc(st, cc.count, chunks, state, s->d_params.as<jtk_lc_params_t>(), s->d_feat.as<double>(),
                               s->d_vtype.as<uint32_t>(), nullptr, 0, s->d_label.as<uint32_t>(), s->d_post.as<double>(),
@@ -924,13 +963,18 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                               s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr, s->d_order.as<uint32_t>() + cc.first,
                               s->d_chain_split.as<uint32_t>() + 2 * cc.first + 4 * j, s->side, s->ev_chain[0], s->ev_chain[1]);
     }
-    if (s->chain_class[2].count && mcmc_rc == 0) {
+    if (s->chain_class[2].count && mcmc_rc == 0 && !x_nochain) {
         const ChainClass &cc = s->chain_class[2];
         mcmc_rc = launch_mcmc_huge(st, cc.count, chunks, state, s->d_params.as<jtk_lc_params_t>(), s->d_feat.as<double>(),
                                    s->d_vtype.as<uint32_t>(), nullptr, 0, s->d_label.as<uint32_t>(), s->d_post.as<double>(),
                                    s->post_stride, s->d_lg.as<double>(), s->d_lg_off.as<uint64_t>(), cc.lds_n, cc.lds_d, cc.lds_k,
                                    s->resume_rng ? s->d_rng.as<uint64_t>() : nullptr, s->d_order.as<uint32_t>() + cc.first,
                                    s->d_chain_ws.as<uint8_t>(), s->d_chain_ws_off.as<uint64_t>());
+    }
+    if (s->chain_main) {
+        HIP_TRY(hipEventRecord(s->ev_chain[3], s->chain_main));
+        HIP_TRY(hipStreamWaitEvent(st_main, s->ev_chain[3], 0));
+        st = st_main;
     }
     tstop(s);
     if (mcmc_rc != 0) {
@@ -980,60 +1024,51 @@ int jtk_lc_debug_chain_profile(jtk_lc_session_t *s, uint64_t *cycles, uint32_t *
     return JTK_OK;
 }
 
-int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post, jtk_lc_result_t *result,
-                         uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out,
-                         uint64_t *ops_out_off, uint64_t ops_cap) {
-    g_last_error.clear();
-    if (!s) return fail(JTK_ERR_INVALID_ARG, "null session");
+// A fetch in two halves, so that the slices of a one-shot call can write their variable-length outputs straight into the
+// caller's arrays: fetch_begin copies the fixed-size results (labels, posteriors, per-chunk records) and learns the lengths of the
+// variable ones; the caller then says where this session's consensus / ops start (one-shot slices: after the previous slice's),
+// and fetch_finish packs them on the device (gather_kernel) and copies exactly those bytes to their final place.  Until round 5
+// every buffer set some chunk's result lived in was downloaded whole into fresh host vectors (up to 3 x the ops + templates of the
+// batch) and unpacked base by base on the host.
+namespace {
+struct FetchPlan {
+    std::vector<ChunkState> state;
+    std::vector<uint32_t> len;      // n_reads ops lengths, then n_chunks consensus lengths
+    uint64_t cons_total = 0, ops_total = 0;
+    bool want_cons = false, want_ops = false;
+    int any_fail = 0;
+    hipEvent_t ev0 = nullptr;
+};
+
+int fetch_begin(jtk_lc_session_t *s, FetchPlan &pl, uint32_t *label, double *log_post, jtk_lc_result_t *result, bool want_cons,
+                bool want_ops) {
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = s->stream;
-    hipEvent_t ev0, ev1;
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipEventRecord(ev0, st));
-    std::vector<ChunkState> state(s->n_chunks);
-    HIP_TRY(hipMemcpyAsync(state.data(), s->d_state.p, state.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventCreate(&pl.ev0));
+    HIP_TRY(hipEventRecord(pl.ev0, st));
+    pl.want_cons = want_cons;
+    pl.want_ops = want_ops;
+    pl.state.resize(s->n_chunks);
+    HIP_TRY(hipMemcpyAsync(pl.state.data(), s->d_state.p, pl.state.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
+    if (want_cons || want_ops) {
+        if (!s->d_out_len.p) {
+            int rc;
+            if ((rc = dev_alloc<uint32_t>(s->d_out_len, (size_t)s->n_reads + s->n_chunks))) return rc;
+            if ((rc = dev_alloc<uint64_t>(s->d_out_off, (size_t)s->n_reads + s->n_chunks + 2))) return rc;
+        }
+        pl.len.resize((size_t)s->n_reads + s->n_chunks);
+        launch_out_len(st, s->n_reads, s->n_chunks, s->d_reads.as<ReadMeta>(), s->d_state.as<ChunkState>(), s->bufs,
+                       s->d_out_len.as<uint32_t>(), s->d_out_len.as<uint32_t>() + s->n_reads);
+        if (!pl.len.empty())
+            HIP_TRY(hipMemcpyAsync(pl.len.data(), s->d_out_len.p, pl.len.size() * 4, hipMemcpyDeviceToHost, st));
+    }
     if (label) HIP_TRY(hipMemcpyAsync(label, s->d_label.p, (size_t)s->n_reads * 4, hipMemcpyDeviceToHost, st));
     if (log_post)
         HIP_TRY(hipMemcpyAsync(log_post, s->d_post.p, (size_t)s->n_reads * s->post_stride * 8, hipMemcpyDeviceToHost, st));
-    // the three buffer sets (DevBufs): a chunk's result lives in the set its state names (0 = never edited).  Only the sets
-    // some chunk's result lives in cross the bus (the states first: 40 bytes per chunk)
-    std::vector<uint8_t> tb[3], ob[3];
-    std::vector<uint32_t> lb[3];
-    const bool want_cons = cons_out && cons_off, want_ops = ops_out && ops_out_off;
-    bool set_used[3] = {false, false, false};
-    if (want_cons || want_ops) {
-        HIP_TRY(hipStreamSynchronize(st));
-        for (const ChunkState &cs : state)
-            if (cs.status == 0) set_used[cs.buf % 3] = true;
-    }
-    for (int b = 0; b < 3; b++) {
-        if (!set_used[b]) continue;
-        if (want_cons) {
-            tb[b].resize(s->tmpl_bytes);
-            HIP_TRY(hipMemcpyAsync(tb[b].data(), s->bufs.tmpl[b], s->tmpl_bytes, hipMemcpyDeviceToHost, st));
-        }
-        if (want_ops) {
-            ob[b].resize(s->ops_bytes);
-            lb[b].resize(s->n_reads);
-            HIP_TRY(hipMemcpyAsync(ob[b].data(), s->bufs.ops[b], s->ops_bytes, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(lb[b].data(), s->bufs.ops_len[b], (size_t)s->n_reads * 4, hipMemcpyDeviceToHost, st));
-        }
-    }
-    HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ev0, ev1);
-    g_timing.d2h_ms = ms;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    int any_fail = 0;
-    static const char BASES[] = "ACGT";
-    uint64_t co = 0, oo = 0;
     for (uint32_t c = 0; c < s->n_chunks; c++) {
-        const ChunkState &cs = state[c];
-        const ChunkMeta &cm = s->h_chunks[c];
-        if (cs.status != 0) any_fail = 1;
+        const ChunkState &cs = pl.state[c];
+        if (cs.status != 0) pl.any_fail = 1;
         if (result) {
             result[c].score = cs.status == 0 ? cs.score : 0.0;
             result[c].cluster_num = cs.status == 0 ? cs.k : 1;
@@ -1041,31 +1076,68 @@ int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post,
             result[c].polish_rounds = cs.rounds;
             result[c].n_variants = cs.dim;
         }
-        if (want_cons) {
-            cons_off[c] = co;
-            if (cs.status == 0) {
-                if (co + cs.tmpl_len > cons_cap) return fail(JTK_ERR_INVALID_ARG, "cons_cap too small");
-                const uint8_t *src = tb[cs.buf % 3].data() + cm.tmpl_off;
-                for (uint32_t p = 0; p < cs.tmpl_len; p++) cons_out[co + p] = (uint8_t)BASES[src[p] & 3];
-                co += cs.tmpl_len;
-            }
-        }
-        if (want_ops) {
-            for (uint32_t r = 0; r < cm.n_reads; r++) {
-                const uint32_t g = cm.read_first + r;
-                ops_out_off[g] = oo;
-                if (cs.status == 0) {
-                    const uint32_t len = lb[cs.buf % 3][g];
-                    if (oo + len > ops_cap) return fail(JTK_ERR_INVALID_ARG, "ops_cap too small");
-                    memcpy(ops_out + oo, ob[cs.buf % 3].data() + s->h_reads[g].ops_off, len);
-                    oo += len;
-                }
-                ops_out_off[g + 1] = oo;
-            }
-        }
     }
-    if (want_cons) cons_off[s->n_chunks] = co;
-    // chunks that went through clustering_recursive's split: the merged clustering replaces the first pass's
+    if (want_ops)
+        for (uint32_t g = 0; g < s->n_reads; g++) pl.ops_total += pl.len[g];
+    if (want_cons)
+        for (uint32_t c = 0; c < s->n_chunks; c++) pl.cons_total += pl.len[s->n_reads + c];
+    return 0;
+}
+
+// cons_out / ops_out: the caller's arrays; cons_off / ops_out_off: the entries of THIS session's chunks / reads (n_chunks + 1 and
+// n_reads + 1 of them are written); cons_base / ops_base: where this session's bytes start inside the arrays
+int fetch_finish(jtk_lc_session_t *s, FetchPlan &pl, uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_base, uint64_t cons_cap,
+                 uint8_t *ops_out, uint64_t *ops_out_off, uint64_t ops_base, uint64_t ops_cap) {
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = s->stream;
+    if (pl.want_cons && cons_base + pl.cons_total > cons_cap) return fail(JTK_ERR_INVALID_ARG, "cons_cap too small");
+    if (pl.want_ops && ops_base + pl.ops_total > ops_cap) return fail(JTK_ERR_INVALID_ARG, "ops_cap too small");
+    if (pl.want_cons || pl.want_ops) {
+        // offsets local to the session (the device packs from 0), written to the caller's arrays with the base added
+        std::vector<uint64_t> off((size_t)s->n_reads + s->n_chunks + 2);
+        uint64_t *ooff = off.data(), *coff = off.data() + s->n_reads + 1;
+        uint64_t oo = 0, co = 0;
+        for (uint32_t g = 0; g < s->n_reads; g++) {
+            ooff[g] = oo;
+            oo += pl.want_ops ? pl.len[g] : 0;
+        }
+        ooff[s->n_reads] = oo;
+        for (uint32_t c = 0; c < s->n_chunks; c++) {
+            coff[c] = co;
+            co += pl.want_cons ? pl.len[s->n_reads + c] : 0;
+        }
+        coff[s->n_chunks] = co;
+        int rc;
+        if (pl.want_ops && !s->d_out_ops.p && (rc = dev_alloc<uint8_t>(s->d_out_ops, s->ops_bytes + 8))) return rc;
+        if (pl.want_cons && !s->d_out_cons.p && (rc = dev_alloc<uint8_t>(s->d_out_cons, s->tmpl_bytes + 8))) return rc;
+        HIP_TRY(hipMemcpyAsync(s->d_out_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, st));
+        launch_gather(st, s->n_reads, s->n_chunks, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), s->d_state.as<ChunkState>(),
+                      s->bufs, s->d_out_off.as<uint64_t>(), s->d_out_off.as<uint64_t>() + s->n_reads + 1,
+                      pl.want_ops ? s->d_out_ops.as<uint8_t>() : nullptr, pl.want_cons ? s->d_out_cons.as<uint8_t>() : nullptr);
+        if (pl.want_ops && oo) HIP_TRY(hipMemcpyAsync(ops_out + ops_base, s->d_out_ops.p, oo, hipMemcpyDeviceToHost, st));
+        if (pl.want_cons && co) HIP_TRY(hipMemcpyAsync(cons_out + cons_base, s->d_out_cons.p, co, hipMemcpyDeviceToHost, st));
+        if (pl.want_ops)
+            for (uint32_t g = 0; g <= s->n_reads; g++) ops_out_off[g] = ops_base + ooff[g];
+        if (pl.want_cons)
+            for (uint32_t c = 0; c <= s->n_chunks; c++) cons_off[c] = cons_base + coff[c];
+    }
+    hipEvent_t ev1;
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, pl.ev0, ev1);
+    g_timing.d2h_ms = ms;
+    (void)hipEventDestroy(pl.ev0);
+    (void)hipEventDestroy(ev1);
+    pl.ev0 = nullptr;
+    return 0;
+}
+
+// chunks that went through clustering_recursive's split: the merged clustering replaces the first pass's
+int fetch_split_results(jtk_lc_session_t *s, uint32_t *label, double *log_post, jtk_lc_result_t *result) {
+    int any_fail = 0;
     for (uint32_t c = 0; c < s->n_chunks && c < s->split.size(); c++) {
         const SplitResult &sr = s->split[c];
         if (sr.k == 0) continue;
@@ -1084,6 +1156,21 @@ int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post,
                     log_post[(size_t)g * s->post_stride + t] = (sr.status == 0 && t < sr.k) ? sr.post[(size_t)r * sr.k + t] : 0.0;
         }
     }
+    return any_fail;
+}
+}  // namespace
+
+int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double *log_post, jtk_lc_result_t *result,
+                         uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out,
+                         uint64_t *ops_out_off, uint64_t ops_cap) {
+    g_last_error.clear();
+    if (!s) return fail(JTK_ERR_INVALID_ARG, "null session");
+    FetchPlan pl;
+    int rc = fetch_begin(s, pl, label, log_post, result, cons_out && cons_off, ops_out && ops_out_off);
+    if (rc == 0) rc = fetch_finish(s, pl, cons_out, cons_off, 0, cons_cap, ops_out, ops_out_off, 0, ops_cap);
+    if (pl.ev0) (void)hipEventDestroy(pl.ev0);
+    if (rc) return rc;
+    const int any_fail = pl.any_fail | fetch_split_results(s, label, log_post, result);
     return any_fail ? fail(JTK_ERR_CHUNK_FAILED, "at least one chunk failed; see result[].status") : 0;
 }
 
@@ -1474,49 +1561,74 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
         }
     }
     const bool want_cons = cons_out && cons_off, want_ops = ops_out && ops_out_off;
+    // Every slice writes its results straight into the caller's arrays.  Where a slice's consensus / ops start depends on the
+    // lengths of the slices before it: a slice learns its own lengths (fetch_begin), waits for its predecessor to publish where it
+    // ends, publishes its own end and only then packs and copies (fetch_finish) -- no per-slice staging vectors, no stitching pass.
     struct Slice {
         std::vector<jtk_lc_chunk_t> chunks;
-        std::vector<uint8_t> cons, ops;
-        std::vector<uint64_t> cons_off, ops_off;
         int rc = 0;
         std::string error;
         jtk_lc_timing_t timing;
     };
     std::vector<Slice> slices(n_slices);
     std::vector<std::function<void()>> jobs(n_slices);
+    std::mutex base_mutex;
+    std::condition_variable base_cv;
+    std::vector<uint64_t> cons_base(n_slices + 1, 0), ops_base(n_slices + 1, 0);
+    std::vector<char> base_known(n_slices + 1, 0);
+    base_known[0] = 1;
     for (size_t sl = 0; sl < n_slices; sl++) {
         Slice &S = slices[sl];
         const size_t c0 = first[sl], c1 = first[sl + 1];
         memset(&S.timing, 0, sizeof S.timing);
-        if (c0 >= c1) continue;
-        const uint64_t r0 = chunks[c0].read_first, r1 = chunks[c1 - 1].read_first + chunks[c1 - 1].n_reads;
-        S.chunks.assign(chunks + c0, chunks + c1);
-        uint64_t cons_need = 64, ops_need = 64;
-        for (auto &ch : S.chunks) {
-            ch.read_first -= r0;
-            cons_need += ch.tmpl_len + ch.tmpl_len / 4 + 64;
-            ops_need += (uint64_t)ch.n_reads * (ch.tmpl_len / 4 + 72);
-        }
-        ops_need += ops_off[r1] - ops_off[r0];
-        if (want_cons) {
-            S.cons.resize(cons_need);
-            S.cons_off.resize(c1 - c0 + 1);
-        }
-        if (want_ops) {
-            S.ops.resize(ops_need);
-            S.ops_off.resize(r1 - r0 + 1);
+        const uint64_t r0 = c0 < c1 ? chunks[c0].read_first : n_reads;
+        const uint64_t r1 = c0 < c1 ? chunks[c1 - 1].read_first + chunks[c1 - 1].n_reads : n_reads;
+        if (c0 < c1) {
+            S.chunks.assign(chunks + c0, chunks + c1);
+            for (auto &ch : S.chunks) ch.read_first -= r0;
         }
         const int device = devices[std::min(sl / slices_per_dev, n_devices - 1)];
-        jobs[sl] = ([=, &S]() {
-            S.rc = run_slice(params, c1 - c0, S.chunks.data(), tmpl_bases, read_bases, read_off + r0, ops, ops_off + r0,
-                             strand + r0, skip_polish, label + r0, log_post + r0 * post_stride, post_stride, result + c0,
-                             want_cons ? S.cons.data() : nullptr, want_cons ? S.cons_off.data() : nullptr, S.cons.size(),
-                             want_ops ? S.ops.data() : nullptr, want_ops ? S.ops_off.data() : nullptr, S.ops.size(), device);
+        jobs[sl] = ([=, &S, &base_mutex, &base_cv, &cons_base, &ops_base, &base_known]() {
+            jtk_lc_session_t *s = nullptr;
+            FetchPlan pl;
+            if (c0 < c1) {
+                S.rc = jtk_lc_session_create(params, c1 - c0, S.chunks.data(), tmpl_bases, read_bases, read_off + r0, ops, ops_off + r0,
+                                             strand + r0, post_stride, device, &s);
+                if (S.rc == 0) S.rc = jtk_lc_session_run(s, skip_polish);
+                if (S.rc == 0)
+                    S.rc = fetch_begin(s, pl, label + r0, log_post + r0 * post_stride, result + c0, want_cons, want_ops);
+            }
+            const bool ok = c0 < c1 && S.rc == 0;
+            uint64_t cb = 0, ob = 0;
+            {   // (also on failure: the slices behind this one are waiting for its end)
+                std::unique_lock<std::mutex> lock(base_mutex);
+                base_cv.wait(lock, [&]() { return base_known[sl] != 0; });
+                cb = cons_base[sl];
+                ob = ops_base[sl];
+                cons_base[sl + 1] = cb + (ok ? pl.cons_total : 0);
+                ops_base[sl + 1] = ob + (ok ? pl.ops_total : 0);
+                base_known[sl + 1] = 1;
+            }
+            base_cv.notify_all();
+            if (ok) {
+                S.rc = fetch_finish(s, pl, cons_out, want_cons ? cons_off + c0 : nullptr, cb, cons_cap, ops_out,
+                                    want_ops ? ops_out_off + r0 : nullptr, ob, ops_cap);
+                if (S.rc == 0 && (pl.any_fail | fetch_split_results(s, label + r0, log_post + r0 * post_stride, result + c0)))
+                    S.rc = fail(JTK_ERR_CHUNK_FAILED, "at least one chunk failed; see result[].status");
+            } else {   // nothing from this slice: its chunks and reads get empty ranges
+                if (want_cons)
+                    for (size_t c = c0; c <= c1 && c <= n_chunks; c++) cons_off[c] = cb;
+                if (want_ops)
+                    for (uint64_t g = r0; g <= r1; g++) ops_out_off[g] = ob;
+            }
+            if (pl.ev0) (void)hipEventDestroy(pl.ev0);
             S.error = g_last_error;   // thread-local in the slice's thread
             S.timing = g_timing;
+            if (s) jtk_lc_session_destroy(s);
         });
     }
-    {   // per device: per_dev worker threads take the device's slices in order
+    {   // per device: per_dev worker threads take the device's slices in order (a slice only ever waits for an EARLIER slice's
+        // lengths, and those are taken first: no cycle)
         std::vector<std::thread> threads;
         std::vector<std::atomic<size_t>> next(n_devices);
         for (size_t d = 0; d < n_devices; d++) next[d] = d * slices_per_dev;
@@ -1530,33 +1642,14 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
         }
         for (auto &t : threads) t.join();
     }
-    // stitch the variable-length outputs together in chunk order
     int rc = 0;
-    uint64_t co = 0, oo = 0;
     memset(&g_timing, 0, sizeof g_timing);
     for (size_t sl = 0; sl < n_slices; sl++) {
         Slice &S = slices[sl];
-        const size_t c0 = first[sl], c1 = first[sl + 1];
-        if (c0 >= c1) continue;
+        if (first[sl] >= first[sl + 1]) continue;
         if (S.rc != 0 && (rc == 0 || rc == JTK_ERR_CHUNK_FAILED)) {
             rc = S.rc;
             g_last_error = S.error;
-        }
-        if (S.rc != 0 && S.rc != JTK_ERR_CHUNK_FAILED) continue;
-        const uint64_t r0 = chunks[c0].read_first, nr = chunks[c1 - 1].read_first + chunks[c1 - 1].n_reads - r0;
-        if (want_cons) {
-            const uint64_t len = S.cons_off[c1 - c0];
-            if (co + len > cons_cap) return fail(JTK_ERR_INVALID_ARG, "cons_cap too small");
-            memcpy(cons_out + co, S.cons.data(), len);
-            for (size_t c = c0; c < c1; c++) cons_off[c] = co + S.cons_off[c - c0];
-            co += len;
-        }
-        if (want_ops) {
-            const uint64_t len = S.ops_off[nr];
-            if (oo + len > ops_cap) return fail(JTK_ERR_INVALID_ARG, "ops_cap too small");
-            memcpy(ops_out + oo, S.ops.data(), len);
-            for (uint64_t g = 0; g <= nr; g++) ops_out_off[r0 + g] = oo + S.ops_off[g];
-            oo += len;
         }
         g_timing.h2d_ms += S.timing.h2d_ms;
         g_timing.d2h_ms += S.timing.d2h_ms;
@@ -1567,7 +1660,6 @@ static int run_once(const jtk_lc_params_t *params, size_t n_chunks, const jtk_lc
             g_timing.kernel_launches[k] += S.timing.kernel_launches[k];
         }
     }
-    if (want_cons) cons_off[n_chunks] = co;
     return rc;
 }
 
