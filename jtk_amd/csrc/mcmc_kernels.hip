@@ -1868,6 +1868,8 @@ __device__ __attribute__((noinline)) double mcmc_chain_tab(LdsShape shape, uint3
 #define HW_REJ 512u
 #define HW_OUT 1024u
 #define HW_PERT 2048u
+#define HW_CROSS 4096u   // (round 6) the proposal ends in the NEXT block of 64 positions: bits 0..5 are its end there
+#define HW_SKIPX 8192u   // ... and is certainly rejected without a residue (== HW_SKIP << 7: never both)
 typedef __attribute__((address_space(3))) const volatile double lds_cvf64;
 typedef __attribute__((address_space(3))) const volatile u32x4_t lds_cvu32x4;
 typedef __attribute__((address_space(3))) volatile u32x4_t lds_vu32x4;
@@ -2102,27 +2104,37 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
             if (lane + 64 * r < n) *(lds_vu32x4 *)(uintptr_t)(tab_lds + ((lane + 64 * r) << 4)) = e;
         }
     };
-    // ---- the window
+    // ---- the window.  Round 6: a window is a BLOCK of 64 consecutive stream positions, and the next block follows at + 64 whatever
+    //      the proposals do (rounds 1-5: the next window started where the first proposal that did not end inside the window
+    //      began, so nothing of it could be fetched before the walk had got there).  A proposal that starts in a block and ends in
+    //      the next one is described by its own record like any other; its hop word carries HW_CROSS and, where it could have
+    //      been stepped over, HW_SKIPX instead of HW_SKIP: the walk stops at it, counts it and goes on in the next block.  The
+    //      records of the next block are requested a block ahead (r_next), and a block's look-up of its reads' entries is in
+    //      flight while its two logarithms are computed: of the ~1,100 cycles a window move cost (three dependent LDS round
+    //      trips and the arithmetic between them), the two round trips a lone wave can hide are hidden.
     uint32_t w_base = 0;          // stream position of lane 0
-    uint32_t w_idx = 0, w_w0 = 0; // per lane: the read the proposal starting here picks; nxt in bits 0..5 or HW_OUT
+    uint32_t w_idx = 0, w_w0 = 0; // per lane: the read the proposal starting here picks; its end (mod 64) | HW_CROSS, or HW_OUT
     float w_lrej = 0.0f, w_lacc = 0.0f;  // per lane: diff below w_lrej: certainly rejected; above w_lacc: certainly accepted
     uint32_t hopw = 0;
-    auto hop_words = [&]() {
-        const u32x4_t tv = *(lds_cvu32x4 *)(uintptr_t)(tab_lds + (w_idx << 4));
+    uint32_t r_next = 0;          // per lane: the record of position w_base + 64 + lane
+    uint32_t n_blocks = 0;        // (statistics build: windows loaded)
+    auto hop_finish = [&](const u32x4_t tv) {
         const float diff = __uint_as_float(tv.x);
-        hopw = w_w0 | tv.w | (diff < w_lrej ? tv.z : 0u) | (diff > w_lacc ? HW_ACC : 0u);
+        // (tv.y is always 0 (evaluate).  It is OR-ed in so that all four registers of the 16-byte load stay live until the entry is
+        // used: the compiler otherwise hands the dead one to the arithmetic that follows the load's issue, and the hardware then
+        // has to wait for the load before that arithmetic may start)
+        const uint32_t h = w_w0 | tv.w | tv.y | (diff < w_lrej ? tv.z : 0u) | (diff > w_lacc ? HW_ACC : 0u);
+        hopw = (h & HW_CROSS) ? ((h & ~HW_SKIP) | ((h & HW_SKIP) << 7)) : h;
     };
-    auto window_load = [&](uint32_t base) {
-        rng.pos = base;
-        rng_release(rng, lane);
-        rng_wait_rec(rng, base + 64);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        w_base = base;
-        const uint32_t r = *(lds_vu32 *)(uintptr_t)(rec_lds + (((base + lane) & rn_mask) << 2));
-        const uint32_t len = (r >> 7) & 63u, nxt = lane + len;
-        const bool in_w = len != 0 && nxt < 64;
+    auto hop_words = [&]() { hop_finish(*(lds_cvu32x4 *)(uintptr_t)(tab_lds + (w_idx << 4))); };
+    // the block whose records are `r`: per-lane registers and hop words (the entries of the block's reads are requested first,
+    // the thresholds are computed while they are on their way)
+    auto block_setup = [&](const uint32_t r) {
         w_idx = r & 127u;
-        w_w0 = in_w ? nxt : HW_OUT;
+        const u32x4_t tv = *(lds_cvu32x4 *)(uintptr_t)(tab_lds + (w_idx << 4));
+        const uint32_t len = (r >> 7) & 63u, nxt = lane + len;
+        const bool parsed = len != 0;
+        w_w0 = parsed ? ((nxt & 63u) | (nxt >= 64u ? HW_CROSS : 0u)) : HW_OUT;
         // The 19 known bits u of the Bernoulli draw (its true value / 2^64 lies in [u, u + 2^-19)) against exp(diff), in the
         // log domain, with guard bands far wider than the errors of the hardware logarithm (v_log_f32: 1 ulp of a number below
         // 100, then one multiplication: < 2e-5) and of diff's rounding to f32 (< 3e-6 where a threshold can lie):
@@ -2132,8 +2144,31 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
         const float u = (float)(r >> 13) * 0x1p-19f;
         const float lr = __builtin_amdgcn_logf(fmaxf(u - 1.3e-6f, 1e-30f)) * 0.6931472f - 2e-3f;  // (operands are normal numbers)
         const float la = __builtin_amdgcn_logf(u + (0x1p-19f + 3e-7f)) * 0.6931472f + 2e-3f;
-        w_lrej = in_w ? fmaxf(lr, -44.39f) : -__builtin_inff();
-        w_lacc = in_w ? la : __builtin_inff();
+        w_lrej = parsed ? fmaxf(lr, -44.39f) : -__builtin_inff();
+        w_lacc = parsed ? la : __builtin_inff();
+        hop_finish(tv);
+    };
+    // the records of [base, base + 128) exist and may not be overwritten
+    auto block_claim = [&](uint32_t base) {
+        rng.pos = base;
+        rng_release(rng, lane);
+        rng_wait_rec(rng, base + 128);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        w_base = base;
+    };
+    auto block_first = [&](uint32_t base) {   // the chain's first block, or the one behind a proposal with scalar draws that went far
+        block_claim(base);
+        const uint32_t r = *(lds_vu32 *)(uintptr_t)(rec_lds + (((base + lane) & rn_mask) << 2));
+        r_next = *(lds_vu32 *)(uintptr_t)(rec_lds + (((base + 64u + lane) & rn_mask) << 2));
+        block_setup(r);
+        n_blocks++;
+    };
+    auto block_advance = [&]() {              // on to the block at w_base + 64: its records came in while this one was walked
+        block_claim(w_base + 64u);
+        const uint32_t r = r_next;
+        r_next = *(lds_vu32 *)(uintptr_t)(rec_lds + (((w_base + 64u + lane) & rn_mask) << 2));
+        block_setup(r);
+        n_blocks++;
     };
     double max = lk;
     unsigned long long argmax[NR];
@@ -2142,23 +2177,16 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
     evaluate();
     const uint32_t total = 2000u * n;
     uint32_t t = 0, p = 0;
-    uint32_t load_at = rng.pos, need_load = 1;
     uint32_t n_events = 0;  // (reported per chunk: jtk_lc_debug_chain_profile)
     ST_T0();
+    block_first(rng.pos);
     for (;;) {
-        // ---- the walk, across windows, up to the next proposal that cannot be skipped.  An inner loop of its own: it
+        // ---- the walk, across blocks, up to the next proposal that cannot be skipped.  An inner loop of its own: it
         //      writes the window's registers and nothing of the chain's state, so the event below meets the back edge
         //      without a block of register moves between them.
         uint32_t hv = 0;
         bool done = false;
         for (;;) {
-            if (need_load) {
-                window_load(load_at);
-                hop_words();
-                p = 0;
-                need_load = 0;
-                ST_CNT(6, 1);
-            }
             if (t >= total) {
                 done = true;
                 break;
@@ -2168,9 +2196,10 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
                 done = true;
                 break;
             }
-            if (!((hv & HW_OUT) && p != 0)) break;
-            load_at = w_base + p;  // the proposal at p does not end inside this window: move the window there
-            need_load = 1;
+            if (!(hv & HW_SKIPX)) break;
+            t++;             // certainly rejected, nothing left behind, ends in the next block: counted, and the walk goes on there
+            p = hv & 63u;
+            block_advance();
         }
         if (done) break;
 #ifdef JTK_MCMC_STATS
@@ -2180,11 +2209,11 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
         uint32_t e_idx, pos_v;  // the read it picks; stream position of the draw a Bernoulli test would compare
         if (!(hv & HW_OUT)) {
             e_idx = uni((uint32_t)__builtin_amdgcn_readlane((int)w_idx, (int)p));
-            pos_v = w_base + (hv & 63u) - 1;
+            pos_v = w_base + (hv & 63u) + ((hv & HW_CROSS) ? 64u : 0u) - 1;
         } else {
-            // not even at the window start: the producer could not parse this one (it needs more look-ahead than a window
-            // has, p ~ 2^-14).  Scalar draws and the exact Bernoulli test; the window is reloaded behind it.
-            scalar_proposal(rng, w_base, n, e_idx, pos_v);
+            // the producer could not parse this one (it needs more look-ahead than it has, p ~ 2^-14): scalar draws and the
+            // exact Bernoulli test
+            scalar_proposal(rng, w_base + p, n, e_idx, pos_v);
             const u32x4_t tv = *(lds_cvu32x4 *)(uintptr_t)(tab_lds + (e_idx << 4));
             hv = HW_OUT | uni(tv.w);
         }
@@ -2267,11 +2296,15 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
         ST_MARK(12);
         if (moved) evaluate();
         ST_MARK(13);
-        if ((hv & HW_OUT) || pos_next - w_base >= 64) {
-            load_at = pos_next;
-            need_load = 1;
+        const uint32_t off_next = pos_next - w_base;
+        if (off_next >= 128u) {        // (only behind scalar draws that went on for more than a block)
+            block_first(pos_next);
+            p = 0;
+        } else if (off_next >= 64u) {  // the entries are up to date (evaluate above): the new block's hop words are made from them
+            p = off_next - 64u;
+            block_advance();
         } else {
-            p = pos_next - w_base;
+            p = off_next;
             if (moved) hop_words();
         }
         ST_MARK(14);
@@ -2280,6 +2313,7 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
 #endif
     }
     ST_CNT(5, total);
+    ST_CNT(6, n_blocks);
     ST_ADD(0);
     if (lane == 0) m.k2_stats[16] += n_events;
     rng.pos = w_base + p;

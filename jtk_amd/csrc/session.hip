@@ -187,6 +187,49 @@ struct StripePool {
 std::mutex g_stripe_mutex;
 std::shared_ptr<StripePool> g_stripes[JTK_POOL_DEVICES];
 
+// The pair-HMM gate (round 6).  A pass of a batch is two phases with opposite needs: the polish rounds + tables + filter fill the
+// device (or could), the chain kernels that follow keep a few hundred long-lived workgroups busy for 100-300 ms and leave the
+// rest of the device idle.  Slices that start together STAY together: they share the device during their pair-HMM rounds, finish
+// them at the same time and then all sit in their chain kernels at once (profiles/r06_trace_summary.txt: 200-300 ms per
+// 880 ms step in which the device ran nothing but chain workgroups; without the chain kernels the same step takes 627 ms).
+// The gate admits at most JTK_LC_PHASE_SLOTS batches per device (default 2) to the pair-HMM phase at a time, first come first
+// served; a batch leaves it when its chain kernels are queued.  The admitted batches get the whole device, finish their rounds
+// sooner, and their chains run under the next batches' pair-HMM rounds -- in a one-shot call's slices and in resident sessions
+// that are run again and again alike.  No effect on results (every batch is still one stream of its own).
+struct PhaseGate {
+    std::mutex m;
+    std::condition_variable cv;
+    uint64_t next_ticket = 0, released = 0;
+};
+PhaseGate g_gate[JTK_POOL_DEVICES];
+int phase_slots() {
+    static const int v = []() {
+        const char *e = getenv("JTK_LC_PHASE_SLOTS");
+        return e ? atoi(e) : 2;
+    }();
+    return v;
+}
+struct PhaseHold {
+    PhaseGate *g = nullptr;
+    explicit PhaseHold(int device) {
+        if (phase_slots() <= 0 || device < 0 || device >= JTK_POOL_DEVICES) return;  // 0: no gate (rounds 1-5)
+        g = &g_gate[device];
+        std::unique_lock<std::mutex> lock(g->m);
+        const uint64_t ticket = g->next_ticket++;
+        g->cv.wait(lock, [&]() { return ticket < g->released + (uint64_t)phase_slots(); });
+    }
+    void release() {
+        if (!g) return;
+        {
+            std::lock_guard<std::mutex> lock(g->m);
+            g->released++;
+        }
+        g->cv.notify_all();
+        g = nullptr;
+    }
+    ~PhaseHold() { release(); }
+};
+
 struct KernelTimer {
     hipEvent_t a = nullptr, b = nullptr;
     int kind = 0;
@@ -849,6 +892,7 @@ static int run_split(jtk_lc_session_t *s);
 // one pass of the kernel sequence over the resident batch
 static int run_batch(jtk_lc_session_t *s, int skip_polish) {
     HIP_TRY(hipSetDevice(s->device));
+    PhaseHold phase(s->device);   // the pair-HMM gate: held until the chain kernels are queued (or the pass ends)
     const double h2d = g_timing.h2d_ms;
     memset(&g_timing, 0, sizeof g_timing);
     g_timing.h2d_ms = h2d;
@@ -942,6 +986,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                   s->d_sel.as<uint8_t>(), s->d_feat.as<double>(), s->d_vtype.as<uint32_t>(), s->d_pos.as<uint32_t>(),
                   s->max_tmpl);
     tstop(s);
+    phase.release();   // everything that fills the device is queued: the next batch may start its rounds
     tstart(s, JTK_K_MCMC);
     int mcmc_rc = 0;
     hipStream_t st_main = st;
