@@ -192,10 +192,12 @@ std::shared_ptr<StripePool> g_stripes[JTK_POOL_DEVICES];
 // rest of the device idle.  Slices that start together STAY together: they share the device during their pair-HMM rounds, finish
 // them at the same time and then all sit in their chain kernels at once (profiles/r06_trace_summary.txt: 200-300 ms per
 // 880 ms step in which the device ran nothing but chain workgroups; without the chain kernels the same step takes 627 ms).
-// The gate admits at most JTK_LC_PHASE_SLOTS batches per device (default 2) to the pair-HMM phase at a time, first come first
-// served; a batch leaves it when its chain kernels are queued.  The admitted batches get the whole device, finish their rounds
-// sooner, and their chains run under the next batches' pair-HMM rounds -- in a one-shot call's slices and in resident sessions
-// that are run again and again alike.  No effect on results (every batch is still one stream of its own).
+// The gate admits at most JTK_LC_PHASE_SLOTS batches per device to the pair-HMM phase at a time, first come first served; a
+// batch leaves it when its chain kernels are queued.  The admitted batches get the whole device, finish their rounds sooner, and
+// their chains run under the next batches' pair-HMM rounds.  MEASURED AND NOT ADOPTED (profiles/r06_gate.txt: 2,810 / 2,888 /
+// 2,982 chunks/s with 2 / 3 / 4 slots against 2,902 without; start offsets between the slices, r06_stagger.txt, do nothing
+// either): a chain workgroup that runs beside pair-HMM waves takes their registers and LDS for as long as it lives, which costs
+// about what the idle tail of the lockstep costs.  Default 0 = no gate; the switch stays for measurements.  No effect on results.
 struct PhaseGate {
     std::mutex m;
     std::condition_variable cv;
@@ -205,7 +207,7 @@ PhaseGate g_gate[JTK_POOL_DEVICES];
 int phase_slots() {
     static const int v = []() {
         const char *e = getenv("JTK_LC_PHASE_SLOTS");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 0;
     }();
     return v;
 }
