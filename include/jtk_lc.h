@@ -51,7 +51,7 @@ typedef enum jtk_status {
     JTK_OK = 0,
     JTK_ERR_INVALID_ARG = -1,     /* null pointer, inconsistent offsets, non-ACGT base, bad op code    */
     JTK_ERR_NO_DEVICE = -2,       /* no usable MI355X / HIP runtime failure (message via last_error)   */
-    JTK_ERR_UNSUPPORTED = -3,     /* band radius > 127 (any read count is taken)                        */
+    JTK_ERR_UNSUPPORTED = -3,     /* band radius > 255 (any read count is taken)                        */
     JTK_ERR_ALLOC = -4,           /* hipMalloc / host allocation failed                                */
     JTK_ERR_OPS_MISMATCH = -5,    /* ops do not consume exactly the template and the read              */
     JTK_ERR_CHUNK_FAILED = -6,    /* >=1 chunk hit a condition on which the reference panics; see      */

@@ -8,7 +8,7 @@
 
 #define JTK_WAVE 64
 #define JTK_MAX_RADIUS 30        // 2r+1 <= 61 lanes: 3 spare lanes make the lane ring unambiguous (phmm_kernel)
-#define JTK_WIDE_MAX_RADIUS 127  // wider bands (CLR / None reads, long ONT chunks) take phmm_wide_kernel
+#define JTK_WIDE_MAX_RADIUS 255  // wider bands (CLR / None reads, long ONT chunks) take phmm_wide_kernel (LDS frames of 256 / 512 cells)
 #define JTK_PAIR_MAX_RADIUS 14   // 2r+1 <= 29 cells + 3 spare lanes fit a 32-lane half: phmm_pair_kernel runs two reads per wave
 #define JTK_SCALE_BLOCK 64       // one power-of-two exponent per 64 anti-diagonals (oracle/phmm.c)
 #define JTK_SCRATCH_GUARD 16     // zero rows in front of a wave's forward stripe (phmm_kernel reads pairs of diagonals >= -13)
@@ -164,19 +164,20 @@ void launch_finalize(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, con
 void launch_sum_final(hipStream_t s, uint32_t n_chunks, const ReadMeta *reads, const ChunkMeta *chunks, const ChunkState *state,
                       const HmmDev *hmm2, const double *raw, const int *rawG, const double *lk, double *total, uint32_t max_tmpl);
 // phmm_wide.hip: the reads of chunks whose band radius exceeds JTK_MAX_RADIUS (phmm_kernel skips them)
-size_t phmm_wide_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
+size_t phmm_wide_lds_bytes(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius);
 uint64_t phmm_wide_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius);
 void launch_phmm_wide(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                       const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
                       double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
-                      double *raw, int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active);
+                      double *raw, int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active,
+                      uint32_t max_radius);
 // expected transition / emission counts of every read of a batch (E-step of the model refit); 45 doubles per read
-size_t phmm_counts_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
+size_t phmm_counts_lds_bytes(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius);
 uint64_t phmm_counts_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius);
 void launch_phmm_counts(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                         const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
                         double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
-                        double *counts, double *lk, uint32_t max_tmpl, uint32_t max_read);
+                        double *counts, double *lk, uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius);
 // io_kernels.hip: the raw reads / ops of a batch recoded on the device (flags: bit 1 = non-ACGT base, bit 2 = op code > 3), and
 // the variable-length results packed for the copy back (lengths first, then consensus as ASCII + ops at prefix-summed offsets)
 void launch_encode_reads(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const uint8_t *raw_bases,

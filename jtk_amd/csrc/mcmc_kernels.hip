@@ -2108,10 +2108,11 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
     //      the proposals do (rounds 1-5: the next window started where the first proposal that did not end inside the window
     //      began, so nothing of it could be fetched before the walk had got there).  A proposal that starts in a block and ends in
     //      the next one is described by its own record like any other; its hop word carries HW_CROSS and, where it could have
-    //      been stepped over, HW_SKIPX instead of HW_SKIP: the walk stops at it, counts it and goes on in the next block.  The
-    //      records of the next block are requested a block ahead (r_next), and a block's look-up of its reads' entries is in
-    //      flight while its two logarithms are computed: of the ~1,100 cycles a window move cost (three dependent LDS round
-    //      trips and the arithmetic between them), the two round trips a lone wave can hide are hidden.
+    //      been stepped over, HW_SKIPX instead of HW_SKIP: the walk stops at it, counts it and goes on in the next block.  A
+    //      block's look-up of its reads' entries is in flight while its two logarithms are computed, every position of the
+    //      stream belongs to exactly one block (a window used to re-read the tail of its predecessor), and the move itself is
+    //      ~60 instructions.  Solo chains -7 .. -10 % (profiles/r06_chain_solo.txt); requesting the next block's records a block
+    //      ahead (JTK_K2_LOOKAHEAD 128) adds nothing: the chain is now bound by its producer wave.
     uint32_t w_base = 0;          // stream position of lane 0
     uint32_t w_idx = 0, w_w0 = 0; // per lane: the read the proposal starting here picks; its end (mod 64) | HW_CROSS, or HW_OUT
     float w_lrej = 0.0f, w_lacc = 0.0f;  // per lane: diff below w_lrej: certainly rejected; above w_lacc: certainly accepted
@@ -2149,24 +2150,37 @@ __device__ __attribute__((noinline)) double mcmc_chain_k2(K2Mem m_in, uint32_t n
         hop_finish(tv);
     };
     // the records of [base, base + 128) exist and may not be overwritten
+#ifndef JTK_K2_LOOKAHEAD
+// Records that must exist beyond a block's base.  64: the block's own records are read when it is entered (default).  128: the
+// next block's records are requested a block ahead (r_next) -- measured (profiles/r06_chain_solo.txt): nothing for the light
+// kernel (the chain is bound by its producer wave, not by this round trip) and -9 % for the general kernel, whose ring holds
+// 1,024 positions: the consumer then waits for the producer 64 positions earlier in every superblock.
+#define JTK_K2_LOOKAHEAD 64u
+#endif
     auto block_claim = [&](uint32_t base) {
         rng.pos = base;
         rng_release(rng, lane);
-        rng_wait_rec(rng, base + 128);
+        rng_wait_rec(rng, base + JTK_K2_LOOKAHEAD);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         w_base = base;
     };
     auto block_first = [&](uint32_t base) {   // the chain's first block, or the one behind a proposal with scalar draws that went far
         block_claim(base);
         const uint32_t r = *(lds_vu32 *)(uintptr_t)(rec_lds + (((base + lane) & rn_mask) << 2));
+#if JTK_K2_LOOKAHEAD >= 128u
         r_next = *(lds_vu32 *)(uintptr_t)(rec_lds + (((base + 64u + lane) & rn_mask) << 2));
+#endif
         block_setup(r);
         n_blocks++;
     };
     auto block_advance = [&]() {              // on to the block at w_base + 64: its records came in while this one was walked
         block_claim(w_base + 64u);
+#if JTK_K2_LOOKAHEAD >= 128u
         const uint32_t r = r_next;
         r_next = *(lds_vu32 *)(uintptr_t)(rec_lds + (((w_base + 64u + lane) & rn_mask) << 2));
+#else   // (measurement: no request ahead -- the block's own records are read now)
+        const uint32_t r = *(lds_vu32 *)(uintptr_t)(rec_lds + (((w_base + lane) & rn_mask) << 2));
+#endif
         block_setup(r);
         n_blocks++;
     };

@@ -16,7 +16,10 @@
 // exact power of two, so the three agree bit for bit (tests/test_gpu_shapes.py::test_wide_band_*).
 #include "device_common.h"
 
-#define WP 256  // band cells per LDS ring row (>= 2 * JTK_WIDE_MAX_RADIUS + 1)
+// Band cells per LDS ring row: a power of two >= 2 * radius + 1, chosen per launch from the largest radius of the batch (256 up
+// to radius 127; 512 up to JTK_WIDE_MAX_RADIUS = 255 -- round 6: CLR / None reads on chunks up to 10 kbp, ONT up to 17 kbp,
+// ReadType::band_width definitions/src/lib.rs:201-210).  A kernel argument: `WP` below is a local of each kernel.
+static uint32_t wide_wp(uint32_t max_radius) { return max_radius <= 127u ? 256u : 512u; }
 
 namespace {
 
@@ -35,8 +38,9 @@ __global__ __launch_bounds__(64) void phmm_wide_kernel(uint32_t n_reads, const R
                                                        const uint64_t *delta_all, const HmmDev *hmm2, double *scratch_all,
                                                        uint64_t scratch_stride, uint32_t *work_counter, uint32_t ticket_base, double *raw_all,
                                                        int *rawG_all, double *lk_all, uint32_t lds_tmpl, uint32_t lds_read,
-                                                       int only_active) {
+                                                       int only_active, uint32_t wp) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const int WP = (int)__builtin_amdgcn_readfirstlane(wp);
     // LDS carve: rings (9 rows of WP doubles, shared by the two sweeps) | acc ring [WP][16] | EF / EB per 64-block |
     // centres c[t] (u16) | template codes | read codes
     double *ring = reinterpret_cast<double *>(smem);          // forward: toM x3, toI x2, toD x2; backward: hM, hI, bD x3
@@ -335,8 +339,9 @@ __global__ __launch_bounds__(64) void phmm_counts_kernel(uint32_t n_reads, const
                                                          const ChunkState *state, DevBufs bufs, const uint8_t *ey_all,
                                                          const uint64_t *delta_all, const HmmDev *hmm2, double *scratch_all,
                                                          uint64_t scratch_stride, uint32_t *work_counter, uint32_t ticket_base, double *counts_all,
-                                                         double *lk_all, uint32_t lds_tmpl, uint32_t lds_read) {
+                                                         double *lk_all, uint32_t lds_tmpl, uint32_t lds_read, uint32_t wp) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const int WP = (int)__builtin_amdgcn_readfirstlane(wp);
     double *ring = reinterpret_cast<double *>(smem);
     double *part = ring + 9 * WP;  // [64][NCNT]
     const uint32_t n_blk = ((lds_tmpl + lds_read) >> 6) + 4;
@@ -557,8 +562,9 @@ __global__ __launch_bounds__(64) void phmm_counts_kernel(uint32_t n_reads, const
 
 }  // namespace
 
-size_t phmm_wide_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
+size_t phmm_wide_lds_bytes(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius) {
     const uint32_t n_blk = ((max_tmpl + max_read) >> 6) + 4;
+    const size_t WP = wide_wp(max_radius);
     size_t b = (size_t)9 * WP * 8 + (size_t)WP * JTK_ACC_N * 8 + (size_t)n_blk * 8;
     b += (size_t)((max_tmpl + max_read + 8) & ~7u) * 2 + ((max_tmpl + 16) & ~15u) + max_read + 16;
     return (b + 15) & ~(size_t)15;
@@ -572,19 +578,21 @@ uint64_t phmm_wide_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint32_
 void launch_phmm_wide(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                       const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
                       double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
-                      double *raw, int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active) {
+                      double *raw, int *rawG, double *lk, uint32_t max_tmpl, uint32_t max_read, int only_active,
+                      uint32_t max_radius) {
     if (n_reads == 0 || n_waves == 0) return;
     const uint32_t base = *ticket_base;
-    const size_t lds = phmm_wide_lds_bytes(max_tmpl, max_read);
+    const size_t lds = phmm_wide_lds_bytes(max_tmpl, max_read, max_radius);
     phmm_wide_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch, scratch_stride,
-                                              work_counter, base, raw, rawG, lk, max_tmpl, max_read, only_active);
+                                              work_counter, base, raw, rawG, lk, max_tmpl, max_read, only_active, wide_wp(max_radius));
     // the host mirror of the never-reset ticket counter moves only when the launch was accepted: a rejected launch (LDS, grid
     // or an earlier sticky error) takes no tickets, and a mirror that ran ahead would make every later launch exit at once
     if (hipPeekAtLastError() == hipSuccess) *ticket_base = base + n_reads + n_waves;
 }
 
-size_t phmm_counts_lds_bytes(uint32_t max_tmpl, uint32_t max_read) {
+size_t phmm_counts_lds_bytes(uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius) {
     const uint32_t n_blk = ((max_tmpl + max_read) >> 6) + 4;
+    const size_t WP = wide_wp(max_radius);
     size_t b = (size_t)9 * WP * 8 + (size_t)(64 * 45 + 1) * 8 + (size_t)n_blk * 8;
     b += (size_t)((max_tmpl + max_read + 8) & ~7u) * 2 + ((max_tmpl + 16) & ~15u) + max_read + 16;
     return (b + 15) & ~(size_t)15;
@@ -595,12 +603,12 @@ uint64_t phmm_counts_scratch_doubles(uint32_t max_tmpl, uint32_t max_read, uint3
 void launch_phmm_counts(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                         const ChunkState *state, DevBufs bufs, const uint8_t *ey, const uint64_t *delta, const HmmDev *hmm2,
                         double *scratch, uint64_t scratch_stride, uint32_t n_waves, uint32_t *work_counter, uint32_t *ticket_base,
-                        double *counts, double *lk, uint32_t max_tmpl, uint32_t max_read) {
+                        double *counts, double *lk, uint32_t max_tmpl, uint32_t max_read, uint32_t max_radius) {
     if (n_reads == 0 || n_waves == 0) return;
     const uint32_t base = *ticket_base;
-    const size_t lds = phmm_counts_lds_bytes(max_tmpl, max_read);
+    const size_t lds = phmm_counts_lds_bytes(max_tmpl, max_read, max_radius);
     phmm_counts_kernel<<<n_waves, 64, lds, s>>>(n_reads, reads, chunks, state, bufs, ey, delta, hmm2, scratch, scratch_stride,
-                                                work_counter, base, counts, lk, max_tmpl, max_read);
+                                                work_counter, base, counts, lk, max_tmpl, max_read, wide_wp(max_radius));
     // the host mirror of the never-reset ticket counter moves only when the launch was accepted: a rejected launch (LDS, grid
     // or an earlier sticky error) takes no tickets, and a mirror that ran ahead would make every later launch exit at once
     if (hipPeekAtLastError() == hipSuccess) *ticket_base = base + n_reads + n_waves;

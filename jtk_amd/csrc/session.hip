@@ -841,7 +841,7 @@ static int session_create_ex(const jtk_lc_params_t *params, size_t n_chunks, con
         }
     }
     if (s->n_wide_reads) {
-        const size_t wl = phmm_wide_lds_bytes(s->max_tmpl, s->max_read);
+        const size_t wl = phmm_wide_lds_bytes(s->max_tmpl, s->max_read, s->max_wide_radius);
         if (wl > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "template + read too long for the LDS staging of phmm_wide_kernel");
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -947,7 +947,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
             launch_phmm_wide(st, s->n_reads, reads, chunks, state, s->bufs, s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(),
                              hmm2, s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves,
                              s->d_wide_counter.as<uint32_t>(), &s->tk_wide, s->d_raw.as<double>(), s->d_rawG.as<int>(),
-                             s->d_lk.as<double>(), s->max_tmpl, s->max_read, only_active);
+                             s->d_lk.as<double>(), s->max_tmpl, s->max_read, only_active, s->max_wide_radius);
         // A polish round needs the column totals of the active chunks, not their per-read tables: the totals come straight from
         // the row sums (sum_final_kernel), and only a chunk that turns out to have converged -- no edit selected -- gets its
         // table, once, from the row sums it still holds.  The last pass materialises the tables of whatever is still active.
@@ -1978,7 +1978,7 @@ int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_l
         max_bw = std::max<uint32_t>(max_bw, (uint32_t)std::ceil((double)chunks[c].tmpl_len * params->band_frac));
     }
     if (n_chunks == 0 || n_reads == 0) return fail(JTK_ERR_INVALID_ARG, "no training pile-up");  // assert!, model_tune.rs:135
-    if (max_bw / 2 > JTK_WIDE_MAX_RADIUS) return fail(JTK_ERR_UNSUPPORTED, "band radius > 127");
+    if (max_bw / 2 > JTK_WIDE_MAX_RADIUS) return fail(JTK_ERR_UNSUPPORTED, "band radius > 255");
     jtk_lc_params_t cur = *params;
     if (cur.gains.max_homopolymer_len == 0) cur.gains.max_homopolymer_len = 1;  // the gains play no part in the refit
     // working copies: consensus and ops change from round to round; band_width stays that of the unpolished chunk (:123)
@@ -2025,7 +2025,7 @@ int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_l
             }
             // (checked before anything is allocated or queued: an early return must not hand a block with a pending memset
             // back to the pool)
-            const size_t lds = phmm_counts_lds_bytes(s->max_tmpl, s->max_read);
+            const size_t lds = phmm_counts_lds_bytes(s->max_tmpl, s->max_read, max_bw / 2);
             if (lds > 160 * 1024) return fail(JTK_ERR_UNSUPPORTED, "template + read too long for the LDS staging of phmm_counts_kernel");
             DevPtr d_wide, d_counts, d_lk, d_scratch, d_counter;
             if ((rc = dev_upload(s, d_wide, wide))) return rc;
@@ -2044,7 +2044,7 @@ int jtk_lc_fit_model(const jtk_lc_params_t *params, size_t n_chunks, const jtk_l
                                s->d_state.as<ChunkState>(), s->bufs, s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(),
                                s->d_hmm2.as<HmmDev>(), d_scratch.as<double>(), stride, (uint32_t)waves,
                                d_counter.as<uint32_t>(), &tk_counts, d_counts.as<double>(), d_lk.as<double>(), s->max_tmpl,
-                               s->max_read);
+                               s->max_read, max_bw / 2);
             HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * 8, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipMemcpyAsync(lks.data(), d_lk.p, lks.size() * 8, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
@@ -2101,7 +2101,8 @@ int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl
         launch_phmm_wide(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
                          s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(),
                          s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves, s->d_wide_counter.as<uint32_t>(), &s->tk_wide,
-                         s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
+                         s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0,
+                         s->max_wide_radius);
     launch_finalize(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state,
                     s->d_hmm2.as<HmmDev>(), s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, 0);
     ChunkState cs;
@@ -2149,7 +2150,8 @@ int jtk_internal_likelihoods(const jtk_lc_params_t *params, size_t n_chunks, con
         launch_phmm_wide(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
                          s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(),
                          s->d_wide_scratch.as<double>(), s->wide_stride, s->n_wide_waves, s->d_wide_counter.as<uint32_t>(), &s->tk_wide,
-                         s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
+                         s->d_raw.as<double>(), s->d_rawG.as<int>(), s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0,
+                         s->max_wide_radius);
     std::vector<ChunkState> cs(n_chunks);
     HIP_TRY(hipMemcpyAsync(cs.data(), state, cs.size() * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(lk_out, s->d_lk.p, (size_t)s->n_reads * 8, hipMemcpyDeviceToHost, st));

@@ -6,7 +6,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
-TAG=${1:-r05}
+TAG=${1:-r06}
 NCH=${2:-500}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -5,7 +5,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
-TAG=${1:-r05}
+TAG=${1:-r06}
 shift || true
 # --no-shard8: every launch in the profile is a launch of the FULL workload (round 3 left the 313-chunk shard runs in: their
 # small launches diluted the per-launch averages by 1.4x)

@@ -240,7 +240,8 @@ def test_full_path_pileup_of_1100_reads_matches_oracle(lib):
 
 # ---- bands wider than one wavefront (phmm_wide_kernel): CLR / None reads, ONT chunks longer than 2,033 bp
 
-@pytest.mark.parametrize("tmpl_len,band_frac,radius", [(600, 0.11, 33), (2000, 0.05, 50), (2100, 0.03, 31), (1000, 0.254, 127)])
+@pytest.mark.parametrize("tmpl_len,band_frac,radius", [(600, 0.11, 33), (2000, 0.05, 50), (2100, 0.03, 31), (1000, 0.254, 127),
+                                                       (900, 0.29, 130), (1100, 0.455, 250)])
 def test_wide_band_modification_table_matches_oracle(lib, tmpl_len, band_frac, radius):
     """ReadType::band_width (definitions/src/lib.rs:173-175,201-210): CLR / None = ceil(0.05 L) -> radius 50 at 2 kbp; an ONT
     chunk of 2,100 bp -> radius 31.  Bit for bit the table of the oracle (and of phmm_kernel, where both take the read)."""
@@ -283,7 +284,7 @@ def test_wide_and_narrow_bands_share_a_batch(lib):
 
 def test_band_wider_than_the_fallback_kernel_is_reported(lib):
     b, cfg, p = helpers.small_batch(n_chunks=2, tmpl_len=1000, reads_per_hap=3)
-    p.band_frac = 0.26                                   # radius 130 > 127
+    p.band_frac = 0.52                                   # radius 260 > 255 (JTK_WIDE_MAX_RADIUS)
     out = api.cluster_chunks(p, b, raise_on_chunk_failure=False)
     assert out["rc"] == -6 and (out["result"]["status"] == -3).all()
 
