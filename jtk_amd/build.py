@@ -86,7 +86,7 @@ def build_experiment(name, extra_flags):
 
 
 PROFILED_SOURCES = ["phmm_kernels.hip", "phmm_sweep.hip", "phmm_pair.hip", "phmm_wide.hip", "polish_kernels.hip", "filter_kernels.hip", "mcmc_kernels.hip",
-                    "session.hip", "io_kernels.hip", "device_common.h"]
+                    "session.hip", "io_kernels.hip", "device_common.h", "finalize_common.h"]
 
 
 def source_sha16():

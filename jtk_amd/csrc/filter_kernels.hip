@@ -13,6 +13,7 @@
 // neighbouring addresses.  compress_small_gains is applied on the fly (the table itself stays
 // uncompressed because polishing needs it).
 #include "device_common.h"
+#include "finalize_common.h"
 
 namespace {
 
@@ -180,9 +181,171 @@ __global__ void column_filter_kernel(const ReadMeta *reads, const ChunkMeta *chu
     if (0.0 < total_lk) cand[col] = total_lk;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// column_filter_fused_kernel (round 6): the same statistics and filters as column_filter_kernel, taken STRAIGHT FROM THE ROW
+// SUMS -- the N x 14(L+1) table is never written (`table - lk -> compress_small_gains -> column
+// (sum, count)` as an epilogue; until round 5 finalize_kernel wrote every read's table in place, 224 KB per read, and this
+// filter read it back column by column).  One workgroup per (chunk, tile of 128 positions) walks the reads IN READ ORDER like
+// sum_final_kernel: a read's rows of the tile are staged in LDS, thread p evaluates the 14 entries of its position with
+// finalize's own expressions (finalize_common.h: the same bits) and feeds the nine rows filter_profiles looks at (rows 0-7 and
+// 11, pseudo_mcmc.rs:447-449) into per-column accumulators: the gain and count of column_sum (:577-588, compressed values above
+// POS_THR, left to right over the reads) and the 2 x 2 strand / sign table of is_explainable_by_strandedness (:314-339).
+// The per-column tests follow when the last read is through.
+// ------------------------------------------------------------------------------------------------------
+#define FF_ROWS 9  // rows 0..7 (substitutions, insertions) and 11 (1-bp deletion)
+__device__ __forceinline__ uint32_t ff_row(int j) { return j < 8 ? (uint32_t)j : 8u + JTK_COPY_SIZE; }
+__global__ __launch_bounds__(FIN_TILE) void column_filter_fused_kernel(const ReadMeta *reads, const ChunkMeta *chunks,
+                                                                      const ChunkState *state, DevBufs bufs,
+                                                                      const jtk_lc_params_t *params, const HmmDev *hmm2,
+                                                                      const double *raw_all, const int *rawG_all,
+                                                                      const double *lk_all, const uint16_t *homop_all,
+                                                                      const uint64_t *homop_off, const double *aux_all,
+                                                                      const uint64_t *aux_off, double *cand_all) {
+    __shared__ __align__(16) double s_raw[FIN_ROWS * FIN_PITCH];
+    __shared__ int s_G[FIN_ROWS];
+    const uint32_t ci = blockIdx.y;
+    const ChunkState st = state[ci];
+    if (st.status != 0) return;
+    const ChunkMeta cm = chunks[ci];
+    const int L = (int)st.tmpl_len;
+    const int p0 = (int)blockIdx.x * FIN_TILE;
+    if (p0 > L) return;
+    const int tid = threadIdx.x, p = p0 + tid;
+    const uint32_t temp_len = (uint32_t)L + 1;
+    double *cand = cand_all + cm.cand_off;
+    if (p <= L) {
+#pragma unroll
+        for (uint32_t row = 0; row < JTK_NUM_ROW; row++) cand[(uint32_t)p * JTK_NUM_ROW + row] = -1.0;
+    }
+    if (cm.copy_num < 2) return;  // clustering() returns before search_variants (:86-88)
+    const uint8_t *x = bufs.tmpl[st.buf] + cm.tmpl_off;
+    const uint16_t *homop = homop_all + homop_off[ci];
+    const jtk_gains_t *g = &params->gains;
+    const uint32_t n = cm.n_reads, bp = (uint32_t)p;
+    // which of the nine columns of this position survive the position filters (:447-456, is_in_short_homopolymer :497-514)
+    uint32_t live = 0;
+    if (p <= L && JTK_MASK_LENGTH <= bp && bp + JTK_MASK_LENGTH <= temp_len) {
+#pragma unroll
+        for (int j = 0; j < FF_ROWS; j++) {
+            const uint32_t row = ff_row(j);
+            const int dt = diff_type_of(row);
+            bool ok = true;
+            if (dt == JTK_DIFF_INS) {
+                const uint8_t base = (uint8_t)(row - 4);
+                const uint32_t prev_len = bp > 0 ? homop[bp - 1] + (x[bp - 1] == base) : 0;
+                const uint32_t next_len = bp < (uint32_t)L ? homop[bp] + (x[bp] == base) : 0;
+                ok = prev_len <= JTK_MAX_HOMOP_LENGTH && next_len <= JTK_MAX_HOMOP_LENGTH;
+            } else if (dt == JTK_DIFF_DEL && bp < (uint32_t)L) {
+                ok = homop[bp] <= JTK_MAX_HOMOP_LENGTH;
+            }
+            if (ok) live |= 1u << j;
+        }
+    }
+    if (!__syncthreads_or(live != 0)) return;  // nothing of this tile can become a candidate
+    const uint32_t homop_here = (p <= L && bp < (uint32_t)L) ? homop[bp] : 1;
+    // MIN_REQ_FRACTION (:141-165): one value per difference type at this position
+    const double mr_sub = gains_expected(g, homop_here, JTK_DIFF_SUBST) * 0.5, mr_ins = gains_expected(g, homop_here, JTK_DIFF_INS) * 0.5,
+                 mr_del = gains_expected(g, homop_here, JTK_DIFF_DEL) * 0.5;
+    double gain[FF_ROWS];
+    // count | obs[strand][sign] as 16-bit fields (launch_filter takes this kernel for pile-ups below 65,536 reads):
+    // cnt_neg0[j] = count | obs[0][0] << 16, pos[j] = obs[0][1] | obs[1][1] << 16, neg1[j] = obs[1][0]
+    uint32_t cnt_neg0[FF_ROWS], pos[FF_ROWS], neg1[FF_ROWS];
+#pragma unroll
+    for (int j = 0; j < FF_ROWS; j++) {
+        gain[j] = 0.0;
+        cnt_neg0[j] = pos[j] = neg1[j] = 0;
+    }
+    const int n_rows = min(FIN_ROWS, L + 1 - p0);
+    for (uint32_t r = 0; r < n; r++) {
+        const uint32_t item = cm.read_first + r;
+        const ReadMeta rm = reads[item];
+        const double lk = lk_all[item];
+        const bool dead = !(lk > JTK_LOG_ZERO);
+        fin_stage(s_raw, s_G, raw_all + rm.raw_off, rawG_all + rm.row_off, p0, n_rows, tid, dead);
+        __syncthreads();
+        double res[JTK_NUM_ROW];
+        double eM[16];  // strand 1 -> hmm2[0], strand 0 -> hmm2[1] (as finalize_kernel); uniform: scalar loads, once per read
+        {
+            const double *src = rm.strand ? hmm2[0].eM : hmm2[1].eM;
+#pragma unroll
+            for (int k = 0; k < 16; k++) eM[k] = src[k];
+        }
+        fin_position(s_raw, s_G, eM, tid, p, L, lk, dead, res);
+        const uint32_t strand = rm.strand ? 1u : 0u;
+#pragma unroll
+        for (int j = 0; j < FF_ROWS; j++) {
+            const double v = compress(res[ff_row(j)], j < 4 ? mr_sub : (j < 8 ? mr_ins : mr_del));
+            if (JTK_POS_THR < v) {
+                gain[j] += v;
+                cnt_neg0[j] += 1u;
+            }
+            if (fabs(v) > 0.0001) {
+                if (jtk_f64_bits(v) >> 63) {   // negative
+                    if (strand) neg1[j] += 1u; else cnt_neg0[j] += 1u << 16;
+                } else {
+                    pos[j] += strand ? 1u << 16 : 1u;
+                }
+            }
+        }
+        __syncthreads();  // before the next read's rows are staged
+    }
+    if (live == 0) return;
+    const uint32_t H = g->max_homopolymer_len;
+    const double *aux = aux_all + aux_off[ci];
+    const double *lfact = aux + (uint64_t)3 * H * (n + 1);
+    const double *lnlam = lfact + (n + 1);
+#pragma unroll
+    for (int j = 0; j < FF_ROWS; j++) {
+        if (!((live >> j) & 1u)) continue;
+        const uint32_t row = ff_row(j), col = bp * JTK_NUM_ROW + row;
+        const uint32_t count_j = cnt_neg0[j] & 0xffffu, o00 = cnt_neg0[j] >> 16, o01 = pos[j] & 0xffffu, o11 = pos[j] >> 16, o10 = neg1[j];
+        const int dt = diff_type_of(row);
+        // has_small_pvalue (:476-495)
+        {
+            const uint32_t homop_len = bp < (uint32_t)L ? homop[bp] : 0;
+            const uint32_t hh = (homop_len < H ? homop_len : H);
+            const double pv = aux[((uint64_t)dt * H + (hh - 1)) * (n + 1) + count_j];
+            const double expt = gains_expected(g, homop_len, dt) * 0.8;  // EXPT_GAIN_FACTOR
+            const double pvalue = (double)temp_len * pv;
+            if (!((double)count_j * expt < gain[j] && pvalue < 0.05 / (double)temp_len)) continue;
+        }
+        // is_explainable_by_strandedness (:314-339)
+        {
+            const uint32_t obs[2][2] = {{o00, o01}, {o10, o11}};
+            const uint32_t strand_count[2] = {o00 + o01, o10 + o11}, sign_count[2] = {o00 + o10, o01 + o11};
+            const uint32_t sum = strand_count[0] + strand_count[1];
+            if (sum == 0) continue;
+            double chisq = 0.0;
+            for (int s = 0; s < 2; s++) {
+                double inner = 0.0;
+                for (int sg = 0; sg < 2; sg++) {
+                    const double expected = (double)(strand_count[s] * sign_count[sg]) / (double)sum;
+                    const double d = (double)obs[s][sg] - expected;
+                    inner += d * d / expected;  // 0/0 = NaN when a strand or a sign is absent, as in the reference
+                }
+                chisq += inner;
+            }
+            if (!(chisq < 10.0)) continue;
+        }
+        // total_lk = max_k poisson_lk(count, coverage*k) + gain (:457-461, :636-638)
+        double max_lk = 0.0;
+        for (uint32_t k = 1; k <= cm.copy_num; k++) {
+            const double lam = params->haploid_coverage * (double)k;
+            const double v = (double)count_j * lnlam[k] - lam - lfact[count_j];
+            if (k == 1 || !(v < max_lk)) max_lk = v;
+        }
+        const double total_lk = max_lk + gain[j];
+        if (0.0 < total_lk) cand[col] = total_lk;
+    }
+}
+
 // one wave per chunk: ordered compaction of the candidates, the greedy pick, then the feature matrix.
+// TABLE = true: the entries come from the materialised table (finalize_kernel ran: rounds 1-5, JTK_FILTER_FUSED=0); false: every
+// entry of a candidate column is evaluated from the row sums when it is needed (fin_entry: the same expressions, the same bits)
+template <bool TABLE>
 __global__ __launch_bounds__(64) void pick_kernel(const ReadMeta *reads, const ChunkMeta *chunks, ChunkState *state,
-                                                  const jtk_lc_params_t *params, const double *table_all,
+                                                  const jtk_lc_params_t *params, const double *table_all, const HmmDev *hmm2,
+                                                  const int *rawG_all, const double *lk_all,
                                                   const uint16_t *homop_all, const uint64_t *homop_off,
                                                   const double *cand_all, uint32_t *list_all, uint8_t *sel_all,
                                                   double *feat_all, uint32_t *vtype_all, uint32_t *pos_all) {
@@ -197,6 +360,13 @@ __global__ __launch_bounds__(64) void pick_kernel(const ReadMeta *reads, const C
     uint8_t *sel = sel_all + cm.cand_off;
     const uint16_t *homop = homop_all + homop_off[ci];
     const jtk_gains_t *g = &params->gains;
+    auto entry = [&](uint32_t r, uint32_t col) -> double {  // table_r[col] (already minus lk_r)
+        const uint32_t item = cm.read_first + r;
+        const ReadMeta &rm = reads[item];
+        if (TABLE) return table_all[rm.table_off + col];
+        return fin_entry(table_all + rm.raw_off, rawG_all + rm.row_off, (rm.strand ? hmm2[0] : hmm2[1]).eM, (int)(col / JTK_NUM_ROW),
+                         col % JTK_NUM_ROW, (int)L, lk_all[item]);
+    };
     __shared__ uint32_t s_np;
     // ---- ordered compaction
     uint32_t np = 0;
@@ -260,8 +430,7 @@ __global__ __launch_bounds__(64) void pick_kernel(const ReadMeta *reads, const C
                 uint32_t mat = 0, mism = 0;
                 double ip = 0.0, isq = 0.0, jsq = 0.0;
                 for (uint32_t r = 0; r < n; r++) {
-                    const uint64_t to = reads[cm.read_first + r].table_off;
-                    const double xv = compress(table_all[to + picked], mr_p), yv = compress(table_all[to + col], mr_i);
+                    const double xv = compress(entry(r, picked), mr_p), yv = compress(entry(r, col), mr_i);
                     if (JTK_POS_THR < fabs(xv) && JTK_POS_THR < fabs(yv)) {
                         if (0.0 < xv * yv)
                             mat++;
@@ -300,7 +469,7 @@ __global__ __launch_bounds__(64) void pick_kernel(const ReadMeta *reads, const C
     for (uint32_t e = lane; e < n * D; e += 64) {
         const uint32_t r = e / D, d = e % D;
         const uint32_t col = pos_all[(uint64_t)ci * JTK_MAX_DIM + d];
-        feat[(uint64_t)r * D + d] = compress(table_all[reads[cm.read_first + r].table_off + col], min_req_of(col));
+        feat[(uint64_t)r * D + d] = compress(entry(r, col), min_req_of(col));
     }
 }
 
@@ -309,19 +478,28 @@ __global__ __launch_bounds__(64) void pick_kernel(const ReadMeta *reads, const C
 void launch_filter(hipStream_t s, uint32_t n_chunks, const ReadMeta *reads, const ChunkMeta *chunks,
                    ChunkState *state, DevBufs bufs, const jtk_lc_params_t *params, const double *table,
                    uint16_t *homop, const uint64_t *homop_off, double *aux, const uint64_t *aux_off, double *cand,
-                   uint32_t *list, uint8_t *sel, double *feat, uint32_t *vtype, uint32_t *pos, uint32_t max_tmpl) {
+                   uint32_t *list, uint8_t *sel, double *feat, uint32_t *vtype, uint32_t *pos, uint32_t max_tmpl,
+                   const HmmDev *hmm2, const int *rawG, const double *lk, int fused) {
     if (n_chunks == 0) return;
     {
         dim3 grid((max_tmpl + 127) / 128, n_chunks);
         homop_kernel<<<grid, 128, 0, s>>>(chunks, state, bufs, homop, homop_off);
     }
     chunk_tables_kernel<<<n_chunks, 64, 0, s>>>(chunks, state, params, aux, aux_off);
+    if (fused) {  // `table` holds the raw row sums (finalize_kernel did not run): statistics and picks straight from them
+        dim3 grid((max_tmpl + 1 + FIN_TILE - 1) / FIN_TILE, n_chunks);
+        column_filter_fused_kernel<<<grid, FIN_TILE, 0, s>>>(reads, chunks, state, bufs, params, hmm2, table, rawG, lk, homop, homop_off,
+                                                            aux, aux_off, cand);
+        pick_kernel<false><<<n_chunks, 64, 0, s>>>(reads, chunks, state, params, table, hmm2, rawG, lk, homop, homop_off, cand, list,
+                                                   sel, feat, vtype, pos);
+        return;
+    }
     {
         const uint32_t cols = JTK_NUM_ROW * (max_tmpl + 1);
         dim3 grid((cols + 127) / 128, n_chunks);
         column_filter_kernel<<<grid, 128, 0, s>>>(reads, chunks, state, bufs, params, table, homop, homop_off, aux,
                                                    aux_off, cand);
     }
-    pick_kernel<<<n_chunks, 64, 0, s>>>(reads, chunks, state, params, table, homop, homop_off, cand, list, sel,
-                                        feat, vtype, pos);
+    pick_kernel<true><<<n_chunks, 64, 0, s>>>(reads, chunks, state, params, table, hmm2, rawG, lk, homop, homop_off, cand, list, sel,
+                                              feat, vtype, pos);
 }

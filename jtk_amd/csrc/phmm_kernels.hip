@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "device_common.h"
+#include "finalize_common.h"
 
 namespace {
 
@@ -141,69 +142,7 @@ __global__ void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const 
 // anything of the tile is written, and its writes end below the first row of the next tile), so the per-read table costs no
 // memory of its own: 9.7 GB less per 625-chunk slice of the headline workload.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double fin_log(double v, int G, double lk) {
-    return (v > 0.0 ? jtk_log(v) + (double)G * JTK_LN2 : JTK_LOG_ZERO) - lk;
-}
-
-#define FIN_TILE 128                   // positions per tile
-#define FIN_ROWS (FIN_TILE + 4)        // raw rows a tile reads: p .. p+4 for its last position
-#define FIN_PITCH (JTK_ACC_N + 1)      // doubles per staged row: 17 keeps the 128-byte rows off each other's LDS banks
-// rows p0 .. p0 + n_rows - 1 of a read's row sums into LDS, with coalesced 16-byte loads
-__device__ __forceinline__ void fin_stage(double *s_raw, int *s_G, const double *raw, const int *rawG, int p0, int n_rows,
-                                          int tid, bool dead) {
-    if (dead) return;
-    const double2 *src = reinterpret_cast<const double2 *>(raw + (uint64_t)p0 * JTK_ACC_N);
-    for (int e = tid; e < n_rows * (JTK_ACC_N / 2); e += FIN_TILE) {
-        const double2 v = src[e];
-        const int row = e / (JTK_ACC_N / 2), k = e % (JTK_ACC_N / 2);
-        s_raw[row * FIN_PITCH + 2 * k] = v.x;
-        s_raw[row * FIN_PITCH + 2 * k + 1] = v.y;
-    }
-    for (int e = tid; e < n_rows; e += FIN_TILE) s_G[e] = rawG[p0 + e];
-}
-// the 14 table entries of position p (thread tid of the tile), minus the read's lk, from the staged rows
-__device__ __forceinline__ void fin_position(const double *s_raw, const int *s_G, const double *eM, int tid, int p, int L,
-                                             double lk, bool dead, double *res) {
-#pragma unroll
-    for (int k = 0; k < JTK_NUM_ROW; k++) res[k] = JTK_LOG_ZERO - (dead ? 0.0 : lk);
-    if (!dead && p <= L) {
-        if (p + 1 <= L) {  // row p+1: sub[p], copy_c[p]
-            const double *a = s_raw + (tid + 1) * FIN_PITCH;
-            const int G = s_G[tid + 1];
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                double v = eM[4 * b + 0] * a[0];
-                v = fma(eM[4 * b + 1], a[1], v);
-                v = fma(eM[4 * b + 2], a[2], v);
-                v = fma(eM[4 * b + 3], a[3], v);
-                v = v + a[4];
-                res[b] = fin_log(v, G, lk);
-            }
-#pragma unroll
-            for (int cc = 0; cc < 3; cc++) res[8 + cc] = fin_log(a[10 + cc], G, lk);
-        }
-        {  // row p: ins[p]
-            const double *a = s_raw + tid * FIN_PITCH;
-            const int G = s_G[tid];
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                double v = eM[4 * b + 0] * a[5];
-                v = fma(eM[4 * b + 1], a[6], v);
-                v = fma(eM[4 * b + 2], a[7], v);
-                v = fma(eM[4 * b + 3], a[8], v);
-                v = v + a[9];
-                res[4 + b] = fin_log(v, G, lk);
-            }
-        }
-#pragma unroll
-        for (int dd = 1; dd <= 3; dd++) {  // row p+d+1: del_d[p]
-            if (p + dd + 1 <= L) {
-                const double *a = s_raw + (tid + dd + 1) * FIN_PITCH;
-                res[11 + dd - 1] = fin_log(a[13 + dd - 1], s_G[tid + dd + 1], lk);
-            }
-        }
-    }
-}
+// (fin_log / fin_stage / fin_position / fin_entry: finalize_common.h -- shared with filter_kernels.hip)
 __global__ __launch_bounds__(FIN_TILE) void finalize_kernel(uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
                                                            const ChunkState *state, const HmmDev *hmm2, double *raw_all,
                                                            const int *rawG_all, const double *lk_all, int only_active,

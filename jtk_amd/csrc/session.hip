@@ -38,7 +38,8 @@
 void launch_filter(hipStream_t s, uint32_t n_chunks, const ReadMeta *reads, const ChunkMeta *chunks,
                    ChunkState *state, DevBufs bufs, const jtk_lc_params_t *params, const double *table,
                    uint16_t *homop, const uint64_t *homop_off, double *aux, const uint64_t *aux_off, double *cand,
-                   uint32_t *list, uint8_t *sel, double *feat, uint32_t *vtype, uint32_t *pos, uint32_t max_tmpl);
+                   uint32_t *list, uint8_t *sel, double *feat, uint32_t *vtype, uint32_t *pos, uint32_t max_tmpl,
+                   const HmmDev *hmm2, const int *rawG, const double *lk, int fused);
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k);
 size_t mcmc_ws_bytes(uint32_t n, uint32_t d, uint32_t k);
 int launch_mcmc_huge(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state, const jtk_lc_params_t *params,
@@ -929,6 +930,12 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
         HIP_TRY(hipEventCreateWithFlags(&s->ev_round[0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_round[1], hipEventDisableTiming));
     }
+    // Round 6: the variant filter takes its column statistics and the picked columns' entries straight from the row sums
+    // (column_filter_fused_kernel, filter_kernels.hip), so a clustering pass never materialises the N x 14(L+1) table --
+    // finalize_kernel runs only where the table itself is the product (window polishing keeps its final-pass call; the
+    // modification-table entry point has its own) or with JTK_FILTER_FUSED=0 (rounds 1-5, kept for differential runs).
+    static const bool filter_fused = !(getenv("JTK_FILTER_FUSED") && atoi(getenv("JTK_FILTER_FUSED")) == 0);
+    const bool need_tables = s->polish_only || !filter_fused || s->max_n > 65535u;  // (the fused filter counts in 16-bit fields)
     const int max_rounds = skip_polish ? 1 : JTK_POLISH_MAX_ROUNDS + 1;
     for (int round = 0; round < max_rounds; round++) {
         const int only_active = round > 0;
@@ -951,10 +958,11 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
         // A polish round needs the column totals of the active chunks, not their per-read tables: the totals come straight from
         // the row sums (sum_final_kernel), and only a chunk that turns out to have converged -- no edit selected -- gets its
         // table, once, from the row sums it still holds.  The last pass materialises the tables of whatever is still active.
-        if (final_pass)
-            launch_finalize(st, s->n_reads, reads, chunks, state, hmm2, s->d_raw.as<double>(), s->d_rawG.as<int>(),
-                            s->d_lk.as<double>(), s->max_tmpl, only_active);
-        else
+        if (final_pass) {
+            if (need_tables)
+                launch_finalize(st, s->n_reads, reads, chunks, state, hmm2, s->d_raw.as<double>(), s->d_rawG.as<int>(),
+                                s->d_lk.as<double>(), s->max_tmpl, only_active);
+        } else
             launch_sum_final(st, s->n_chunks, reads, chunks, state, hmm2, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                              s->d_lk.as<double>(), s->d_total.as<double>(), s->max_tmpl);
         tstop(s);
@@ -966,7 +974,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
         if (!final_pass)
             launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 1);
         tstop(s);
-        if (!final_pass && !s->polish_only) {  // the chunks that converged in this round: their tables, for the variant search
+        if (!final_pass && !s->polish_only && need_tables) {  // the chunks that converged in this round: their tables, for the variant search
             tstart(s, JTK_K_PHMM);
             launch_finalize(st, s->n_reads, reads, chunks, state, hmm2, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                             s->d_lk.as<double>(), s->max_tmpl, 0, round);
@@ -986,7 +994,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                   s->d_raw.as<double>(), s->d_homop.as<uint16_t>(), s->d_homop_off.as<uint64_t>(),
                   s->d_aux.as<double>(), s->d_aux_off.as<uint64_t>(), s->d_cand.as<double>(), s->d_list.as<uint32_t>(),
                   s->d_sel.as<uint8_t>(), s->d_feat.as<double>(), s->d_vtype.as<uint32_t>(), s->d_pos.as<uint32_t>(),
-                  s->max_tmpl);
+                  s->max_tmpl, hmm2, s->d_rawG.as<int>(), s->d_lk.as<double>(), need_tables ? 0 : 1);
     tstop(s);
     phase.release();   // everything that fills the device is queued: the next batch may start its rounds
     tstart(s, JTK_K_MCMC);
@@ -1139,9 +1147,10 @@ int fetch_finish(jtk_lc_session_t *s, FetchPlan &pl, uint8_t *cons_out, uint64_t
     hipStream_t st = s->stream;
     if (pl.want_cons && cons_base + pl.cons_total > cons_cap) return fail(JTK_ERR_INVALID_ARG, "cons_cap too small");
     if (pl.want_ops && ops_base + pl.ops_total > ops_cap) return fail(JTK_ERR_INVALID_ARG, "ops_cap too small");
+    std::vector<uint64_t> off;   // (source of an asynchronous upload: lives until the stream has been waited for, below)
     if (pl.want_cons || pl.want_ops) {
         // offsets local to the session (the device packs from 0), written to the caller's arrays with the base added
-        std::vector<uint64_t> off((size_t)s->n_reads + s->n_chunks + 2);
+        off.resize((size_t)s->n_reads + s->n_chunks + 2);
         uint64_t *ooff = off.data(), *coff = off.data() + s->n_reads + 1;
         uint64_t oo = 0, co = 0;
         for (uint32_t g = 0; g < s->n_reads; g++) {
