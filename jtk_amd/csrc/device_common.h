@@ -101,7 +101,7 @@ struct DevBufs {
 // ---- kernel launchers (definitions in the .hip files) ----
 size_t phmm_lds_bytes(uint32_t max_tmpl, uint32_t max_read);
 void launch_band_prep(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
-                      ChunkState *state, DevBufs bufs, uint64_t *delta, int only_active);
+                      ChunkState *state, DevBufs bufs, uint64_t *delta, int only_active, uint32_t max_tmpl, uint32_t max_read);
 // Work queues: `work_counter` is a device ticket counter that is never reset (no fill blit in front of a launch).  A wave
 // takes tickets until one is past the launch's last item, so a launch advances the counter by exactly n_items + n_waves;
 // `ticket_base` (host, owned by the session) is the counter's value when the launch starts and is advanced by the launcher.

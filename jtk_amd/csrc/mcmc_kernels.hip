@@ -2858,7 +2858,7 @@ __global__ __launch_bounds__(64) void chain_split_kernel(uint32_t count, const u
 
 }  // namespace
 
-// LDS work area of one chunk (the producer's 16 KiB jump table comes from global memory unless JTK_MCMC_JUMP_LDS is set).
+// LDS work area of one chunk for a ring of 2 x (64 << seg_log) positions (the producer's jump table lives in global memory / L2).
 static size_t mcmc_lds_core(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, uint32_t seg_log = JTK_SEG_LOG_LIGHT) {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
     const size_t npad = (lds_n + 63u) & ~63u;
@@ -2881,8 +2881,9 @@ size_t mcmc_ws_bytes(uint32_t n, uint32_t d, uint32_t k) {
     k = clamp_k(k);
     return ((mcmc_lds_core(n, d, k) - mcmc_lds_fixed()) + 255) & ~(size_t)255;
 }
-// (the session sorts chunks into launch classes by this number: the 24 KiB ring of the light kernel; the general kernel is
-// launched with 12 KiB less, launch_mcmc)
+// (the session sorts chunks into launch classes by this number, which assumes the light kernel's 24 KiB ring; the general kernel
+// is launched with 12 KiB less (launch_mcmc), so the classing is conservative by that much and jtk_lc_timing_t.chain_lds_bytes
+// reports an upper bound -- ADVICE round 5; left as it is: tests pin the class boundaries at these sizes)
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k) { return mcmc_lds_core(lds_n, lds_d, clamp_k(lds_k)); }
 
 // ---- host: the byte-digit table of M^(63*SEG), from nothing but the generator's own step function

@@ -65,70 +65,88 @@ __device__ __forceinline__ int delta_bit(const uint64_t *delta, int t) {  // c[t
 }
 
 // ------------------------------------------------------------------------------------------------------
-// band_prep: one thread per read walks its ops and writes delta bits (c[t] - c[t-1]); validates that the
-// ops consume exactly the template and the read.  A Match step visits c = i+1 on both of its diagonals.
+// band_prep: the delta bits (c[t] - c[t-1]) of every read's band from its ops, the interval of anti-diagonals whose whole
+// band lies inside the DP matrix, and the check that the ops consume exactly the template and the read.  A Match step
+// visits c = i+1 on both of its diagonals.
+// Round 6: one WAVE per read, 64 ops per step (rounds 1-5: one thread per read walking its ~2,300 ops with dependent 8-byte
+// loads, 1.2 ms per polish round whatever the number of active reads).  An op's position (i, j) before it is a prefix count
+// of the ops before it that consume a template / a read base: two ballots and two mbcnt per 64 ops; the delta bits are OR-ed
+// into the wave's words in LDS and leave as whole words.  The walk is order-free: the interval is [first, last] diagonal that
+// satisfies the condition (the set is one interval, see below), a min / max over the lanes.
 // ------------------------------------------------------------------------------------------------------
-__global__ void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
-                                 ChunkState *state, DevBufs bufs, uint64_t *delta, int only_active) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+#define BP_WAVES 4
+__global__ __launch_bounds__(64 * BP_WAVES) void band_prep_kernel(uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
+                                                                 ChunkState *state, DevBufs bufs, uint64_t *delta, int only_active,
+                                                                 uint32_t max_words) {
+    extern __shared__ __align__(8) unsigned char bp_smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t r = blockIdx.x * BP_WAVES + wave;
     if (r >= n_reads) return;
     const ReadMeta rm = reads[r];
     ChunkState *st = &state[rm.chunk];
     if (st->status != 0) return;
     if (only_active && !st->active) return;
+    unsigned long long *sd = reinterpret_cast<unsigned long long *>(bp_smem) + (size_t)wave * max_words;
     const uint32_t L = st->tmpl_len, n = rm.read_len, T = L + n;
     const uint8_t *ops = bufs.ops[st->buf] + rm.ops_off;
     const uint32_t n_ops = bufs.ops_len[st->buf][r];
     uint64_t *d = delta + rm.delta_off;
     const uint32_t words = (T >> 6) + 2;
-    for (uint32_t w = 0; w < words; w++) d[w] = 0;
-    uint32_t i = 0, j = 0, t = 0;
-    bool bad = false;
+    for (uint32_t w = lane; w < words; w += 64) sd[w] = 0ull;
     // the interval [f_lo, f_hi] of diagonals whose WHOLE band lies inside the DP matrix (0 <= i <= L, 0 <= j <= n for every
     // band cell): c - r >= 0, c + r <= L, c + r <= t, c - r >= t - n.  c and t - c are non-decreasing in t, so the set is one
     // interval; phmm_kernel runs it under an EXEC mask that is the band and takes per-lane predicates outside of it.
     const int32_t rad = (int32_t)chunks[rm.chunk].radius;
-    uint32_t f_lo = 1, f_hi = 0;
+    uint32_t f_lo = 0xffffffffu, f_hi = 0;  // per lane: min / max of the diagonals it saw satisfy the condition
     auto visit = [&](uint32_t tt, uint32_t cc) {  // diagonal tt has centre cc
         const int32_t c = (int32_t)cc, td = (int32_t)tt;
         if (c - rad >= 0 && c + rad <= (int32_t)L && c + rad <= td && c - rad >= td - (int32_t)n) {
-            if (f_hi < f_lo) f_lo = tt;
-            f_hi = tt;
+            f_lo = tt < f_lo ? tt : f_lo;
+            f_hi = tt > f_hi ? tt : f_hi;
         }
     };
-    // the walk is one thread per read and latency bound: fetch the ops 8 at a time (ops_off is 8-byte aligned)
-    uint64_t chunk8 = 0;
-    for (uint32_t k = 0; k < n_ops; k++) {
-        if ((k & 7u) == 0) chunk8 = *reinterpret_cast<const uint64_t *>(ops + k);
-        uint8_t op = (uint8_t)(chunk8 >> (8 * (k & 7u)));
-        if (op == JTK_OP_INS) {
-            t += 1;
-            j++;
-            visit(t, i);
-        } else if (op == JTK_OP_DEL) {
-            t += 1;
-            if (t <= T) d[t >> 6] |= 1ull << (t & 63);
-            i++;
-            visit(t, i);
-        } else if (op <= JTK_OP_MISMATCH) {
-            t += 1;
-            if (t <= T) d[t >> 6] |= 1ull << (t & 63);
-            i++;
-            visit(t, i);
-            t += 1;
-            j++;
-            visit(t, i);
-        } else {
-            bad = true;
+    uint32_t i0 = 0, j0 = 0;  // template / read bases consumed before this step's 64 ops (uniform)
+    bool bad = false;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t base = 0; base < n_ops && !bad; base += 64) {
+        const uint32_t k = base + lane;
+        const bool has = k < n_ops;
+        const uint32_t op = has ? ops[k] : (uint32_t)JTK_OP_INS;
+        const bool invalid = has && op > JTK_OP_DEL;
+        const bool di = has && (op <= JTK_OP_MISMATCH || op == JTK_OP_DEL), dj = has && (op <= JTK_OP_MISMATCH || op == JTK_OP_INS);
+        const unsigned long long mi = __ballot(di), mj = __ballot(dj);
+        const uint32_t i = i0 + (uint32_t)__popcll(mi & below), j = j0 + (uint32_t)__popcll(mj & below), t = i + j;  // before the op
+        const uint32_t t_after = t + (di ? 1u : 0u) + (dj ? 1u : 0u);
+        // (the serial walk stopped at the first op that passed diagonal T: nothing behind it left a bit or a visit; the read is
+        // bad either way, and so is its chunk -- only the bounds matter here)
+        if (has && !invalid && t_after <= T + 2) {
+            if (op == JTK_OP_INS) {
+                visit(t + 1, i);
+            } else {
+                if (t + 1 <= T) atomicOr(&sd[(t + 1) >> 6], 1ull << ((t + 1) & 63u));
+                visit(t + 1, i + 1);
+                if (op != JTK_OP_DEL) visit(t + 2, i + 1);
+            }
         }
-        if (t > T) {
-            bad = true;
-            break;
-        }
+        if (__ballot(invalid || (has && t_after > T)) != 0ull) bad = true;
+        i0 += (uint32_t)__popcll(mi);
+        j0 += (uint32_t)__popcll(mj);
     }
-    if (bad || i != L || j != n) atomicMin(&st->status, (int)JTK_ERR_OPS_MISMATCH);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(f_lo, o, 64), b = __shfl_xor(f_hi, o, 64);
+        f_lo = a < f_lo ? a : f_lo;
+        f_hi = b > f_hi ? b : f_hi;
+    }
+    if (bad || i0 != L || j0 != n) {
+        bad = true;
+        if (lane == 0) atomicMin(&st->status, (int)JTK_ERR_OPS_MISMATCH);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the wave's own LDS atomics are done before its lanes read the words
+    for (uint32_t w = lane; w < words; w += 64) d[w] = sd[w];
     // the word behind the read's delta words (session.hip sizes the slot from the template CAPACITY: one word to spare)
-    d[((chunks[rm.chunk].tmpl_cap + rm.read_len) >> 6) + 2] = (bad || f_hi < f_lo) ? 1ull : ((uint64_t)f_hi << 32 | f_lo);
+    if (lane == 0)
+        d[((chunks[rm.chunk].tmpl_cap + rm.read_len) >> 6) + 2] = (bad || f_hi < f_lo) ? 1ull : ((uint64_t)f_hi << 32 | f_lo);
 }
 
 
@@ -255,9 +273,11 @@ __global__ __launch_bounds__(FIN_TILE) void sum_final_kernel(const ReadMeta *rea
 }  // namespace
 
 void launch_band_prep(hipStream_t s, uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
-                      ChunkState *state, DevBufs bufs, uint64_t *delta, int only_active) {
+                      ChunkState *state, DevBufs bufs, uint64_t *delta, int only_active, uint32_t max_tmpl, uint32_t max_read) {
     if (n_reads == 0) return;
-    band_prep_kernel<<<(n_reads + 63) / 64, 64, 0, s>>>(n_reads, reads, chunks, state, bufs, delta, only_active);
+    const uint32_t max_words = ((max_tmpl + max_read) >> 6) + 3;   // (T >> 6) + 2 words of the longest read, T <= max_tmpl + max_read
+    band_prep_kernel<<<(n_reads + BP_WAVES - 1) / BP_WAVES, 64 * BP_WAVES, (size_t)BP_WAVES * max_words * 8, s>>>(
+        n_reads, reads, chunks, state, bufs, delta, only_active, max_words);
 }
 
 

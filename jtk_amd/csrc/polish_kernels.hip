@@ -107,10 +107,25 @@ __global__ __launch_bounds__(64) void select_edits_kernel(const ChunkMeta *chunk
     new_len[ci] = w;
 }
 
-// one thread per read: local surgery of the ops around the edits, then Match/Mismatch re-tagging.
-__global__ void rethread_kernel(uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
-                                ChunkState *state, DevBufs bufs, const uint8_t *ey_all, const Edit *edits_all) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+// Local surgery of a read's ops around the round's edits, then Match / Mismatch re-tagging against the edited template.
+// What the serial walk does (rounds 1-5: one thread per read, ~2,300 dependent steps, 2.3 ms per round however few reads are
+// active), op by op with `ti` old template bases consumed:
+//   * an Ins op passes through;
+//   * an op that consumes old base ti inside a DELETION edit (pos <= ti < pos + d) becomes an Ins if it aligned a read base
+//     (Match / Mismatch) and disappears if it was a Del; any other consuming op passes through;
+//   * after the op that makes ti == pos of an INSERTION edit (rows 4..10; also before the first op for pos == 0), k Del ops
+//     follow, k = edit_inserted();
+//   * substitutions change no op; every Match / Mismatch is re-tagged from the new template base and the read base it aligns.
+// Edits of a round are at least six positions apart (select_edits_kernel), so an op meets at most one deletion and one insertion
+// edit, and every rule above is a function of the op and of ti alone -- ti is a prefix count.  Round 6: one WAVE per read, 64 ops
+// per step: ballot / mbcnt for ti, one packed prefix sum for the output position and the new (template, read) coordinates of
+// every emitted op.  Byte for byte the serial result (every full-path parity test compares the ops).
+#define RT_WAVES 4
+__global__ __launch_bounds__(64 * RT_WAVES) void rethread_kernel(uint32_t n_reads, const ReadMeta *reads, const ChunkMeta *chunks,
+                                                                ChunkState *state, DevBufs bufs, const uint8_t *ey_all,
+                                                                const Edit *edits_all) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t r = blockIdx.x * RT_WAVES + (threadIdx.x >> 6);
     if (r >= n_reads) return;
     const ReadMeta rm = reads[r];
     ChunkState *st = &state[rm.chunk];
@@ -122,82 +137,79 @@ __global__ void rethread_kernel(uint32_t n_reads, const ReadMeta *reads, const C
     uint8_t *out = bufs.ops[nb] + rm.ops_off;
     const uint32_t n_ops = bufs.ops_len[b][r];
     const uint8_t *tmpl = bufs.tmpl[nb] + cm.tmpl_off;  // the edited template
-    const uint8_t *ey = ey_all + rm.ey_off;                // read base j is ey[j+1] & 3
-    uint32_t w = 0, e = 0, ti = 0;
-    uint32_t ni = 0, nj = 0;  // positions in the NEW template / the read, for re-tagging
+    const uint8_t *ey = ey_all + rm.ey_off;               // read base j is ey[j+1] & 3
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t w0 = 0, ti0 = 0, ni0 = 0, nj0 = 0;  // uniform: ops written, old template bases consumed, new template / read position
+    uint32_t e_cur = 0;                          // uniform: edits before it cannot touch an op from here on
     bool overflow = false;
-    // One thread per read, latency bound: the three input streams (ops, new template, read) are fetched 8 bytes
-    // at a time and the output leaves 8 bytes at a time (slots are 8-byte aligned with >= 8 bytes of slack).
-    uint64_t in8 = 0, t8 = 0, y8 = 0, out8 = 0;
-    uint32_t t8_at = ~0u, y8_at = ~0u;  // 8-byte block currently held of tmpl / ey
-    auto tmpl_at = [&](uint32_t q) -> uint8_t {
-        const uint64_t a = (uint64_t)(cm.tmpl_off + q);  // absolute byte offset: blocks are aligned in the buffer
-        const uint32_t blk = (uint32_t)(a >> 3);
-        if (blk != t8_at) {
-            t8 = *reinterpret_cast<const uint64_t *>(bufs.tmpl[nb] + ((uint64_t)blk << 3));
-            t8_at = blk;
-        }
-        return (uint8_t)(t8 >> (8 * (a & 7)));
-    };
-    auto ey_at = [&](uint32_t q) -> uint8_t {
-        const uint64_t a = rm.ey_off + q;
-        const uint32_t blk = (uint32_t)(a >> 3);
-        if (blk != y8_at) {
-            y8 = *reinterpret_cast<const uint64_t *>(ey_all + ((uint64_t)blk << 3));
-            y8_at = blk;
-        }
-        return (uint8_t)(y8 >> (8 * (a & 7)));
-    };
-    auto emit = [&](uint8_t op) {
-        if (w >= rm.ops_cap) {
-            overflow = true;
-            return;
-        }
-        if (op == JTK_OP_INS) {
-            nj++;
-        } else if (op == JTK_OP_DEL) {
-            ni++;
-        } else {
-            op = tmpl_at(ni) == (ey_at(nj + 1) & 3) ? JTK_OP_MATCH : JTK_OP_MISMATCH;
-            ni++;
-            nj++;
-        }
-        out8 |= (uint64_t)op << (8 * (w & 7u));
-        w++;
-        if ((w & 7u) == 0) {
-            *reinterpret_cast<uint64_t *>(out + w - 8) = out8;
-            out8 = 0;
-        }
-    };
-    auto pending_inserts = [&]() {
-        while (e < ne && edits[e].pos == ti && edits[e].row >= 4 && edits[e].row < 11) {
-            const uint32_t k = edit_inserted(edits[e].row, edits[e].pos, L);
-            for (uint32_t q = 0; q < k; q++) emit(JTK_OP_DEL);
-            e++;
-        }
-    };
-    pending_inserts();
-    for (uint32_t k = 0; k < n_ops; k++) {
-        if ((k & 7u) == 0) in8 = *reinterpret_cast<const uint64_t *>(ops + k);
-        const uint8_t op = (uint8_t)(in8 >> (8 * (k & 7u)));
-        if (op == JTK_OP_INS) {
-            emit(op);
-            continue;
-        }
-        if (e < ne && edits[e].row >= 11 && edits[e].pos <= ti && ti < edits[e].pos + (edits[e].row - 10)) {
-            if (op != JTK_OP_DEL) emit(JTK_OP_INS);
-            ti++;
-            if (ti == edits[e].pos + (edits[e].row - 10)) e++;
-        } else {
-            emit(op);
-            if (e < ne && edits[e].row < 4 && edits[e].pos == ti) e++;
-            ti++;
-        }
-        pending_inserts();
+    // an insertion edit at position 0 fires before the first op
+    if (edits[0].pos == 0 && edits[0].row >= 4 && edits[0].row < 11) {
+        const uint32_t k = edit_inserted(edits[0].row, 0, L);
+        if (lane < k && lane < rm.ops_cap) out[lane] = JTK_OP_DEL;
+        overflow = overflow || k > rm.ops_cap;
+        w0 = k;
+        ni0 = k;
     }
-    if ((w & 7u) != 0 && !overflow) *reinterpret_cast<uint64_t *>(out + (w & ~7u)) = out8;  // inside the slot: cap % 8 == 0
-    bufs.ops_len[nb][r] = w;
-    if (overflow) atomicMin(&st->status, (int)JTK_ERR_CHUNK_FAILED);
+    for (uint32_t base = 0; base < n_ops; base += 64) {
+        const uint32_t kk = base + lane;
+        const bool has = kk < n_ops;
+        const uint32_t op = has ? ops[kk] : (uint32_t)JTK_OP_INS;
+        const bool cons = has && op != JTK_OP_INS;                   // consumes an old template base
+        const unsigned long long mc = __ballot(cons);
+        const uint32_t ti = ti0 + (uint32_t)__popcll(mc & below);    // old bases consumed before this op
+        // edits whose reach ends before this step's first consuming op are behind us (uniform cursor)
+        while (e_cur < ne) {
+            const Edit ed = edits[e_cur];
+            const uint32_t last = ed.row >= 11 ? ed.pos + (ed.row - 10) - 1 : (ed.row >= 4 ? ed.pos - 1 : ed.pos);  // last ti it touches
+            if ((ed.row >= 4 && ed.row < 11 && ed.pos == 0) || last < ti0)
+                e_cur++;
+            else
+                break;
+        }
+        uint32_t first = has ? op : 4u;   // what the op becomes: an op code, or 4 = nothing
+        uint32_t k_del = 0;               // Del ops that follow it
+        if (cons) {
+            for (uint32_t e = e_cur; e < ne; e++) {
+                const Edit ed = edits[e];
+                if (ed.pos > ti + 1) break;
+                if (ed.row >= 11) {
+                    if (ed.pos <= ti && ti < ed.pos + (ed.row - 10)) first = op != JTK_OP_DEL ? (uint32_t)JTK_OP_INS : 4u;
+                } else if (ed.row >= 4 && ed.pos == ti + 1) {
+                    k_del = edit_inserted(ed.row, ed.pos, L);
+                }
+            }
+        }
+        const uint32_t c_out = (first != 4u ? 1u : 0u) + k_del;
+        const uint32_t c_t = ((first <= JTK_OP_MISMATCH || first == JTK_OP_DEL) ? 1u : 0u) + k_del;     // new template bases consumed
+        const uint32_t c_r = (first <= JTK_OP_MISMATCH || first == JTK_OP_INS) ? 1u : 0u;                // read bases consumed
+        const uint32_t packed = c_out | c_t << 10 | c_r << 20;
+        uint32_t incl = packed;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += u;
+        }
+        const uint32_t excl = incl - packed, total = __shfl(incl, 63, 64);
+        uint32_t w = w0 + (excl & 1023u);
+        const uint32_t ni = ni0 + ((excl >> 10) & 1023u), nj = nj0 + (excl >> 20);
+        if (first != 4u) {
+            uint32_t o1 = first;
+            if (first <= JTK_OP_MISMATCH) o1 = tmpl[ni] == (ey[nj + 1] & 3) ? JTK_OP_MATCH : JTK_OP_MISMATCH;
+            if (w < rm.ops_cap) out[w] = (uint8_t)o1;
+            w++;
+        }
+        for (uint32_t q = 0; q < k_del; q++)
+            if (w + q < rm.ops_cap) out[w + q] = JTK_OP_DEL;
+        w0 += total & 1023u;
+        ni0 += (total >> 10) & 1023u;
+        nj0 += total >> 20;
+        ti0 += (uint32_t)__popcll(mc);
+        overflow = overflow || w0 > rm.ops_cap;
+    }
+    if (lane == 0) {
+        bufs.ops_len[nb][r] = overflow ? rm.ops_cap : w0;
+        if (overflow) atomicMin(&st->status, (int)JTK_ERR_CHUNK_FAILED);
+    }
 }
 
 // reads of chunks WITHOUT edits keep their ops: copy them so both buffers stay valid is unnecessary --
@@ -259,7 +271,7 @@ void launch_polish_round(hipStream_t s, uint32_t n_chunks, uint32_t n_reads, con
     select_edits_kernel<<<n_chunks, 64, max_tmpl + 64, s>>>(chunks, state, bufs, total, edits, new_len,
                                                             ignore_edge, final_pass);
     if (!final_pass) {
-        rethread_kernel<<<(n_reads + 63) / 64, 64, 0, s>>>(n_reads, reads, chunks, state, bufs, ey, edits);
+        rethread_kernel<<<(n_reads + RT_WAVES - 1) / RT_WAVES, 64 * RT_WAVES, 0, s>>>(n_reads, reads, chunks, state, bufs, ey, edits);
         commit_kernel<<<1, 256, 0, s>>>(n_chunks, state, new_len, n_active_out, n_active_host);
     }
 }

@@ -918,7 +918,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
     launch_reset_pass(st, s->n_chunks, state, s->d_state0.as<ChunkState>(), s->d_nactive.as<uint32_t>(), JTK_NACTIVE_SLOTS);
 
     tstart(s, JTK_K_POLISH);
-    launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 0);
+    launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 0, s->max_tmpl, s->max_read);
     tstop(s);
     // The host has to learn when every chunk has converged, but the device never waits for it: round r+1 is queued BEFORE the
     // host looks at round r's counter (a round without active chunks does nothing: every kernel of a round >= 1 skips the
@@ -972,7 +972,7 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
                             s->d_newlen.as<uint32_t>(), s->max_tmpl, s->ignore_edge, final_pass,
                             s->d_nactive.as<uint32_t>() + round, s->h_nactive_dev + round);
         if (!final_pass)
-            launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 1);
+            launch_band_prep(st, s->n_reads, reads, chunks, state, s->bufs, s->d_delta.as<uint64_t>(), 1, s->max_tmpl, s->max_read);
         tstop(s);
         if (!final_pass && !s->polish_only && need_tables) {  // the chunks that converged in this round: their tables, for the variant search
             tstart(s, JTK_K_PHMM);
@@ -2102,7 +2102,7 @@ int jtk_lc_modification_table(const jtk_lc_params_t *params, const uint8_t *tmpl
     ChunkState *state = s->d_state.as<ChunkState>();
     launch_reset_pass(st, s->n_chunks, state, s->d_state0.as<ChunkState>(), s->d_nactive.as<uint32_t>(), JTK_NACTIVE_SLOTS);
     launch_band_prep(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
-                     s->d_delta.as<uint64_t>(), 0);
+                     s->d_delta.as<uint64_t>(), 0, s->max_tmpl, s->max_read);
     launch_phmm(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
                 s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(), s->stripes->set(), s->n_waves, s->d_counter.as<uint32_t>(), &s->tk_phmm, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                 s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);
@@ -2151,7 +2151,7 @@ int jtk_internal_likelihoods(const jtk_lc_params_t *params, size_t n_chunks, con
     ChunkState *state = s->d_state.as<ChunkState>();
     launch_reset_pass(st, s->n_chunks, state, s->d_state0.as<ChunkState>(), s->d_nactive.as<uint32_t>(), JTK_NACTIVE_SLOTS);
     launch_band_prep(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
-                     s->d_delta.as<uint64_t>(), 0);
+                     s->d_delta.as<uint64_t>(), 0, s->max_tmpl, s->max_read);
     launch_phmm(st, s->n_reads, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), state, s->bufs,
                 s->d_ey.as<uint8_t>(), s->d_delta.as<uint64_t>(), s->d_hmm2.as<HmmDev>(), s->stripes->set(), s->n_waves, s->d_counter.as<uint32_t>(), &s->tk_phmm, s->d_raw.as<double>(), s->d_rawG.as<int>(),
                 s->d_lk.as<double>(), s->max_tmpl, s->max_read, 0);

@@ -29,16 +29,35 @@ def main():
         m = re.match(r"\s*ds_read_b64 v\[(\d+):(\d+)\], v(\d+)", line)
         lo, hi = int(m.group(1)), int(m.group(2))
         loads += 1
+        # Scan to the wait that COVERS this load: the first hand-placed lgkmcnt(0), or the first hand-placed
+        # lgkmcnt(1) that follows a LATER hand-issued load (then this one is no longer the youngest).  Until there the compiler must
+        # neither touch the destination registers nor issue an LDS / scalar-memory operation of its own: lgkmcnt counts those too,
+        # and scalar loads return out of order, so "all but the youngest" would stop meaning what the hand-placed wait assumes.
         j = i + 1
-        while j < len(lines) and not (lines[j].strip().startswith("s_waitcnt") and lines[j - 1].strip() == ";;#ASMSTART"):
-            t = lines[j]
-            if "ds_read" not in t and re.search(r"\bv\[%d:%d\]|\bv%d\b|\bv%d\b" % (lo, hi, lo, hi), t):
-                bad += 1
-                print("line %d: %s  is used before its wait: line %d: %s" % (i + 1, line.strip(), j + 1, t.strip()))
+        later_reads, covered = 0, False
+        while j < len(lines) and j - i <= 96:
+            t = lines[j].strip()
+            hand = lines[j - 1].strip() == ";;#ASMSTART"
+            if hand and t.startswith("s_waitcnt"):
+                mm = re.search(r"lgkmcnt\((\d+)\)", t)
+                n = int(mm.group(1)) if mm else 0
+                if n == 0 or (n == 1 and later_reads >= 1):
+                    covered = True
+                    break
+            elif hand and t.startswith("ds_read"):
+                later_reads += 1
+            else:
+                if re.search(r"\bv\[%d:%d\]|\bv%d\b|\bv%d\b" % (lo, hi, lo, hi), t) and not t.startswith(";"):
+                    bad += 1
+                    print("line %d: %s  is used before its wait: line %d: %s" % (i + 1, line.strip(), j + 1, t))
+                op = t.split()[0] if t and not t.startswith((";", ".")) and not t.endswith(":") else ""
+                if not hand and (op.startswith("s_load") or op.startswith("s_buffer_load") or op.startswith("ds_")):
+                    bad += 1
+                    print("line %d: %s  has a compiler-issued %s in flight beside it (line %d)" % (i + 1, line.strip(), op, j + 1))
             j += 1
-        if j - i > 64:
+        if not covered:
             bad += 1
-            print("line %d: %s  has no wait within 64 lines" % (i + 1, line.strip()))
+            print("line %d: %s  has no covering wait within 96 lines" % (i + 1, line.strip()))
     print("hand-issued row loads: %d, violations: %d" % (loads, bad))
     return 1 if bad or loads == 0 else 0
 
