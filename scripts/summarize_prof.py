@@ -16,7 +16,7 @@ from jtk_amd import build as jbuild  # noqa: E402
 
 FAMILY = {"mcmc": ["mcmc_kernel_light", "mcmc_kernel", "chain_split_kernel"], "phmm": ["phmm_kernel", "phmm_pair_kernel", "phmm_wide_kernel", "finalize_kernel", "sum_final_kernel"],
           "polish": ["select_edits_kernel", "rethread_kernel", "commit_kernel", "band_prep_kernel"],
-          "filter": ["homop_kernel", "chunk_tables_kernel", "column_filter_kernel", "pick_kernel"]}
+          "filter": ["homop_kernel", "chunk_tables_kernel", "column_filter_kernel", "column_filter_fused_kernel", "pick_kernel"]}
 
 
 def short(name):
