@@ -217,29 +217,37 @@ def refit_parity(p_refit, batch, raw, n_plain=56):
                 max_abs_dlogpost=float(np.abs(raw["log_post"][rows] - ora["log_post"]).max()))
 
 
-PMC_PROFILE = "r05_pmc_traffic.json"
-
-
 def pmc_traffic(workload, sha):
     """HBM bytes per PASS of the workload per kernel family from the rocprofv3 PMC passes committed under profiles/ --
     (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the profile / the passes in it (FETCH_SIZE doubled per the gfx950
     correction of MI355X_MICROARCH.md) -- but only when they were taken on THIS build of the library (same kernel sources and
     flags, or the same .so), on this workload, and with nothing but full-workload launches in the profile; otherwise None: a
-    stale profile says nothing about the kernels being timed."""
-    path = os.path.join(ROOT, "profiles", PMC_PROFILE)
-    try:
-        prof = json.load(open(path))
-    except (OSError, ValueError):
-        return None, "no profiles/" + PMC_PROFILE
+    stale profile says nothing about the kernels being timed.  Every profiles/rNN_pmc_traffic.json is looked at, newest round
+    first (round 6: the name was fixed to round 5's, so a line measured on a newer library could only ever say "stale")."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), reverse=True)
+    if not paths:
+        return None, "no profiles/rNN_pmc_traffic.json"
     src = jbuild.source_sha16()
-    if prof.get("src_sha16") != src and prof.get("lib_sha16") != sha:
-        return None, (f"profiles/{PMC_PROFILE} was taken on kernel sources {prof.get('src_sha16')} "
-                      f"(library {prof.get('lib_sha16')}), this is {src} ({sha})")
-    if prof.get("workload") != workload:
-        return None, f"profiles/{PMC_PROFILE} is for workload {prof.get('workload')}"
-    if not prof.get("full_workload_launches_only") or "family_bytes_per_pass" not in prof:
-        return None, f"profiles/{PMC_PROFILE} mixes launches of other batch sizes"
-    return dict(prof["family_bytes_per_pass"]), None
+    why = None
+    for path in paths:
+        name = os.path.basename(path)
+        try:
+            prof = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if prof.get("src_sha16") != src and prof.get("lib_sha16") != sha:
+            why = why or (f"profiles/{name} was taken on kernel sources {prof.get('src_sha16')} "
+                          f"(library {prof.get('lib_sha16')}), this is {src} ({sha})")
+            continue
+        if prof.get("workload") != workload:
+            why = why or f"profiles/{name} is for workload {prof.get('workload')}"
+            continue
+        if not prof.get("full_workload_launches_only") or "family_bytes_per_pass" not in prof:
+            why = why or f"profiles/{name} mixes launches of other batch sizes"
+            continue
+        return dict(prof["family_bytes_per_pass"]), None
+    return None, why
 
 
 def main():
