@@ -1123,7 +1123,17 @@ int fetch_begin(jtk_lc_session_t *s, FetchPlan &pl, uint32_t *label, double *log
     HIP_TRY(hipStreamSynchronize(st));
     for (uint32_t c = 0; c < s->n_chunks; c++) {
         const ChunkState &cs = pl.state[c];
-        if (cs.status != 0) pl.any_fail = 1;
+        if (cs.status != 0) {
+            pl.any_fail = 1;
+            // a failed chunk has no clustering: its reads get label 0 and zero posteriors, not whatever the device buffers held
+            // (round 6: found by comparing a sliced call with the same call in one piece)
+            const ChunkMeta &cm = s->h_chunks[c];
+            for (uint32_t r = 0; r < cm.n_reads; r++) {
+                if (label) label[cm.read_first + r] = 0;
+                if (log_post)
+                    for (uint32_t t = 0; t < s->post_stride; t++) log_post[(size_t)(cm.read_first + r) * s->post_stride + t] = 0.0;
+            }
+        }
         if (result) {
             result[c].score = cs.status == 0 ? cs.score : 0.0;
             result[c].cluster_num = cs.status == 0 ? cs.k : 1;

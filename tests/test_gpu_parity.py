@@ -354,6 +354,79 @@ def test_one_shot_slicing_does_not_change_results(lib, monkeypatch, n_slices):
     assert t["kernel_launches"]["mcmc"] == min(n_slices, 7)
 
 
+def _copy_batch(b):
+    import dataclasses
+    return dataclasses.replace(b, **{f.name: getattr(b, f.name).copy() for f in dataclasses.fields(b)
+                                    if isinstance(getattr(b, f.name), np.ndarray)})
+
+
+@pytest.mark.changes_env
+def test_device_side_validation_reports_what_the_host_loop_reported(lib, monkeypatch):
+    """Round 6: reads and ops are validated and recoded by encode_reads_kernel, not by a host loop.  Same verdicts: a non-ACGT
+    base in a read or a template and an op code above 3 fail the CALL with JTK_ERR_INVALID_ARG (also when the offender sits in
+    the last slice of a sliced call); lower-case bases are bases."""
+    b, cfg, p = helpers.small_batch(n_chunks=6, tmpl_len=260, reads_per_hap=5)
+    good = api.cluster_chunks(p, b)
+    low = _copy_batch(b)
+    low.read_bases[:] = np.frombuffer(bytes(low.read_bases).lower(), dtype=np.uint8)
+    low.tmpl_bases[:] = np.frombuffer(bytes(low.tmpl_bases).lower(), dtype=np.uint8)
+    out = api.cluster_chunks(p, low)
+    for k in ("label", "log_post", "cons", "cons_off", "ops_out", "ops_out_off"):
+        assert np.array_equal(out[k], good[k]), k
+    last_read = int(b.read_off[-2])           # first base of the batch's last read
+    for slices in ("1", "3"):
+        monkeypatch.setenv("JTK_LC_SLICES", slices)
+        bad = _copy_batch(b)
+        bad.read_bases[last_read + 7] = ord("N")
+        with pytest.raises(ffi.JtkError) as e:
+            api.cluster_chunks(p, bad)
+        assert e.value.status == -1 and "non-ACGT base in a read" in str(e.value)
+        bad = _copy_batch(b)
+        bad.ops[int(b.ops_off[-2]) + 3] = 7
+        with pytest.raises(ffi.JtkError) as e:
+            api.cluster_chunks(p, bad)
+        assert e.value.status == -1 and "bad op code" in str(e.value)
+        bad = _copy_batch(b)
+        bad.tmpl_bases[int(b.chunks["tmpl_off"][5]) + 11] = ord("-")
+        with pytest.raises(ffi.JtkError) as e:
+            api.cluster_chunks(p, bad)
+        assert e.value.status == -1 and "template" in str(e.value)
+    assert np.array_equal(api.cluster_chunks(p, b)["label"], good["label"])   # (the library is fine afterwards)
+
+
+@pytest.mark.changes_env
+def test_a_failed_chunk_inside_a_slice_leaves_the_other_outputs_in_place(lib, monkeypatch):
+    """One read whose ops do not consume its template (band_prep: JTK_ERR_OPS_MISMATCH for the chunk): the call returns
+    JTK_ERR_CHUNK_FAILED, the chunk has no consensus / ops (empty ranges), and every other chunk's results -- written by the
+    slices straight into the caller's arrays at offsets that depend on the failed chunk's ZERO length -- equal those of the same
+    call in one piece."""
+    b, cfg, p = helpers.small_batch(n_chunks=7, tmpl_len=300, reads_per_hap=5)
+    bad = _copy_batch(b)
+    r = int(bad.chunks["read_first"][3]) + 2
+    o0 = int(bad.ops_off[r])
+    k = next(i for i in range(o0, int(bad.ops_off[r + 1])) if bad.ops[i] == ffi.OP_MATCH)
+    bad.ops[k] = ffi.OP_INS                     # one template base is no longer consumed
+    monkeypatch.setenv("JTK_LC_SLICES", "1")
+    whole = api.cluster_chunks(p, bad, raise_on_chunk_failure=False)
+    assert whole["rc"] == -6 and int(whole["result"]["status"][3]) == -5
+    assert (np.delete(whole["result"]["status"], 3) == 0).all()
+    assert whole["cons_off"][3] == whole["cons_off"][4]                      # nothing for the failed chunk
+    ref = api.cluster_chunks(p, b)
+    for c in (0, 1, 2, 4, 5, 6):                                             # the others are what they are without it
+        a0, a1 = int(whole["cons_off"][c]), int(whole["cons_off"][c + 1])
+        r0, r1 = int(ref["cons_off"][c]), int(ref["cons_off"][c + 1])
+        assert bytes(whole["cons"][a0:a1]) == bytes(ref["cons"][r0:r1])
+    for n_slices in ("2", "3", "7"):
+        monkeypatch.setenv("JTK_LC_SLICES", n_slices)
+        sliced = api.cluster_chunks(p, bad, raise_on_chunk_failure=False)
+        assert sliced["rc"] == -6
+        for key in ("label", "log_post", "cons_off", "ops_out_off"):
+            assert np.array_equal(sliced[key], whole[key]), (n_slices, key)
+        n, m = int(whole["cons_off"][-1]), int(whole["ops_out_off"][-1])
+        assert np.array_equal(sliced["cons"][:n], whole["cons"][:n]) and np.array_equal(sliced["ops_out"][:m], whole["ops_out"][:m])
+        assert np.array_equal(sliced["result"]["status"], whole["result"]["status"])
+
+
 def test_session_is_repeatable_and_matches_one_shot(lib):
     b, cfg, p = helpers.small_batch(n_chunks=3, tmpl_len=400, reads_per_hap=8)
     one = api.cluster_chunks(p, b)
