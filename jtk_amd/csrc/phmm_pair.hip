@@ -204,7 +204,13 @@ __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, cons
             const double toI = fma(fd, aDI, fma(fi, aII, fm * aMI));
             const double toD = fma(fd, aDD, fma(fi, aID, fm * aMD));
             // the pair's first entry is toM of diagonal t-1 in its own block's scale (the value before this step's rescale)
+#if defined(JTK_PAIR_X_NOSTREAM)  // timing only (scripts/pair_probe_r6.sh): no pair leaves the wave but the ones the sweep back starts from
+            if (t >= Tmax - 5) scratch[(uint64_t)t * 64 + lane] = make_double2(toM_prev, toD);
+#elif defined(JTK_PAIR_X_REPLAYCOST)  // timing only: one row per four diagonals (a checkpoint would be two rows per eight)
+            if (t >= Tmax - 5 || (t & 3) == 2) scratch[(uint64_t)t * 64 + lane] = make_double2(toM_prev, toD);
+#else
             scratch[(uint64_t)t * 64 + lane] = make_double2(toM_prev, toD);
+#endif
             toM_2 = toM_1;
             toM_1 = toM;
             toI_1 = toI;
@@ -407,8 +413,55 @@ __global__ __launch_bounds__(64, 2) void phmm_pair_kernel(uint32_t n_items, cons
         if (t <= Tmax) step(t, std::integral_constant<int, (u)>{}, std::integral_constant<int, (2 - (u)) & 3>{}); \
     }
             PR_GROUP_STEP(0)
+#if defined(JTK_PAIR_X_NOSTREAM)
+            // timing only: the sweep back without its stream of pairs (the bound on what any replay can win); the tables are garbage
+#pragma unroll
+            for (int qq = 0; qq < PR_PF; qq++) pqY[qq] = pq[qq];
+#elif defined(JTK_PAIR_X_REPLAYCOST)
+            // timing only: what a replay would cost -- one row loaded per group of four (the checkpoint's share), then the forward
+            // step of four diagonals (band position, emission look-ups, the two seam-patched rotates, the nine products, the block's
+            // rescale from the stored exponents) whose pairs are what the next group consumes; the state is seeded from the
+            // loaded row, so the values are of the right magnitude but the tables are garbage
+            {
+                const double2 seed = load_pair(tb - 9);  // row == 2 (mod 4): stored by the forward sweep of this build
+                double rM1 = seed.x, rM2 = seed.x, rI1 = seed.y, rD1 = seed.y;
+                int rc = c5;
+#pragma unroll
+                for (int qq = 0; qq < PR_PF; qq++) {
+                    const int tn = tb - 12 + qq;
+                    if (tn >= 1) rc += dbit(tn) - dbit(tn + 4);  // a centre that moves like the band's
+                    const int lo = rc - r, off = (l32 - lo) & 31, i = lo + off, j = tn - i;
+                    const bool act = valid && off <= 2 * r && (unsigned)i <= (unsigned)L && (unsigned)j <= (unsigned)n;
+                    const int jj = (unsigned)(j + PR_PAD) <= (unsigned)(lds_read + 2 * PR_PAD) ? j : 0;
+                    const int ii = (unsigned)(i + PR_PAD - 1) <= (unsigned)(lds_tmpl + 2 * PR_PAD - 2) ? i : 0;
+                    const int ey8 = ey0[jj], xs = xs0[ii];
+                    const double eMv = *reinterpret_cast<const double *>(t_eM + xs + (ey8 & 24));
+                    const double eIv = *reinterpret_cast<const double *>(t_eI + ey8);
+                    const double pM = rot32_from_prev(rM2), pD = rot32_from_prev(rD1);
+                    double fm = eMv * pM, fi = eIv * rI1, fd = pD;
+                    if (!act) fm = fi = fd = 0.0;
+                    const double rM_prev = rM1;
+                    if ((tn & (JTK_SCALE_BLOCK - 1)) == 0 && tn >= JTK_SCALE_BLOCK) {
+                        const double sc = pr_pow2(h_EF[(tn >> 6) - 1] - h_EF[tn >> 6]);
+                        fm *= sc;
+                        fi *= sc;
+                        fd *= sc;
+                        rM1 *= sc;
+                    }
+                    const double toM = fma(fd, aDM, fma(fi, aIM, fm * aMM));
+                    const double toI = fma(fd, aDI, fma(fi, aII, fm * aMI));
+                    const double toD = fma(fd, aDD, fma(fi, aID, fm * aMD));
+                    pqY[(qq + 3) & 3] = make_double2(rM_prev, toD);
+                    rM2 = rM1;
+                    rM1 = toM;
+                    rI1 = toI;
+                    rD1 = toD;
+                }
+            }
+#else
 #pragma unroll
             for (int qq = 0; qq < PR_PF; qq++) pqY[qq] = load_pair(s_of(tb, qq) - 4);
+#endif
             PR_GROUP_STEP(1)
             PR_GROUP_STEP(2)
             PR_GROUP_STEP(3)

@@ -4,7 +4,7 @@ import torch  # noqa: F401  (first: see bench.py)
 sys.path.insert(0, "/root/repo")
 from jtk_amd import api, batch as jb, synth
 
-cfg = dict(synth.CONFIGS["ont_diploid"])
+cfg = dict(synth.CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "ont_diploid"])  # e.g. hifi_diploid: the pair kernel
 b, cfg = synth.make_batch(cfg, int(sys.argv[1]) if len(sys.argv) > 1 else 500)
 p = jb.default_params(cfg["coverage"], cfg["band_frac"])
 s = api.Session(p, b)
