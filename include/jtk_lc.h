@@ -198,6 +198,15 @@ JTK_LC_API int jtk_lc_session_fetch(jtk_lc_session_t *s, uint32_t *label, double
                          uint8_t *cons_out, uint64_t *cons_off, uint64_t cons_cap, uint8_t *ops_out,
                          uint64_t *ops_out_off, uint64_t ops_cap);
 JTK_LC_API int jtk_lc_session_destroy(jtk_lc_session_t *s);
+/* The reference's trace! rows (log level Trace) of ONE chunk's clustering, after a jtk_lc_session_run: '\n'-terminated rows, in the
+ * order the reference logs them -- TOTAL, CAND per candidate column (pseudo_mcmc.rs:467-472), PICK per picked column (:539),
+ * DUMP per selected column (:122-127), RANGE (:236), and per candidate cluster count the two LK rows (:250, :256) and, where the
+ * count was accepted, COUNTS (:262).  (Not written: the per-column PVALUE / RAWCOUNT / FILTER rows of the filter, REMOVE, VARS.)
+ * The chunk's pick and its chain run once more on the device, in instantiations that record what the rows need (the product
+ * kernels carry none of it); labels, posteriors and scores come out as they were.  *len = bytes of text (no terminator);
+ * JTK_ERR_INVALID_ARG with *len set when cap is too small; JTK_ERR_UNSUPPORTED for a session that holds a chunk of copy number
+ * >= 8 (clustering_recursive, mod.rs:125-189); a chunk of copy number < 2 logs nothing (pseudo_mcmc.rs:86-88). */
+JTK_LC_API int jtk_lc_session_trace(jtk_lc_session_t *s, size_t chunk, char *text, size_t cap, size_t *len);
 
 /* ---- stage pieces, exported because the reference exposes them too ------------------------------ */
 

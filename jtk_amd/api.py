@@ -209,6 +209,18 @@ class Session:
             check(rc)
         return dict(rc=rc, label=label, log_post=post, result=result)
 
+    def trace(self, chunk):
+        """the reference's trace! rows of one chunk's clustering (TOTAL / CAND / PICK / DUMP / RANGE / LK / COUNTS;
+        pseudo_mcmc.rs:122-127,236,250-262,467-472,539) after run(): a list of rows"""
+        need = C.c_size_t(0)
+        buf = C.create_string_buffer(1 << 16)
+        rc = self._lib.jtk_lc_session_trace(self._h, int(chunk), buf, len(buf), C.byref(need))
+        if rc != 0 and need.value > len(buf):
+            buf = C.create_string_buffer(need.value)
+            rc = self._lib.jtk_lc_session_trace(self._h, int(chunk), buf, len(buf), C.byref(need))
+        check(rc)
+        return buf.raw[:need.value].decode().splitlines()
+
     def chain_profile(self):
         """jtk_lc_debug_chain_profile (include/jtk_lc_debug.h): per chunk, the cycles of its chain and its events"""
         cyc = np.zeros(self.batch.n_chunks, dtype=np.uint64)

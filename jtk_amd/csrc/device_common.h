@@ -20,6 +20,7 @@
 #define JTK_MAX_HOMOP_LENGTH 2   // pseudo_mcmc.rs:4
 #define JTK_MAX_COPY 7           // one clustering() call sees copy_num < 8 (UPPER_COPY_NUM, mod.rs:85); larger chunks
                                  // go through clustering_recursive's split, which session.hip drives
+#define JTK_TRACE_MAX_PICKS 64    // jtk_lc_session_trace: picks recorded per chunk (ROUND * max(copy_num, 2) <= 21 of them happen)
 #define JTK_MAX_DIM (3 * JTK_MAX_COPY)  // ROUND * max(copy_num, 2) picked columns (pseudo_mcmc.rs:421,527,532)
 #define JTK_MAX_PILEUP 1023      // reads per pile-up in the chain kernel: 10-bit read indices in its proposal records and hop
                                  // words (register tables to 255 reads, LDS tables beyond); the LDS work area (n x D

@@ -342,14 +342,16 @@ __global__ __launch_bounds__(FIN_TILE) void column_filter_fused_kernel(const Rea
 // one wave per chunk: ordered compaction of the candidates, the greedy pick, then the feature matrix.
 // TABLE = true: the entries come from the materialised table (finalize_kernel ran: rounds 1-5, JTK_FILTER_FUSED=0); false: every
 // entry of a candidate column is evaluated from the row sums when it is needed (fin_entry: the same expressions, the same bits)
-template <bool TABLE>
-__global__ __launch_bounds__(64) void pick_kernel(const ReadMeta *reads, const ChunkMeta *chunks, ChunkState *state,
-                                                  const jtk_lc_params_t *params, const double *table_all, const HmmDev *hmm2,
-                                                  const int *rawG_all, const double *lk_all,
-                                                  const uint16_t *homop_all, const uint64_t *homop_off,
-                                                  const double *cand_all, uint32_t *list_all, uint8_t *sel_all,
-                                                  double *feat_all, uint32_t *vtype_all, uint32_t *pos_all) {
-    const uint32_t ci = blockIdx.x;
+// TRACE = true (pick_trace_kernel, jtk_lc_session_trace): the same pick once more for ONE chunk, leaving what the reference's
+// trace! rows need -- tr[0] = candidates (TOTAL :467), tr[1] = picks, tr[2 ..] = the picked candidates' list indices in pick order
+// (PICK :539), tr_count[i] = reads with a gain above POS_THR in candidate i's column (CAND :471, column_sum's count :577-588).
+template <bool TABLE, bool TRACE>
+__device__ __forceinline__ void pick_body(const uint32_t ci, const ReadMeta *reads, const ChunkMeta *chunks, ChunkState *state,
+                                          const jtk_lc_params_t *params, const double *table_all, const HmmDev *hmm2,
+                                          const int *rawG_all, const double *lk_all,
+                                          const uint16_t *homop_all, const uint64_t *homop_off,
+                                          const double *cand_all, uint32_t *list_all, uint8_t *sel_all,
+                                          double *feat_all, uint32_t *vtype_all, uint32_t *pos_all, uint32_t *tr, uint32_t *tr_count) {
     ChunkState *st = &state[ci];
     if (st->status != 0) return;
     const ChunkMeta cm = chunks[ci];
@@ -386,6 +388,18 @@ __global__ __launch_bounds__(64) void pick_kernel(const ReadMeta *reads, const C
         const uint32_t bp = col / JTK_NUM_ROW, row = col % JTK_NUM_ROW;
         return gains_expected(g, bp < L ? homop[bp] : 1, diff_type_of(row)) * 0.5;
     };
+    uint32_t n_picks = 0;
+    if (TRACE) {
+        for (uint32_t i = lane; i < np; i += 64) {
+            const uint32_t col = list[i];
+            const double mr = min_req_of(col);
+            uint32_t cnt = 0;
+            for (uint32_t r = 0; r < n; r++)
+                if (JTK_POS_THR < compress(entry(r, col), mr)) cnt++;
+            tr_count[i] = cnt;
+        }
+        if (lane == 0) tr[0] = np;
+    }
     // ---- pick_filtered_profiles
     const uint32_t per_round = cm.copy_num > 2 ? cm.copy_num : 2;
     for (uint32_t round = 0; round < 3; round++) {
@@ -417,6 +431,10 @@ __global__ __launch_bounds__(64) void pick_kernel(const ReadMeta *reads, const C
             const double mr_p = min_req_of(picked);
             __syncthreads();
             if (lane == 0) sel[bi] = 1;
+            if (TRACE) {
+                if (lane == 0 && n_picks < JTK_TRACE_MAX_PICKS) tr[2 + n_picks] = (uint32_t)bi;
+                n_picks++;
+            }
             __syncthreads();
             for (uint32_t i = lane; i < np; i += 64) {
                 if (!(sel[i] == 0 || sel[i] == 3)) continue;
@@ -449,6 +467,7 @@ __global__ __launch_bounds__(64) void pick_kernel(const ReadMeta *reads, const C
             __syncthreads();
         }
     }
+    if (TRACE && lane == 0) tr[1] = n_picks < JTK_TRACE_MAX_PICKS ? n_picks : JTK_TRACE_MAX_PICKS;
     // ---- selected probes in candidate order; features (filter_by) and variant types
     if (lane == 0) {
         uint32_t d = 0;
@@ -473,7 +492,43 @@ __global__ __launch_bounds__(64) void pick_kernel(const ReadMeta *reads, const C
     }
 }
 
+template <bool TABLE>
+__global__ __launch_bounds__(64) void pick_kernel(const ReadMeta *reads, const ChunkMeta *chunks, ChunkState *state,
+                                                  const jtk_lc_params_t *params, const double *table_all, const HmmDev *hmm2,
+                                                  const int *rawG_all, const double *lk_all,
+                                                  const uint16_t *homop_all, const uint64_t *homop_off,
+                                                  const double *cand_all, uint32_t *list_all, uint8_t *sel_all,
+                                                  double *feat_all, uint32_t *vtype_all, uint32_t *pos_all) {
+    pick_body<TABLE, false>(blockIdx.x, reads, chunks, state, params, table_all, hmm2, rawG_all, lk_all, homop_all, homop_off, cand_all,
+                            list_all, sel_all, feat_all, vtype_all, pos_all, nullptr, nullptr);
+}
+template <bool TABLE>
+__global__ __launch_bounds__(64) void pick_trace_kernel(uint32_t ci, const ReadMeta *reads, const ChunkMeta *chunks, ChunkState *state,
+                                                        const jtk_lc_params_t *params, const double *table_all, const HmmDev *hmm2,
+                                                        const int *rawG_all, const double *lk_all,
+                                                        const uint16_t *homop_all, const uint64_t *homop_off,
+                                                        const double *cand_all, uint32_t *list_all, uint8_t *sel_all,
+                                                        double *feat_all, uint32_t *vtype_all, uint32_t *pos_all, uint32_t *tr,
+                                                        uint32_t *tr_count) {
+    pick_body<TABLE, true>(ci, reads, chunks, state, params, table_all, hmm2, rawG_all, lk_all, homop_all, homop_off, cand_all, list_all,
+                           sel_all, feat_all, vtype_all, pos_all, tr, tr_count);
+}
+
 }  // namespace
+
+// jtk_lc_session_trace: chunk `ci`'s pick again (the candidates, list and every output come out as they were) with the trace
+// arrays filled: tr = 2 + JTK_TRACE_MAX_PICKS words, tr_count = one word per candidate (<= the chunk's column count).
+void launch_pick_trace(hipStream_t s, uint32_t ci, const ReadMeta *reads, const ChunkMeta *chunks, ChunkState *state,
+                       const jtk_lc_params_t *params, const double *table, const uint16_t *homop, const uint64_t *homop_off,
+                       const double *cand, uint32_t *list, uint8_t *sel, double *feat, uint32_t *vtype, uint32_t *pos,
+                       const HmmDev *hmm2, const int *rawG, const double *lk, int fused, uint32_t *tr, uint32_t *tr_count) {
+    if (fused)
+        pick_trace_kernel<false><<<1, 64, 0, s>>>(ci, reads, chunks, state, params, table, hmm2, rawG, lk, homop, homop_off, cand, list,
+                                                  sel, feat, vtype, pos, tr, tr_count);
+    else
+        pick_trace_kernel<true><<<1, 64, 0, s>>>(ci, reads, chunks, state, params, table, hmm2, rawG, lk, homop, homop_off, cand, list,
+                                                 sel, feat, vtype, pos, tr, tr_count);
+}
 
 void launch_filter(hipStream_t s, uint32_t n_chunks, const ReadMeta *reads, const ChunkMeta *chunks,
                    ChunkState *state, DevBufs bufs, const jtk_lc_params_t *params, const double *table,

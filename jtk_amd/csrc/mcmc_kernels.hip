@@ -2547,6 +2547,19 @@ __device__ __forceinline__ void likelihood_gain_dyn(uint32_t k, const Lds &m, ui
     }
 }
 
+// (trace instantiation only) get_read_lk_gains for a run-time cluster count 2 .. 7
+__device__ __forceinline__ void read_lk_gains_dyn(uint32_t k, const Lds &m, uint32_t n, uint32_t D, const uint8_t *assign, uint8_t *used,
+                                                  uint32_t lane) {
+    switch (k) {
+        case 2: get_read_lk_gains<2>(m, n, D, assign, used, lane); break;
+        case 3: get_read_lk_gains<3>(m, n, D, assign, used, lane); break;
+        case 4: get_read_lk_gains<4>(m, n, D, assign, used, lane); break;
+        case 5: get_read_lk_gains<5>(m, n, D, assign, used, lane); break;
+        case 6: get_read_lk_gains<6>(m, n, D, assign, used, lane); break;
+        default: get_read_lk_gains<7>(m, n, D, assign, used, lane); break;
+    }
+}
+
 __device__ __forceinline__ double gains_expected(const jtk_gains_t *g, uint32_t homop_len, int dt) {
     if (homop_len == 0) homop_len = 1;
     const uint32_t h = homop_len < g->max_homopolymer_len ? homop_len : g->max_homopolymer_len;
@@ -2568,7 +2581,15 @@ __device__ __forceinline__ double gains_expected(const jtk_gains_t *g, uint32_t 
 #ifndef JTK_MCMC_WAVES
 #define JTK_MCMC_WAVES 2
 #endif
-template <bool LIGHT, bool HUGE = false>
+// TRACE = true (mcmc_kernel_trace, jtk_lc_session_trace): the same clustering once more for ONE chunk, leaving what the reference's
+// trace! rows of cluster_filtered_variants need in `trace` (doubles): [0] = first k, [1] = last k of the RANGE row (:236), [2] = number
+// of records; record r at [8 + 16 r]: k, score, expected_gain, improved_reads (the LK rows :250,:256), accepted?, then the k cluster
+// sizes (COUNTS :262); from [JTK_TRACE_OLD] the n per-read gains of the accepted clustering (read_lk_gains :229, which feeds only
+// improved_reads).  The product instantiations compile none of it.
+#define JTK_TRACE_REC 8
+#define JTK_TRACE_REC_LEN 16
+#define JTK_TRACE_OLD (JTK_TRACE_REC + 8 * JTK_TRACE_REC_LEN)
+template <bool LIGHT, bool HUGE = false, bool TRACE = false>
 __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *state,
                                                   const jtk_lc_params_t *params, const double *feat_all,
                                                   const uint32_t *vtype_all, const uint64_t *vt_off_all,
@@ -2577,7 +2598,7 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
                                                   uint32_t lds_n, uint32_t lds_d, uint32_t lds_k, uint32_t seg_log_in,
                                                   uint32_t flags, const uint64_t *rng_resume, const uint32_t *order,
                                                   const uint32_t *order_count, unsigned char *ws_base = nullptr,
-                                                  const uint64_t *ws_off = nullptr) {
+                                                  const uint64_t *ws_off = nullptr, double *trace = nullptr) {
     // workgroups are dispatched in blockIdx order: `order` lists the chunks with the longest chains first (their
     // length is 20 x 2000 x n proposals per candidate k), so that on ragged batches the kernel does not end on a
     // long chain that started late.  `order_count`, if given, is the device-side length of the list (the grid is the
@@ -2695,6 +2716,16 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
     const uint32_t end = copy_num < 1 + 2 * D ? copy_num : 1 + 2 * D;
     const uint32_t start = (end > 5 ? end : 5) - 3;
     bool failed = false;
+    uint32_t trace_n = 0;  // (TRACE) records written
+    if constexpr (TRACE) {
+        if (lane == 0) {
+            trace[0] = (double)start;
+            trace[1] = (double)end;
+            trace[2] = 0.0;
+        }
+        for (uint32_t i = lane; i < n; i += 64) trace[JTK_TRACE_OLD + i] = 0.0;
+        wsync();
+    }
     for (uint32_t k = start; k <= end; k++) {
         double score;
         const bool ran = run_k_dyn<LIGHT, HUGE>(k, shape, n, D, coverage, rng, &score, lane);
@@ -2739,6 +2770,40 @@ __device__ __forceinline__ void mcmc_body(const ChunkMeta *chunks, ChunkState *s
             if (d == 0 || !(v < expt)) expt = v;
         }
         const double expected_gain = jtk_fmax(0.8 * expt, 0.1) * per_cluster_cov + 0.1;
+        if constexpr (TRACE) {
+            // new_lk_gains of the clustering this k ended with (at k == 2 fbuf may hold the other candidate's): get_read_lk_gains of
+            // m.best once more, then min_gain (:276-284: first minimum, the value only) and count_improved_reads (:308-312)
+            read_lk_gains_dyn(k, m, n, D, m.best, m.tmp_used, lane);
+            double min_gain = 1.0;
+            bool have_min = false;
+            for (uint32_t d = 0; d < D; d++)
+                if (m.used[d]) {
+                    const double v = gains_expected(&params->gains, vt[2 * d], (int)vt[2 * d + 1]) / 3.0;
+                    if (!have_min || v < min_gain) min_gain = v;
+                    have_min = true;
+                }
+            uint32_t improved = 0;
+            for (uint32_t i = 0; i < n; i++) improved += trace[JTK_TRACE_OLD + i] + min_gain < m.fbuf[i] ? 1u : 0u;
+            const bool accept = expected_gain < score - max;
+            double *rec = trace + JTK_TRACE_REC + (uint64_t)trace_n * JTK_TRACE_REC_LEN;
+            if (lane == 0 && trace_n < 8) {
+                rec[0] = (double)k;
+                rec[1] = score;
+                rec[2] = expected_gain;
+                rec[3] = (double)improved;
+                rec[4] = accept ? 1.0 : 0.0;
+                for (uint32_t c = 0; c < k; c++) {
+                    uint32_t cnt = 0;
+                    for (uint32_t i = 0; i < n; i++) cnt += m.best[i] == c ? 1u : 0u;
+                    rec[5 + c] = (double)cnt;
+                }
+                trace[2] = (double)(trace_n + 1);
+            }
+            trace_n++;
+            if (accept)
+                for (uint32_t i = lane; i < n; i += 64) trace[JTK_TRACE_OLD + i] = m.fbuf[i];
+            wsync();
+        }
         if (expected_gain < score - max) {
             wsync();
             for (uint32_t i = lane; i < n; i += 64) m.accepted[i] = m.best[i];
@@ -2812,6 +2877,11 @@ __global__ __launch_bounds__(128, JTK_MCMC_WAVES) void mcmc_kernel(MCMC_KERNEL_P
 // seven inlined instantiations of that chain need ~360 registers, and nothing here is built for speed.
 __global__ __launch_bounds__(128, 1) void mcmc_kernel_huge(MCMC_KERNEL_PARAMS, unsigned char *ws_base, const uint64_t *ws_off) {
     mcmc_body<false, true>(MCMC_KERNEL_ARGS, ws_base, ws_off);
+}
+// jtk_lc_session_trace: ONE chunk through the global-workspace body (any pile-up size), with the trace records
+__global__ __launch_bounds__(128, 1) void mcmc_kernel_trace(MCMC_KERNEL_PARAMS, unsigned char *ws_base, const uint64_t *ws_off,
+                                                            double *trace) {
+    mcmc_body<false, true, true>(MCMC_KERNEL_ARGS, ws_base, ws_off, trace);
 }
 #ifndef JTK_MCMC_LIGHT_WAVES
 #ifdef JTK_MCMC_STATS
@@ -3023,5 +3093,19 @@ int launch_mcmc_huge(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, 
     mcmc_kernel_huge<<<n_chunks, 128, mcmc_lds_fixed() + JTK_HUGE_LDS, s>>>(chunks, state, params, feat, vtype, vt_off, vt_stride_mode, label, post,
                                                              post_stride, lg, lg_off, max_n, max_d, clamp_k(max_k), JTK_SEG_LOG_LIGHT, 0u,
                                                              rng_resume, order, nullptr, ws, ws_off);
+    return 0;
+}
+
+// jtk_lc_session_trace: the chunk listed in order[0] once more through mcmc_kernel_trace (its results come out as they were);
+// `trace` = mcmc_trace_doubles(n) doubles, `ws` = mcmc_ws_bytes of the chunk, ws_off[0] = 0.
+size_t mcmc_trace_doubles(uint32_t n_reads) { return (size_t)JTK_TRACE_OLD + n_reads; }
+int launch_mcmc_trace(hipStream_t s, const ChunkMeta *chunks, ChunkState *state, const jtk_lc_params_t *params, const double *feat,
+                      const uint32_t *vtype, uint32_t *label, double *post, uint32_t post_stride, double *lg, const uint64_t *lg_off,
+                      uint32_t n, uint32_t d, uint32_t k, const uint32_t *order, unsigned char *ws, const uint64_t *ws_off,
+                      double *trace) {
+    if (mcmc_upload_jump_table(s) != 0) return -1;
+    mcmc_kernel_trace<<<1, 128, mcmc_lds_fixed() + JTK_HUGE_LDS, s>>>(chunks, state, params, feat, vtype, nullptr, 0u, label, post, post_stride,
+                                                                     lg, lg_off, n, d, clamp_k(k), JTK_SEG_LOG_LIGHT, 0u, nullptr,
+                                                                     order, nullptr, ws, ws_off, trace);
     return 0;
 }

@@ -15,6 +15,7 @@
 // consensus, cluster it with its share of the copies, recurse -- as further resident batches, one sub-problem
 // per chunk and round because a chunk's calls share one RNG stream in depth-first order.
 #include <cmath>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +41,15 @@ void launch_filter(hipStream_t s, uint32_t n_chunks, const ReadMeta *reads, cons
                    uint16_t *homop, const uint64_t *homop_off, double *aux, const uint64_t *aux_off, double *cand,
                    uint32_t *list, uint8_t *sel, double *feat, uint32_t *vtype, uint32_t *pos, uint32_t max_tmpl,
                    const HmmDev *hmm2, const int *rawG, const double *lk, int fused);
+void launch_pick_trace(hipStream_t s, uint32_t ci, const ReadMeta *reads, const ChunkMeta *chunks, ChunkState *state,
+                       const jtk_lc_params_t *params, const double *table, const uint16_t *homop, const uint64_t *homop_off,
+                       const double *cand, uint32_t *list, uint8_t *sel, double *feat, uint32_t *vtype, uint32_t *pos,
+                       const HmmDev *hmm2, const int *rawG, const double *lk, int fused, uint32_t *tr, uint32_t *tr_count);
+size_t mcmc_trace_doubles(uint32_t n_reads);
+int launch_mcmc_trace(hipStream_t s, const ChunkMeta *chunks, ChunkState *state, const jtk_lc_params_t *params, const double *feat,
+                      const uint32_t *vtype, uint32_t *label, double *post, uint32_t post_stride, double *lg, const uint64_t *lg_off,
+                      uint32_t n, uint32_t d, uint32_t k, const uint32_t *order, unsigned char *ws, const uint64_t *ws_off,
+                      double *trace);
 size_t mcmc_lds_bytes(uint32_t lds_n, uint32_t lds_d, uint32_t lds_k);
 size_t mcmc_ws_bytes(uint32_t n, uint32_t d, uint32_t k);
 int launch_mcmc_huge(hipStream_t s, uint32_t n_chunks, const ChunkMeta *chunks, ChunkState *state, const jtk_lc_params_t *params,
@@ -321,6 +331,7 @@ struct jtk_lc_session {
     DevPtr d_rng;                        // 4 x u64 per chunk: where each chunk's RNG stream resumes (sub-problems only)
     bool resume_rng = false;
     bool polish_only = false;            // jtk_lc_polish_chunks: no variant search, no clustering
+    bool ran = false, ran_fused = false; // a clustering pass has run (jtk_lc_session_trace needs its device state); with the fused filter?
     // reads whose band is wider than one wavefront (radius > JTK_MAX_RADIUS) take phmm_wide_kernel
     uint32_t n_wide_reads = 0, max_wide_radius = 0, n_wide_waves = 0;
     uint64_t wide_stride = 0;
@@ -1036,6 +1047,8 @@ static int run_batch(jtk_lc_session_t *s, int skip_polish) {
         (void)hipStreamSynchronize(st);
         return fail(JTK_ERR_INTERNAL, "the chain kernel could not be launched (jump table upload failed)");
     }
+    s->ran = true;
+    s->ran_fused = !need_tables;
     }  // !polish_only
     HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1062,6 +1075,140 @@ int jtk_lc_session_run(jtk_lc_session_t *s, int skip_polish) {
     int rc = run_batch(s, skip_polish);
     if (rc == 0 && s->has_split) rc = run_split(s);
     return rc;
+}
+
+// ---- the reference's trace! rows of one chunk (include/jtk_lc.h: jtk_lc_session_trace)
+namespace {
+void trace_row(std::string &out, const char *fmt, ...) {
+    char line[512];
+    va_list ap;
+    va_start(ap, fmt);
+    int m = vsnprintf(line, sizeof line, fmt, ap);
+    va_end(ap);
+    if (m < 0) return;
+    out.append(line, std::min<size_t>((size_t)m, sizeof line - 1));
+    out.push_back('\n');
+}
+std::string fx(double x, int prec) {  // Rust's {x:.N}: the correctly rounded decimal, as printf's; NaN is "NaN"
+    if (x != x) return "NaN";
+    char b[400];
+    snprintf(b, sizeof b, "%.*f", prec, x);
+    return b;
+}
+}  // namespace
+
+int jtk_lc_session_trace(jtk_lc_session_t *s, size_t chunk, char *text, size_t cap, size_t *len) {
+    g_last_error.clear();
+    if (!s || !len || (cap && !text)) return fail(JTK_ERR_INVALID_ARG, "null argument");
+    *len = 0;
+    if (chunk >= s->n_chunks) return fail(JTK_ERR_INVALID_ARG, "no such chunk in the session");
+    if (s->polish_only || s->features_only || !s->ran)
+        return fail(JTK_ERR_INVALID_ARG, "jtk_lc_session_trace needs a session whose last jtk_lc_session_run clustered its chunks");
+    if (s->has_split)  // (run_split re-uses the session's buffers for the sub-problems of clustering_recursive, mod.rs:125-189)
+        return fail(JTK_ERR_UNSUPPORTED, "jtk_lc_session_trace: the session holds a chunk of copy number >= 8 (clustering_recursive)");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = s->stream;
+    const uint32_t ci = (uint32_t)chunk;
+    const ChunkMeta &cm = s->h_chunks[ci];
+    ChunkState cs;
+    HIP_TRY(hipMemcpyAsync(&cs, s->d_state.as<ChunkState>() + ci, sizeof cs, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (cs.status != 0) return fail(cs.status, "jtk_lc_session_trace: the chunk failed in the run");
+    std::string out;
+    if (cm.copy_num < 2) {  // clustering() returns before anything is logged (pseudo_mcmc.rs:86-88)
+        *len = 0;
+        return JTK_OK;
+    }
+    const uint32_t n = cm.n_reads, L = cs.tmpl_len, cols = JTK_NUM_ROW * (L + 1);
+    // ---- the pick once more, with its trace arrays
+    DevPtr d_tr, d_cnt, d_order1, d_ws, d_ws_off, d_trace;
+    int rc;
+    if ((rc = dev_alloc<uint32_t>(d_tr, 2 + JTK_TRACE_MAX_PICKS))) return rc;
+    if ((rc = dev_alloc<uint32_t>(d_cnt, cols))) return rc;
+    HIP_TRY(hipMemsetAsync(d_tr.p, 0, (2 + JTK_TRACE_MAX_PICKS) * sizeof(uint32_t), st));
+    launch_pick_trace(st, ci, s->d_reads.as<ReadMeta>(), s->d_chunks.as<ChunkMeta>(), s->d_state.as<ChunkState>(),
+                      s->d_params.as<jtk_lc_params_t>(), s->d_raw.as<double>(), s->d_homop.as<uint16_t>(), s->d_homop_off.as<uint64_t>(),
+                      s->d_cand.as<double>(), s->d_list.as<uint32_t>(), s->d_sel.as<uint8_t>(), s->d_feat.as<double>(),
+                      s->d_vtype.as<uint32_t>(), s->d_pos.as<uint32_t>(), s->d_hmm2.as<HmmDev>(), s->d_rawG.as<int>(), s->d_lk.as<double>(),
+                      s->ran_fused ? 1 : 0, d_tr.as<uint32_t>(), d_cnt.as<uint32_t>());
+    std::vector<uint32_t> tr(2 + JTK_TRACE_MAX_PICKS);
+    HIP_TRY(hipMemcpyAsync(tr.data(), d_tr.p, tr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&cs, s->d_state.as<ChunkState>() + ci, sizeof cs, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    const uint32_t np = std::min(tr[0], cols), n_picks = std::min<uint32_t>(tr[1], JTK_TRACE_MAX_PICKS), D = cs.dim;
+    std::vector<uint32_t> list(np), cnt(np), pos(JTK_MAX_DIM);
+    std::vector<double> cand(cols), feat((size_t)n * D);
+    if (np) {
+        HIP_TRY(hipMemcpyAsync(list.data(), s->d_list.as<uint32_t>() + cm.cand_off, np * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt.p, np * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipMemcpyAsync(cand.data(), s->d_cand.as<double>() + cm.cand_off, cols * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(pos.data(), s->d_pos.as<uint32_t>() + (uint64_t)ci * JTK_MAX_DIM, JTK_MAX_DIM * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, st));
+    if (!feat.empty())
+        HIP_TRY(hipMemcpyAsync(feat.data(), s->d_feat.as<double>() + cm.feat_off, feat.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    auto diff_letter = [](uint32_t row) { return row < 4 ? "S" : (row < 8 + JTK_COPY_SIZE ? "I" : "D"); };  // pos_to_bp_and_difftype :168-178
+    trace_row(out, "TOTAL\t%u", np);                                                                       // :467
+    for (uint32_t i = 0; i < np; i++)                                                                       // :468-472
+        trace_row(out, "CAND\t%u\t%u\t%s\t%u", list[i] / JTK_NUM_ROW, list[i] % JTK_NUM_ROW, fx(cand[list[i]], 1).c_str(), cnt[i]);
+    for (uint32_t p = 0; p < n_picks; p++) {                                                                // :537-539
+        const uint32_t col = tr[2 + p] < np ? list[tr[2 + p]] : 0;
+        trace_row(out, "PICK\t%u\t%s\t%s", col / JTK_NUM_ROW, diff_letter(col % JTK_NUM_ROW), fx(cand[col], 3).c_str());
+    }
+    for (uint32_t d = 0; d < D; d++) {                                                                      // :122-127
+        double sum = 0.0;
+        for (uint32_t r = 0; r < n; r++) {
+            const double x = feat[(size_t)r * D + d];
+            sum += x != x ? 0.0 : (x > 0.0 ? x : 0.0);  // f64::max(x, 0) ignores NaN
+        }
+        trace_row(out, "DUMP\t%u\t%u\t%u\t%s\t%s", d, pos[d] / JTK_NUM_ROW, pos[d] % JTK_NUM_ROW, fx(cand[pos[d]], 1).c_str(),
+                  fx(sum, 1).c_str());
+    }
+    // ---- cluster_filtered_variants once more, with its records (:213-274); its early return logs nothing (:221-225)
+    if (!(D == 0 || n <= cm.copy_num)) {
+        const uint32_t k = std::min<uint32_t>(std::max<uint32_t>(cm.copy_num, 2u), JTK_MAX_COPY);
+        const uint32_t dmax = std::min<uint32_t>(JTK_MAX_DIM, 3u * std::max<uint32_t>(cm.copy_num, 2u));
+        std::vector<uint32_t> order1(1, ci);
+        std::vector<uint64_t> ws_off1(1, 0);
+        if ((rc = dev_upload(s, d_order1, order1))) return rc;
+        if ((rc = dev_upload(s, d_ws_off, ws_off1))) return rc;
+        if ((rc = dev_alloc<uint8_t>(d_ws, mcmc_ws_bytes(n, dmax, k)))) return rc;
+        const size_t tn = mcmc_trace_doubles(n);
+        if ((rc = dev_alloc<double>(d_trace, tn))) return rc;
+        HIP_TRY(hipMemsetAsync(d_trace.p, 0, tn * sizeof(double), st));
+        if (launch_mcmc_trace(st, s->d_chunks.as<ChunkMeta>(), s->d_state.as<ChunkState>(), s->d_params.as<jtk_lc_params_t>(),
+                              s->d_feat.as<double>(), s->d_vtype.as<uint32_t>(), s->d_label.as<uint32_t>(), s->d_post.as<double>(),
+                              s->post_stride, s->d_lg.as<double>(), s->d_lg_off.as<uint64_t>(), n, dmax, k, d_order1.as<uint32_t>(),
+                              d_ws.as<uint8_t>(), d_ws_off.as<uint64_t>(), d_trace.as<double>()) != 0) {
+            (void)hipStreamSynchronize(st);
+            return fail(JTK_ERR_INTERNAL, "the chain kernel could not be launched (jump table upload failed)");
+        }
+        std::vector<double> tv(tn);
+        HIP_TRY(hipMemcpyAsync(tv.data(), d_trace.p, tn * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&cs, s->d_state.as<ChunkState>() + ci, sizeof cs, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipGetLastError());
+        if (cs.status != 0) return fail(cs.status, "jtk_lc_session_trace: the chunk failed when its chain ran again");
+        trace_row(out, "RANGE\t%u..=%u", (unsigned)tv[0], (unsigned)tv[1]);                                 // :236
+        const uint32_t nrec = std::min<uint32_t>((uint32_t)tv[2], 8u);
+        for (uint32_t r = 0; r < nrec; r++) {
+            const double *rec = tv.data() + 8 + 16 * r;
+            const unsigned kk = (unsigned)rec[0];
+            trace_row(out, "LK\t%u\t%s", kk, fx(rec[1], 3).c_str());                                        // :250
+            trace_row(out, "LK\t%u\t%s\t%s\t%u", kk, fx(rec[1], 3).c_str(), fx(rec[2], 3).c_str(), (unsigned)rec[3]);  // :256
+            if (rec[4] != 0.0) {                                                                            // :258-262
+                std::string c = "COUNTS\t[";
+                for (unsigned q = 0; q < kk && q < JTK_MAX_COPY; q++) c += (q ? ", " : "") + std::to_string((unsigned)rec[5 + q]);
+                trace_row(out, "%s]", c.c_str());
+            }
+        }
+    }
+    *len = out.size();
+    if (out.size() > cap) return fail(JTK_ERR_INVALID_ARG, "jtk_lc_session_trace: the text needs " + std::to_string(out.size()) + " bytes");
+    if (!out.empty()) memcpy(text, out.data(), out.size());
+    return JTK_OK;
 }
 
 // include/jtk_lc_debug.h: per chunk, the cycles of its chain and the proposals that could not be stepped over

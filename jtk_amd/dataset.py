@@ -228,14 +228,17 @@ def normalize_local_clustering(ds):
             n["posterior"] = post[i].tolist()
 
 
-def local_clustering_selected(ds, selection, gains=None, device=0, failed=None, refit=True, record=None):
+def local_clustering_selected(ds, selection, gains=None, device=0, failed=None, refit=True, record=None, trace=None):
     """mod.rs:56-83 on the parsed JSON object `ds` (modified in place).
 
     The reference panics when a chunk hits one of its asserts; here such a chunk (and a chunk of a shape this build does
     not take) comes back with a status.  With `failed` = a list, those chunks are left exactly as they were, their
     (chunk id, status) pairs are appended to it and every other chunk is written back; with `failed` = None the call
     raises like the reference, before touching `ds`.  `record` = a list: the reference's per-chunk RECORD lines (mod.rs:121,
-    `debug!`) of the chunks that were written back are appended to it (api.record_rows)."""
+    `debug!`) of the chunks that were written back are appended to it (api.record_rows).  `trace` = a list: the reference's
+    trace! rows of every clustered chunk of copy number < 8 (TOTAL / CAND / PICK / DUMP / RANGE / LK / COUNTS,
+    pseudo_mcmc.rs:122-127,236,250-262,467-472,539), chunk after chunk in chunk-id order (api.Session.trace: those chunks once
+    more through a resident session -- a debugging aid, like the log level it mirrors)."""
     validate(ds)
     update_coverage(ds)                                                       # mod.rs:57
     if refit:
@@ -289,15 +292,22 @@ def local_clustering_selected(ds, selection, gains=None, device=0, failed=None, 
                                 for c in range(batch.n_chunks)], batch.chunks["copy_num"], out["result"],
                                np.diff(out["cons_off"]).astype(np.int64), api.last_timing())
         record.extend(r for c, r in enumerate(rows) if int(out["result"][c]["status"]) == 0)
+    if trace is not None:
+        keep = [c for c in range(batch.n_chunks) if int(out["result"][c]["status"]) == 0 and int(batch.chunks["copy_num"][c]) < 8]
+        if keep:
+            with api.Session(params, batch.subset(keep), device=device) as sess:
+                sess.run()
+                for i in range(len(keep)):
+                    trace.extend(sess.trace(i))
     normalize_local_clustering(ds)                                            # mod.rs:82
     return ds
 
 
-def local_clustering(ds, gains=None, device=0, failed=None, refit=True, record=None):
+def local_clustering(ds, gains=None, device=0, failed=None, refit=True, record=None, trace=None):
     """mod.rs:23-26: every selected chunk."""
     validate(ds)
     return local_clustering_selected(ds, [c["id"] for c in ds["selected_chunks"]], gains=gains, device=device,
-                                     failed=failed, refit=refit, record=record)
+                                     failed=failed, refit=refit, record=record, trace=trace)
 
 
 def correct_clustering_selected(ds, selection, device=0, min_gain=None):
@@ -426,10 +436,14 @@ def main(argv=None):
                          "and listed on stderr instead of aborting the stage")
     ap.add_argument("-v", "--verbose", action="store_true",
                     help="write the reference's per-chunk RECORD lines (mod.rs:121, its debug! level) to stderr")
+    ap.add_argument("--trace", action="store_true",
+                    help="write the reference's trace! rows of every clustered chunk (TOTAL / CAND / PICK / DUMP / RANGE / LK / "
+                         "COUNTS; its -vvv) to stderr")
     args = ap.parse_args(argv)
     ds = json.load(sys.stdin if args.input == "-" else open(args.input))
     failed = [] if args.keep_going else None
     record = [] if args.verbose else None
+    trace = [] if args.trace else None
     if args.stage == "correct_clustering":
         validate(ds)
         if args.chunks:
@@ -438,10 +452,10 @@ def main(argv=None):
             correct_clustering(ds, device=args.device)
     elif args.chunks:
         local_clustering_selected(ds, [int(x) for x in args.chunks.split(",")], device=args.device, failed=failed,
-                                  refit=not args.no_refit, record=record)
+                                  refit=not args.no_refit, record=record, trace=trace)
     else:
-        local_clustering(ds, device=args.device, failed=failed, refit=not args.no_refit, record=record)
-    for row in record or []:
+        local_clustering(ds, device=args.device, failed=failed, refit=not args.no_refit, record=record, trace=trace)
+    for row in (trace or []) + (record or []):
         sys.stderr.write(row + "\n")
     for cid, status in failed or []:
         sys.stderr.write(f"LC\tFAILED\t{cid}\t{status}\t{ffi.lib().jtk_lc_strerror(status).decode()}\n")

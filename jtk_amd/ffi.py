@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = (
     "jtk_lc_cluster_chunks", "jtk_lc_cluster_chunks_multi", "jtk_lc_cluster_polished", "jtk_lc_polish_chunks", "jtk_lc_modification_table",
     "jtk_lc_cluster_features", "jtk_lc_estimate_gains", "jtk_lc_estimate_minimum_gain", "jtk_lc_fit_model", "jtk_lc_correct_clustering", "jtk_lc_trim_cache", "jtk_lc_pileup_sort_key", "jtk_lc_normalize_pileup", "jtk_lc_strerror",
     "jtk_lc_last_error", "jtk_lc_version", "jtk_lc_device_ok", "jtk_lc_last_timing",
-    "jtk_lc_session_create", "jtk_lc_session_run", "jtk_lc_session_fetch", "jtk_lc_session_destroy",
+    "jtk_lc_session_create", "jtk_lc_session_run", "jtk_lc_session_fetch", "jtk_lc_session_destroy", "jtk_lc_session_trace",
 )
 SYNTH_SYMBOLS = ("jtk_synth_pileup",)
 
@@ -149,6 +149,7 @@ def lib():
     sig("jtk_lc_session_run", i32, vp, i32)
     sig("jtk_lc_session_fetch", i32, vp, PU32, PD, vp, PU8, PU64, u64, PU8, PU64, u64)
     sig("jtk_lc_session_destroy", i32, vp)
+    sig("jtk_lc_session_trace", i32, vp, sz, C.c_char_p, sz, C.POINTER(sz))
     _lib = L
     return L
 

@@ -84,6 +84,13 @@ typedef struct jo_cluster_config { /* pseudo_mcmc.rs:17-25 */
     double local_coverage;
 } jo_cluster_config_t;
 
+/* the reference's trace! rows of a chunk's clustering (TOTAL / CAND / PICK / DUMP / RANGE / LK / COUNTS; pseudo_mcmc.c says which
+ * lines) go to the sink while one is set: '\n'-terminated rows; len keeps counting beyond cap */
+typedef struct jo_trace {
+    char *text;
+    size_t cap, len;
+} jo_trace_t;
+void jo_trace_set(jo_trace_t *t);
 void jo_homopolymer_length(const uint8_t *xs, size_t n, size_t *out);        /* :195-211 */
 double jo_cosine_similarity(const double *profiles, size_t n, size_t cols, size_t i, size_t j); /* :602 */
 double jo_sokal_michener(const double *profiles, size_t n, size_t cols, size_t i, size_t j);    /* :618 */

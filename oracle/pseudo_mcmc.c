@@ -12,6 +12,39 @@
 #define NUM_ROW JTK_NUM_ROW
 #define COPY_SIZE JTK_COPY_SIZE
 
+/* ---- the reference's trace! rows (log level Trace) of one chunk's clustering, into a text buffer.  One sink for the process: the
+ * caller (jo_trace_chunk, local_clustering.c) runs ONE chunk while it is set.  Rows kept: TOTAL :467, CAND :471, PICK :539,
+ * DUMP :126, RANGE :236, LK :250,:256, COUNTS :262.  (Not kept: the per-column PVALUE / RAWCOUNT / FILTER rows, REMOVE, VARS.)
+ * Rust's {:.N} and C's %.Nf both print the correctly rounded decimal; NaN is "NaN" in Rust. */
+#include <stdarg.h>
+#include <stdio.h>
+static jo_trace_t *jo_trace_sink = NULL;
+void jo_trace_set(jo_trace_t *t) { jo_trace_sink = t; }
+static void trace_row(const char *fmt, ...) {
+    jo_trace_t *t = jo_trace_sink;
+    if (!t) return;
+    char line[512];
+    va_list ap;
+    va_start(ap, fmt);
+    int m = vsnprintf(line, sizeof line, fmt, ap);
+    va_end(ap);
+    if (m < 0) return;
+    if ((size_t)m >= sizeof line) m = (int)sizeof line - 1;
+    if (t->len + (size_t)m + 1 <= t->cap) {
+        memcpy(t->text + t->len, line, (size_t)m);
+        t->text[t->len + (size_t)m] = '\n';
+    }
+    t->len += (size_t)m + 1; /* keeps counting beyond cap: the caller learns the size it needs */
+}
+/* {x:.N} of an f64 */
+static const char *fx(char *buf, size_t cap, double x, int prec) {
+    if (x != x)
+        snprintf(buf, cap, "NaN");
+    else
+        snprintf(buf, cap, "%.*f", prec, x);
+    return buf;
+}
+
 /* pseudo_mcmc.rs:168-178 */
 static void pos_to_bp_and_difftype(size_t pos, size_t *bp, int *dt) {
     size_t op = pos % NUM_ROW;
@@ -234,6 +267,14 @@ static size_t pick_filtered_profiles(const size_t *ppos, const double *pscore, s
             if (nx < 0) break;
             size_t picked_pos = ppos[nx];
             size_t picked_bp = picked_pos / NUM_ROW;
+            if (jo_trace_sink) { /* :538-539: position in bp, DiffType as S / I / D, lk */
+                size_t bp_;
+                int dt_;
+                char b_[64];
+                pos_to_bp_and_difftype(picked_pos, &bp_, &dt_);
+                trace_row("PICK\t%zu\t%s\t%s", bp_, dt_ == JTK_DIFF_SUBST ? "S" : (dt_ == JTK_DIFF_DEL ? "D" : "I"),
+                          fx(b_, sizeof b_, pscore[nx], 3));
+            }
             sel[nx] = 1;
             for (size_t i = 0; i < np; i++) {
                 if (!(sel[i] == 0 || sel[i] == 3)) continue;
@@ -304,6 +345,14 @@ size_t jo_filter_profiles(const uint8_t *tmpl, size_t tl, const double *profiles
             ppos[np] = pos;
             pscore[np] = total_lk;
             np++;
+        }
+    }
+    if (jo_trace_sink) { /* :467-472 */
+        trace_row("TOTAL\t%zu", np);
+        for (size_t i = 0; i < np; i++) {
+            char b_[64];
+            trace_row("CAND\t%zu\t%zu\t%s\t%zu", ppos[i] / NUM_ROW, ppos[i] % NUM_ROW, fx(b_, sizeof b_, pscore[i], 1),
+                      tot_cnt[ppos[i]]);
         }
     }
     size_t d = pick_filtered_profiles(ppos, pscore, np, profiles, n, cols, cluster_num, pos_out, score_out);
@@ -586,6 +635,8 @@ int jo_cluster_filtered_variants(const double *variants, size_t n, size_t dim, c
     size_t end = copy_num < 1 + 2 * dim ? copy_num : 1 + 2 * dim;
     size_t start = (end > 5 ? end : 5) - 3;
     int rc = 0;
+    double *old_gn = (double *)calloc(n ? n : 1, sizeof(double)); /* read_lk_gains (:229): feeds the trace rows only */
+    trace_row("RANGE\t%zu..=%zu", start, end);                    /* :236, {:?} of a RangeInclusive */
     for (size_t k = start; k <= end; k++) {
         double score;
         if (jo_mcmc_clustering(variants, n, dim, k, coverage, rng, asn, &score, gn, used) != 0) {
@@ -604,8 +655,36 @@ int jo_cluster_filtered_variants(const double *variants, size_t n, size_t dim, c
         }
         double expected_gain_per_read = expected_gains(cfg->gains, vt_homop, vt_type, dim, prev_used, used);
         double expected_gain = expected_gain_per_read * per_cluster_cov + 0.1;
+        if (jo_trace_sink) { /* :250-256; min_gain :276-284 (min_by: first minimum; the value only), count_improved_reads :308-312 */
+            double min_gain = 1.0;
+            int have_min = 0;
+            for (size_t d = 0; d < dim; d++)
+                if (used[d]) {
+                    double v = jo_gains_expected(cfg->gains, vt_homop[d], vt_type[d]) / 3.0;
+                    if (!have_min || v < min_gain) min_gain = v;
+                    have_min = 1;
+                }
+            size_t improved = 0;
+            for (size_t i = 0; i < n; i++)
+                if (old_gn[i] + min_gain < gn[i]) improved++;
+            char b1[64], b2[64];
+            trace_row("LK\t%zu\t%s", k, fx(b1, sizeof b1, score, 3));
+            trace_row("LK\t%zu\t%s\t%s\t%zu", k, fx(b1, sizeof b1, score, 3), fx(b2, sizeof b2, expected_gain, 3), improved);
+        }
         if (expected_gain < score - max) {
+            if (jo_trace_sink) { /* :258-262, {:?} of a Vec<usize> */
+                char line[256];
+                size_t w = 0;
+                w += (size_t)snprintf(line + w, sizeof line - w, "COUNTS\t[");
+                for (size_t c = 0; c < k; c++) {
+                    size_t cnt = 0;
+                    for (size_t i = 0; i < n; i++) cnt += asn[i] == c;
+                    w += (size_t)snprintf(line + w, sizeof line - w, c ? ", %zu" : "%zu", cnt);
+                }
+                trace_row("%s]", line);
+            }
             memcpy(assignments, asn, n * sizeof(size_t));
+            memcpy(old_gn, gn, n * sizeof(double));
             max = score;
             max_k = k;
             memcpy(prev_used, used, dim);
@@ -618,6 +697,7 @@ int jo_cluster_filtered_variants(const double *variants, size_t n, size_t dim, c
         *score_out = max;
         *k_out = max_k;
     }
+    free(old_gn);
     free(prev_used);
     free(used);
     free(used2);
@@ -673,6 +753,14 @@ size_t jo_search_variants(const uint8_t *tmpl, size_t tl, size_t n, const uint8_
     }
     for (size_t r = 0; r < n; r++)
         for (size_t j = 0; j < d; j++) variants[r * d + j] = profiles[r * cols + pos_out[j]];
+    if (jo_trace_sink) /* :122-127 */
+        for (size_t j = 0; j < d; j++) {
+            double sum = 0.0;
+            for (size_t r = 0; r < n; r++) sum += jtk_fmax(profiles[r * cols + pos_out[j]], 0.0);
+            char b1[64], b2[64];
+            trace_row("DUMP\t%zu\t%zu\t%zu\t%s\t%s", j, pos_out[j] / NUM_ROW, pos_out[j] % NUM_ROW, fx(b1, sizeof b1, score[j], 1),
+                      fx(b2, sizeof b2, sum, 1));
+        }
     free(homop);
     free(score);
     free(profiles);

@@ -221,6 +221,11 @@ def likelihood(hmm, tmpl, read, ops, radius):
 
 def cluster_chunks(params, batch, skip_polish=False, n_threads=0, want_record=False):
     """batch: jtk_amd.batch.Batch-like object with flat numpy arrays (see jtk_amd/batch.py)."""
+    return _cluster_chunks_live(params, batch, skip_polish, n_threads, want_record)
+
+
+def _cluster_chunks_live(params, batch, skip_polish=False, n_threads=0, want_record=False):
+    """(the live oracle: tests/conftest.py puts the fixture directory in front of cluster_chunks, never of this one)"""
     L = lib()
     nchunks = len(batch.chunks)
     nreads = len(batch.strand)
@@ -245,6 +250,28 @@ def cluster_chunks(params, batch, skip_polish=False, n_threads=0, want_record=Fa
     if want_record:
         out["record_ms"] = rec
     return out
+
+
+class Trace(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("cap", C.c_size_t), ("len", C.c_size_t)]
+
+
+def trace_chunk(params, batch, chunk, skip_polish=False):
+    """the reference's trace! rows of one chunk's clustering as the oracle logs them (oracle/pseudo_mcmc.c: TOTAL / CAND / PICK /
+    DUMP / RANGE / LK / COUNTS): the chunk alone through jo_cluster_chunks on one thread while the sink is set; a list of rows"""
+    L = lib()
+    L.jo_trace_set.restype = None
+    L.jo_trace_set.argtypes = [C.POINTER(Trace)]
+    sub = batch.subset([int(chunk)])
+    buf = C.create_string_buffer(1 << 20)
+    t = Trace(C.cast(buf, C.c_void_p), len(buf), 0)
+    L.jo_trace_set(C.byref(t))
+    try:
+        out = _cluster_chunks_live(params, sub, skip_polish=skip_polish, n_threads=1)
+    finally:
+        L.jo_trace_set(None)
+    assert t.len <= len(buf)
+    return out, buf.raw[:t.len].decode().splitlines()
 
 
 def polish_chunks(params, batch, radius=0, take_num=0, ignore_edge=0, n_threads=0):

@@ -181,9 +181,16 @@ def test_json_stage_matches_the_cpp_host_mirror(jtk_lib, tmp_path, capsys, n_sel
     argv = [str(src), str(dst)] + (["--chunks", ",".join(str(c) for c in range(n_selected))] if n_selected < n_chunks else [])
     argv += [] if refit else ["--no-refit"]           # refit: update_models_on_both_strands on the device (mod.rs:58)
     argv += ["--verbose"]                             # the reference's RECORD lines (mod.rs:121) on stderr
+    argv += ["--trace"] if not refit else []          # and its trace! rows (TOTAL / CAND / PICK / DUMP / RANGE / LK / COUNTS)
     D.main(argv)                                      # gains: estimate_gain_default on the device (mod.rs:60)
     out = json.loads(dst.read_text())
-    rec = [l.split("\t") for l in capsys.readouterr().err.splitlines() if l.startswith("RECORD\t")]
+    err = capsys.readouterr().err.splitlines()
+    rec = [l.split("\t") for l in err if l.startswith("RECORD\t")]
+    if not refit:   # one TOTAL row per clustered chunk; where a cluster count was accepted, its COUNTS row adds up to the pile-up
+        assert sum(l.startswith("TOTAL\t") for l in err) == n_selected
+        for l in err:
+            if l.startswith("COUNTS\t"):
+                assert sum(int(x) for x in l.split("\t")[1].strip("[]").split(", ")) == 2 * rph
     exe = HM.build_driver()
     ref = subprocess.run([exe, str(n_chunks), str(tmpl_len), str(rph), "-", str(n_selected), "1" if refit else "0"],
                          capture_output=True, text=True, env=dict(os.environ, JTK_HOST_MIRROR_RECORD="1"))

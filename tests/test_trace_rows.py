@@ -1,0 +1,147 @@
+"""The reference's trace! rows of a chunk's clustering (`LK`, `CAND`, `PICK`; pseudo_mcmc.rs:122-127 DUMP, :236 RANGE,
+:250,:256 LK, :262 COUNTS, :467 TOTAL, :471 CAND, :539 PICK).  The oracle writes them where the reference's trace! calls stand
+(oracle/pseudo_mcmc.c); the device re-runs the chunk's pick and chain in recording instantiations (jtk_lc_session_trace) and must
+produce the same text, row for row.  CPU: the oracle's rows agree with the oracle's own results and with the Rust format strings.
+GPU: device text == oracle text."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+import oracle_ffi as O
+from jtk_amd import api, batch as jb, ffi, synth
+
+
+def _params(cfg):
+    return jb.default_params(cfg["coverage"], cfg["band_frac"])
+
+
+def _check_rows_against_result(rows, res, n_reads):
+    """what the rows must say given the chunk's result record (score, cluster_num, n_variants)"""
+    kinds = [r.split("\t")[0] for r in rows]
+    assert kinds[0] == "TOTAL"
+    total = int(rows[0].split("\t")[1])
+    cands = [r.split("\t") for r in rows if r.startswith("CAND\t")]
+    picks = [r.split("\t") for r in rows if r.startswith("PICK\t")]
+    dumps = [r.split("\t") for r in rows if r.startswith("DUMP\t")]
+    assert len(cands) == total
+    assert len(dumps) == int(res["n_variants"]) <= len(picks) <= total
+    # the order the reference logs in: TOTAL, CAND*, PICK*, DUMP*, then RANGE, (LK, LK, COUNTS?)*
+    assert re.fullmatch(r"T C* P* D* (R (L L N?)*)?".replace(" ", ""),
+                        "".join({"TOTAL": "T", "CAND": "C", "PICK": "P", "DUMP": "D", "RANGE": "R", "LK": "L", "COUNTS": "N"}[k]
+                                for k in kinds))
+    cand_cols = [(int(c[1]), int(c[2])) for c in cands]
+    assert cand_cols == sorted(cand_cols)                                      # candidates in column order
+    assert [(int(d[2]), int(d[3])) for d in dumps] == sorted((int(d[2]), int(d[3])) for d in dumps)   # the selected ones too
+    for c in cands:
+        assert 0 <= int(c[2]) < 14 and re.fullmatch(r"-?\d+\.\d", c[3]) and 0 < int(c[4]) <= n_reads
+    for p in picks:
+        assert p[2] in ("S", "I", "D") and re.fullmatch(r"-?\d+\.\d{3}", p[3])
+    for i, d in enumerate(dumps):
+        assert int(d[1]) == i and (d[2], d[3]) in [(c[1], c[2]) for c in cands]
+        assert d[4] == [c[3] for c in cands if (c[1], c[2]) == (d[2], d[3])][0]   # the candidate's lk, {:.1} both times
+    if "RANGE" in kinds:
+        lo, hi = map(int, rows[kinds.index("RANGE")].split("\t")[1].split("..="))
+        lks = [r.split("\t") for r in rows if r.startswith("LK\t")]
+        assert len(lks) % 2 == 0 and all(len(a) == 3 and len(b) == 5 and a[1:3] == b[1:3] for a, b in zip(lks[::2], lks[1::2]))
+        ks = [int(a[1]) for a in lks[::2]]
+        assert ks == list(range(lo, lo + len(ks))) and ks[-1] <= hi
+        counts = [r for r in rows if r.startswith("COUNTS\t")]
+        if counts:
+            last = [int(x) for x in counts[-1].split("\t")[1].strip("[]").split(", ")]
+            assert len(last) == int(res["cluster_num"]) and sum(last) == n_reads
+            accepted_lk = lks[2 * (len(counts) - 1)][2]
+            assert accepted_lk == "%.3f" % float(res["score"])                # the accepted k's score is the chunk's
+        else:
+            assert int(res["cluster_num"]) == 1 and float(res["score"]) == 0.0
+    else:
+        assert int(res["cluster_num"]) == 1 and float(res["score"]) == 0.0
+
+
+def test_oracle_trace_rows_agree_with_its_results(oracle):
+    b, cfg = synth.make_batch("ont_diploid", 3)
+    p = helpers.oracle_params(_params(cfg))
+    plain = O._cluster_chunks_live(p, b, n_threads=0)
+    seen_range = False
+    for c in range(3):
+        out, rows = O.trace_chunk(p, b, c)
+        assert out["rc"] == 0
+        # tracing changes nothing
+        assert np.array_equal(out["label"], plain["label"][b.chunks["read_first"][c]:][:b.chunks["n_reads"][c]])
+        assert helpers.bits(out["result"]["score"])[0] == helpers.bits(plain["result"]["score"])[c]
+        _check_rows_against_result(rows, out["result"][0], int(b.chunks["n_reads"][c]))
+        seen_range = seen_range or any(r.startswith("RANGE") for r in rows)
+    assert seen_range, "none of the three pile-ups had a variant column: the LK rows went unchecked"
+    # no sink, no rows, same answers (the sink is cleared after a traced chunk)
+    again = O._cluster_chunks_live(p, b, n_threads=0)
+    assert np.array_equal(again["label"], plain["label"])
+
+
+def test_oracle_rows_follow_the_rust_format_strings(oracle):
+    """RANGE is {:?} of a RangeInclusive, COUNTS {:?} of a Vec<usize>; a copy-number-1 chunk logs nothing (pseudo_mcmc.rs:86-88).
+    ({:.1} / {:.3} of the lk fields: _check_rows_against_result.)"""
+    b, cfg = synth.make_batch("ont_diploid", 1)
+    p = helpers.oracle_params(_params(cfg))
+    one = b.subset([0])
+    one.chunks["copy_num"][0] = 1
+    _, rows = O.trace_chunk(p, one, 0)
+    assert rows == []
+    out, rows = O.trace_chunk(p, b, 0)
+    rng = [r for r in rows if r.startswith("RANGE")]
+    assert rng == ["RANGE\t2..=2"]                       # copy_num 2: start = max(end, 5) - 3 = 2 = end
+    counts = [r for r in rows if r.startswith("COUNTS")]
+    assert counts and re.fullmatch(r"COUNTS\t\[\d+, \d+\]", counts[0])
+    lab = out["label"]
+    # the COUNTS row is the k = 2 clustering BEFORE the re-assignment of clustering()'s tail (:98-105); the sizes still add up
+    assert sum(int(x) for x in counts[0].split("\t")[1].strip("[]").split(", ")) == len(lab)
+
+
+@pytest.mark.gpu
+def test_device_trace_rows_match_the_oracle(jtk_lib, oracle):
+    """diploid ONT (light chain), HiFi (pair kernel) and a 4-copy pile-up (K-way chain, k = 2 .. 4 tried): the session's rows are
+    the oracle's, byte for byte, and the session's results are untouched by the recording re-run"""
+    cases = [("ont_diploid", 6, [0, 1, 2, 5]), ("hifi_diploid", 2, [0, 1]), ("ont_4copy", 2, [0, 1])]
+    seen_lk = 0
+    for name, n_chunks, which in cases:
+        b, cfg = synth.make_batch(name, n_chunks)
+        p = _params(cfg)
+        with api.Session(p, b) as s:
+            s.run()
+            before = s.fetch()
+            for c in which:
+                dev_rows = s.trace(c)
+                _, ora_rows = O.trace_chunk(helpers.oracle_params(p), b, c)
+                assert dev_rows == ora_rows, (name, c, dev_rows, ora_rows)
+                _check_rows_against_result(dev_rows, before["result"][c], int(b.chunks["n_reads"][c]))
+                seen_lk += sum(r.startswith("LK\t") for r in dev_rows)
+            after = s.fetch()
+            for k in ("label", "log_post", "result", "cons", "cons_off", "ops_out", "ops_out_off"):
+                assert before[k].tobytes() == after[k].tobytes(), (name, k)
+    assert seen_lk >= 8
+
+
+@pytest.mark.gpu
+def test_device_trace_after_skip_polish_and_its_errors(jtk_lib, oracle):
+    b, cfg = synth.make_batch("ont_diploid", 2)
+    p = _params(cfg)
+    L = ffi.lib()
+    need = C.c_size_t(0)
+    with api.Session(p, b) as s:
+        # before any run: nothing to trace
+        assert L.jtk_lc_session_trace(s._h, 0, None, 0, C.byref(need)) == -1          # JTK_ERR_INVALID_ARG
+        s.run(skip_polish=True)                                                       # pseudo_mcmc::clustering on the draft as given
+        rows = s.trace(0)
+        _, ora = O.trace_chunk(helpers.oracle_params(p), b, 0, skip_polish=True)
+        assert rows == ora
+        assert L.jtk_lc_session_trace(s._h, 7, None, 0, C.byref(need)) == -1          # no such chunk
+        small = C.create_string_buffer(4)
+        assert L.jtk_lc_session_trace(s._h, 0, small, 4, C.byref(need)) == -1 and need.value == sum(len(r) + 1 for r in rows) > 4
+        assert L.jtk_lc_session_trace(None, 0, small, 4, C.byref(need)) == -1
+    # a session that holds a chunk of copy number >= 8 (clustering_recursive) is refused
+    b8, cfg8 = synth.make_batch("ont_4copy", 1, reads_per_hap=10)
+    b8.chunks["copy_num"][0] = 8
+    with api.Session(_params(cfg8), b8) as s:
+        s.run()
+        assert L.jtk_lc_session_trace(s._h, 0, None, 0, C.byref(need)) == -3          # JTK_ERR_UNSUPPORTED
