@@ -103,6 +103,11 @@ struct LocalClusteringOptions {
     // milliseconds are its share of the call's kernel time (jtk_lc_last_timing): pair-HMM + polishing by band cells x passes,
     // the chain by proposals x candidate k.  nullptr: no lines.
     std::ostream *record = nullptr;
+    // The reference's trace! rows of every clustered chunk (log level Trace: TOTAL / CAND / PICK / DUMP / RANGE / LK / COUNTS,
+    // pseudo_mcmc.rs:122-127,236,250-262,467-472,539), chunk after chunk in chunk-id order: the call's chunks once more through a
+    // resident session and jtk_lc_session_trace (a debugging aid, like the log level it mirrors).  Not available for a call that
+    // holds a chunk of copy number >= 8 (clustering_recursive): nothing is written then.  nullptr: no rows.
+    std::ostream *trace = nullptr;
 };
 
 inline double band_frac(ReadType t) {  // definitions/src/lib.rs:173-175, 201-210
@@ -384,6 +389,28 @@ inline void local_clustering_selected(DataSet &ds, const std::unordered_set<uint
                          polish_ms, (unsigned long long)(cons_off[c + 1] - cons_off[c]), result[c].score, chunks[c].n_reads);
                 *opt.record << line;
             }
+        }
+    }
+    if (opt.trace) {
+        jtk_lc_session_t *sess = nullptr;
+        if (jtk_lc_session_create(&params, chunks.size(), chunks.data(), tmpl.data(), reads.data(), read_off.data(), ops.data(),
+                                  ops_off.data(), strand.data(), stride, opt.device, &sess) == 0) {
+            const int run_rc = jtk_lc_session_run(sess, 0);
+            if (run_rc == 0 || run_rc == JTK_ERR_CHUNK_FAILED) {
+                std::vector<char> text(1 << 16);
+                for (size_t c = 0; c < chunks.size(); c++) {
+                    if (result[c].status != 0) continue;
+                    size_t len = 0;
+                    int trc = jtk_lc_session_trace(sess, c, text.data(), text.size(), &len);
+                    if (trc != 0 && len > text.size()) {
+                        text.resize(len);
+                        trc = jtk_lc_session_trace(sess, c, text.data(), text.size(), &len);
+                    }
+                    if (trc != 0) break;  // (JTK_ERR_UNSUPPORTED: the call holds a chunk of copy number >= 8)
+                    opt.trace->write(text.data(), (std::streamsize)len);
+                }
+            }
+            jtk_lc_session_destroy(sess);
         }
     }
     normalize_local_clustering(ds);  // mod.rs:82

@@ -87,6 +87,7 @@ int main(int argc, char **argv) {
     opt.gains = device_gains ? nullptr : &gains;
     opt.refit_model = argc > 6 && atoi(argv[6]) != 0;  // update_models_on_both_strands (mod.rs:58)
     if (getenv("JTK_HOST_MIRROR_RECORD")) opt.record = &std::cerr;  // the reference's RECORD lines (mod.rs:121) on stderr
+    if (getenv("JTK_HOST_MIRROR_TRACE")) opt.trace = &std::cerr;    // and its trace! rows (TOTAL / CAND / PICK / DUMP / RANGE / LK / COUNTS)
     try {
         if (n_selected >= n_chunks) {
             jtk::local_clustering(ds, opt);

@@ -193,8 +193,12 @@ def test_json_stage_matches_the_cpp_host_mirror(jtk_lib, tmp_path, capsys, n_sel
                 assert sum(int(x) for x in l.split("\t")[1].strip("[]").split(", ")) == 2 * rph
     exe = HM.build_driver()
     ref = subprocess.run([exe, str(n_chunks), str(tmpl_len), str(rph), "-", str(n_selected), "1" if refit else "0"],
-                         capture_output=True, text=True, env=dict(os.environ, JTK_HOST_MIRROR_RECORD="1"))
+                         capture_output=True, text=True,
+                         env=dict(os.environ, JTK_HOST_MIRROR_RECORD="1", **({} if refit else {"JTK_HOST_MIRROR_TRACE": "1"})))
     assert ref.returncode == 0, ref.stderr
+    if not refit:   # the trace! rows of the two host mirrors are the same text
+        kinds = ("TOTAL\t", "CAND\t", "PICK\t", "DUMP\t", "RANGE\t", "LK\t", "COUNTS\t")
+        assert [l for l in err if l.startswith(kinds)] == [l for l in ref.stderr.splitlines() if l.startswith(kinds)]
     # RECORD\tchunk id\telapsed ms\tpolish ms\tconsensus length\tscore (3 decimals)\tcoverage -- one per clustered chunk, from
     # the stage itself, in both host mirrors (the milliseconds are a share of the call's kernel time: not compared)
     rec_cpp = [l.split("\t") for l in ref.stderr.splitlines() if l.startswith("RECORD\t")]

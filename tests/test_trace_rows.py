@@ -98,6 +98,47 @@ def test_oracle_rows_follow_the_rust_format_strings(oracle):
     assert sum(int(x) for x in counts[0].split("\t")[1].strip("[]").split(", ")) == len(lab)
 
 
+def _golden_cases():
+    import json
+    import os
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, here)
+    import make_cfg3_64
+    import make_trace_rows as mk
+    g = json.load(open(os.path.join(here, "trace_rows.json")))
+    for case in g["cases"]:
+        b, p = mk.make_inputs(case["config"], case["n_chunks"])
+        assert make_cfg3_64.inputs_digest(b) == case["inputs_sha256"], "the generator no longer produces the golden's inputs"
+        yield case, b, p
+
+
+def test_oracle_reproduces_the_golden_trace_rows(oracle):
+    """tests/golden/trace_rows.json (tests/golden/make_trace_rows.py): the oracle in the tree still writes the committed rows"""
+    n = 0
+    for case, b, p in _golden_cases():
+        _, rows = O.trace_chunk(helpers.oracle_params(p), b, case["chunk"])
+        assert rows == case["rows"], (case["config"], case["chunk"])
+        n += 1
+    assert n >= 5
+
+
+@pytest.mark.gpu
+def test_device_reproduces_the_golden_trace_rows(jtk_lib):
+    """the device's rows against the committed ones: no oracle in the loop"""
+    sessions = {}
+    try:
+        for case, b, p in _golden_cases():
+            key = (case["config"], case["n_chunks"])
+            if key not in sessions:
+                sessions[key] = api.Session(p, b)
+                sessions[key].run()
+            assert sessions[key].trace(case["chunk"]) == case["rows"], (case["config"], case["chunk"])
+    finally:
+        for s in sessions.values():
+            s.close()
+
+
 @pytest.mark.gpu
 def test_device_trace_rows_match_the_oracle(jtk_lib, oracle):
     """diploid ONT (light chain), HiFi (pair kernel) and a 4-copy pile-up (K-way chain, k = 2 .. 4 tried): the session's rows are
