@@ -98,6 +98,68 @@ def test_oracle_rows_follow_the_rust_format_strings(oracle):
     assert sum(int(x) for x in counts[0].split("\t")[1].strip("[]").split(", ")) == len(lab)
 
 
+def test_cand_and_dump_rows_against_a_numpy_restatement(oracle):
+    """CAND's lk and count (pseudo_mcmc.rs:457-461 + column_sum :577-588) and DUMP's sum (:124) recomputed here in numpy from the
+    oracle's per-read tables: table - lk, compress_small_gains (:141-165: |x| below half the expected gain of the column's type
+    and homopolymer length -> 0), per column the sum and count of the gains above POS_THR, lk = max_k Poisson(count | k * coverage)
+    + sum.  A second statement of what the rows mean, independent of the C that writes them."""
+    import math
+    b, cfg = synth.make_batch("ont_diploid", 1)
+    p = _params(cfg)
+    po = helpers.oracle_params(p)
+    _, rows = O.trace_chunk(po, b, 0, skip_polish=True)     # skip_polish: the template the tables are taken on is the one given
+    cands = [r.split("\t") for r in rows if r.startswith("CAND\t")]
+    dumps = [r.split("\t") for r in rows if r.startswith("DUMP\t")]
+    assert cands and dumps
+    tmpl = b.template(0)
+    tl, n = len(tmpl), int(b.chunks["n_reads"][0])
+    radius = int(math.ceil(tl * p.band_frac)) // 2          # mod.rs:96,112
+    tabs = []
+    for r in b.chunk_reads(0):
+        hmm = po.forward if b.strand[r] else po.reverse
+        tab, lk = O.modification_table(hmm, tmpl, b.read(r), b.read_ops(r), radius)
+        tabs.append(tab - lk)
+    prof = np.array(tabs)                                   # n x 14 (tl + 1)
+    homop = np.ones(tl, dtype=np.int64)                     # homopolymer_length :195-211
+    i = 0
+    while i < tl:
+        j = i
+        while j + 1 < tl and tmpl[j + 1] == tmpl[i]:
+            j += 1
+        homop[i:j + 1] = j - i + 1
+        i = j + 1
+
+    def expected(homop_len, row):                           # Gains::expected, likelihood_gains.rs:79-87; difftype :168-178
+        g = p.gains
+        h = min(max(int(homop_len), 1), int(g.max_homopolymer_len))
+        tab = g.subst if row < 4 else (g.insertions if row < 8 + 3 else g.deletions)
+        return tab[h - 1].gain
+
+    cov = float(p.haploid_coverage)
+    for c in cands:
+        bp, row, lk_txt, count_txt = int(c[1]), int(c[2]), c[3], int(c[4])
+        mr = expected(homop[bp] if bp < tl else 1, row) * 0.5
+        col = prof[:, bp * 14 + row].copy()
+        col[np.abs(col) < mr] = 0.0
+        gain, count = 0.0, 0
+        for x in col:                                       # left to right, as the reference sums
+            if 0.00001 < x:
+                gain += float(x)
+                count += 1
+        assert count == count_txt
+        pois = max(count * math.log(cov * k) - cov * k - sum(math.log(q) for q in range(1, count + 1)) for k in (1, 2))
+        assert "%.1f" % (pois + gain) == lk_txt, (bp, row, pois + gain, lk_txt)
+    for d in dumps:
+        bp, row = int(d[2]), int(d[3])
+        mr = expected(homop[bp] if bp < tl else 1, row) * 0.5
+        col = prof[:, bp * 14 + row].copy()
+        col[np.abs(col) < mr] = 0.0
+        tot = 0.0
+        for x in col:
+            tot += max(float(x), 0.0)
+        assert "%.1f" % tot == d[5]
+
+
 def _golden_cases():
     import json
     import os
