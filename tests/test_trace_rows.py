@@ -205,7 +205,8 @@ def test_device_reproduces_the_golden_trace_rows(jtk_lib):
 def test_device_trace_rows_match_the_oracle(jtk_lib, oracle):
     """diploid ONT (light chain), HiFi (pair kernel) and a 4-copy pile-up (K-way chain, k = 2 .. 4 tried): the session's rows are
     the oracle's, byte for byte, and the session's results are untouched by the recording re-run"""
-    cases = [("ont_diploid", 6, [0, 1, 2, 5]), ("hifi_diploid", 2, [0, 1]), ("ont_4copy", 2, [0, 1])]
+    # (a 4-copy chunk's recording chain takes ~23 s on the device: one here, another one in the golden test above)
+    cases = [("ont_diploid", 6, [0, 1, 2, 5]), ("hifi_diploid", 2, [0, 1]), ("ont_4copy", 2, [1])]
     seen_lk = 0
     for name, n_chunks, which in cases:
         b, cfg = synth.make_batch(name, n_chunks)
@@ -222,7 +223,7 @@ def test_device_trace_rows_match_the_oracle(jtk_lib, oracle):
             after = s.fetch()
             for k in ("label", "log_post", "result", "cons", "cons_off", "ops_out", "ops_out_off"):
                 assert before[k].tobytes() == after[k].tobytes(), (name, k)
-    assert seen_lk >= 8
+    assert seen_lk >= 6
 
 
 @pytest.mark.gpu
