@@ -98,15 +98,17 @@ def test_oracle_rows_follow_the_rust_format_strings(oracle):
     assert sum(int(x) for x in counts[0].split("\t")[1].strip("[]").split(", ")) == len(lab)
 
 
-def test_cand_and_dump_rows_against_a_numpy_restatement(oracle):
+@pytest.mark.parametrize("config", ["ont_diploid", "ont_4copy"])
+def test_cand_and_dump_rows_against_a_numpy_restatement(oracle, config):
     """CAND's lk and count (pseudo_mcmc.rs:457-461 + column_sum :577-588) and DUMP's sum (:124) recomputed here in numpy from the
     oracle's per-read tables: table - lk, compress_small_gains (:141-165: |x| below half the expected gain of the column's type
     and homopolymer length -> 0), per column the sum and count of the gains above POS_THR, lk = max_k Poisson(count | k * coverage)
     + sum.  A second statement of what the rows mean, independent of the C that writes them."""
     import math
-    b, cfg = synth.make_batch("ont_diploid", 1)
+    b, cfg = synth.make_batch(config, 1)
     p = _params(cfg)
     po = helpers.oracle_params(p)
+    ks = range(1, int(b.chunks["copy_num"][0]) + 1)         # the cluster counts of the Poisson term (:457-460)
     _, rows = O.trace_chunk(po, b, 0, skip_polish=True)     # skip_polish: the template the tables are taken on is the one given
     cands = [r.split("\t") for r in rows if r.startswith("CAND\t")]
     dumps = [r.split("\t") for r in rows if r.startswith("DUMP\t")]
@@ -147,7 +149,7 @@ def test_cand_and_dump_rows_against_a_numpy_restatement(oracle):
                 gain += float(x)
                 count += 1
         assert count == count_txt
-        pois = max(count * math.log(cov * k) - cov * k - sum(math.log(q) for q in range(1, count + 1)) for k in (1, 2))
+        pois = max(count * math.log(cov * k) - cov * k - sum(math.log(q) for q in range(1, count + 1)) for k in ks)
         assert "%.1f" % (pois + gain) == lk_txt, (bp, row, pois + gain, lk_txt)
     for d in dumps:
         bp, row = int(d[2]), int(d[3])
@@ -158,6 +160,55 @@ def test_cand_and_dump_rows_against_a_numpy_restatement(oracle):
         for x in col:
             tot += max(float(x), 0.0)
         assert "%.1f" % tot == d[5]
+    # PICK rows: pick_filtered_profiles (:516-575) restated -- three rounds of max(copy_num, 2) picks, each the LAST maximum among
+    # the candidates still open (find_next_variants :590-600), a pick closes the candidates within MASK_LENGTH bp for good and those
+    # that resemble it (Sokal-Michener or |cosine| above 0.8 over the reads where both columns are non-zero) until the next round
+    def column(c):
+        bp, row = int(c[1]), int(c[2])
+        col = prof[:, bp * 14 + row].copy()
+        col[np.abs(col) < expected(homop[bp] if bp < tl else 1, row) * 0.5] = 0.0
+        return col
+    cols = [column(c) for c in cands]
+    # the scores at full precision are not in the rows: recompute them as above (they decide the order)
+    score = []
+    for c, col in zip(cands, cols):
+        g = float(sum(float(x) for x in col if 0.00001 < x))
+        cnt = int(c[4])
+        score.append(max(cnt * math.log(cov * k) - cov * k - sum(math.log(q) for q in range(1, cnt + 1)) for k in ks) + g)
+    sel = [0] * len(cands)
+    order = []
+    for _round in range(3):
+        sel = [0 if f == 3 else f for f in sel]
+        for _ in range(max(int(b.chunks["copy_num"][0]), 2)):
+            open_ = [i for i, f in enumerate(sel) if f == 0]
+            if not open_:
+                break
+            nx = max(reversed(open_), key=lambda i: score[i])          # max_by: the last maximum
+            order.append(nx)
+            sel[nx] = 1
+            for i, f in enumerate(sel):
+                if f not in (0, 3):
+                    continue
+                if abs(int(cands[i][1]) - int(cands[nx][1])) < 7:       # MASK_LENGTH
+                    sel[i] = 2
+                    continue
+                x, y = cols[nx], cols[i]
+                both = (np.abs(x) > 0.00001) & (np.abs(y) > 0.00001)
+                mat = int(((x * y > 0) & both).sum())
+                tot = int(both.sum())
+                sok = 0.0 if tot == 0 else max(mat, tot - mat) / tot
+                isq, jsq = float((x[both] ** 2).sum()), float((y[both] ** 2).sum())
+                cs = 0.0 if isq == 0.0 else float((x[both] * y[both]).sum()) / math.sqrt(isq) / math.sqrt(jsq)
+                if 0.8 < sok or 0.8 < abs(cs):
+                    sel[i] = 3
+    picks = [r.split("\t") for r in rows if r.startswith("PICK\t")]
+    letter = lambda row: "S" if row < 4 else ("I" if row < 11 else "D")
+    assert [(p_[1], p_[2]) for p_ in picks] == [(cands[i][1], letter(int(cands[i][2]))) for i in order]
+    assert [p_[3] for p_ in picks] == ["%.3f" % score[i] for i in order]
+    assert sorted(i for i, f in enumerate(sel) if f == 1) == sorted(
+        i for i, c in enumerate(cands) if (c[1], c[2]) in [(d[2], d[3]) for d in dumps])       # the selected columns are the DUMP rows
+    if config == "ont_4copy":   # the case is there for what the diploid one lacks: candidates closed by a pick
+        assert len(cands) > len(dumps) >= 4 and any(f in (2, 3) for f in sel)
 
 
 def _golden_cases():
