@@ -12,13 +12,14 @@
 #define NUM_ROW JTK_NUM_ROW
 #define COPY_SIZE JTK_COPY_SIZE
 
-/* ---- the reference's trace! rows (log level Trace) of one chunk's clustering, into a text buffer.  One sink for the process: the
- * caller (jo_trace_chunk, local_clustering.c) runs ONE chunk while it is set.  Rows kept: TOTAL :467, CAND :471, PICK :539,
+/* ---- the reference's trace! rows (log level Trace) of one chunk's clustering, into a text buffer.  The sink belongs to the THREAD
+ * that set it: the caller (tests/oracle_ffi.py: trace_chunk) runs ONE chunk on one thread (jo_cluster_chunks with n_threads = 1
+ * stays on the calling thread) while it is set; the worker threads of any other call see no sink and write nothing.  Rows kept: TOTAL :467, CAND :471, PICK :539,
  * DUMP :126, RANGE :236, LK :250,:256, COUNTS :262.  (Not kept: the per-column PVALUE / RAWCOUNT / FILTER rows, REMOVE, VARS.)
  * Rust's {:.N} and C's %.Nf both print the correctly rounded decimal; NaN is "NaN" in Rust. */
 #include <stdarg.h>
 #include <stdio.h>
-static jo_trace_t *jo_trace_sink = NULL;
+static __thread jo_trace_t *jo_trace_sink = NULL;
 void jo_trace_set(jo_trace_t *t) { jo_trace_sink = t; }
 static void trace_row(const char *fmt, ...) {
     jo_trace_t *t = jo_trace_sink;

@@ -265,11 +265,17 @@ def trace_chunk(params, batch, chunk, skip_polish=False):
     sub = batch.subset([int(chunk)])
     buf = C.create_string_buffer(1 << 20)
     t = Trace(C.cast(buf, C.c_void_p), len(buf), 0)
+    # n_threads = 1 keeps the chunk on this thread (the sink is thread-local); jo_cluster_chunks sets OpenMP's thread count for the
+    # process, so it is put back afterwards: the oracle calls of the tests that follow run on every CPU again
+    gomp = C.CDLL("libgomp.so.1")
+    gomp.omp_get_max_threads.restype = C.c_int
+    before = gomp.omp_get_max_threads()
     L.jo_trace_set(C.byref(t))
     try:
         out = _cluster_chunks_live(params, sub, skip_polish=skip_polish, n_threads=1)
     finally:
         L.jo_trace_set(None)
+        gomp.omp_set_num_threads(before)
     assert t.len <= len(buf)
     return out, buf.raw[:t.len].decode().splitlines()
 
