@@ -3,7 +3,7 @@
 // reference's git dependencies are un-vendored.  Source a jtk maintainer adds to ban-m/jtk; INTEGRATION.md explains it and
 // tests/test_rust_shim_source.py keeps it in step with include/jtk_lc.h.  The same call sequence is exercised end to end
 // by the C++ host mirror (jtk_amd/csrc/host/local_clustering.hpp) and the Python harness (jtk_amd/api.py).
-use std::os::raw::{c_char, c_int};
+use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct JtkHmm {                       // == definitions::HMMParam (definitions/src/lib.rs:101-126)
@@ -82,6 +82,16 @@ extern "C" {
         n_reads: usize, read_id: *const u64, node_off: *const u64, nodes: *const JtkCcNode, posteriors: *const f64,
         n_chunks: usize, chunks: *mut JtkCcChunk, n_selected: usize, selection: *const u64,
         haploid_coverage: f64, min_gain: f64, cluster_out: *mut u64, touched: *mut u8, device: c_int) -> c_int;
+    // the resident-batch form (jtk_lc.h: session_create + run + fetch == jtk_lc_cluster_chunks) and, on it, the reference's
+    // trace! rows of one chunk (TOTAL / CAND / PICK / DUMP / RANGE / LK / COUNTS; pseudo_mcmc.rs:122-127,236,250-262,467-472,539)
+    pub fn jtk_lc_session_create(
+        params: *const JtkLcParams, n_chunks: usize, chunks: *const JtkLcChunk,
+        tmpl_bases: *const u8, read_bases: *const u8, read_off: *const u64,
+        ops: *const u8, ops_off: *const u64, strand: *const u8, post_stride: u32, device: c_int,
+        out: *mut *mut c_void) -> c_int;
+    pub fn jtk_lc_session_run(s: *mut c_void, skip_polish: c_int) -> c_int;
+    pub fn jtk_lc_session_trace(s: *mut c_void, chunk: usize, text: *mut c_char, cap: usize, len: *mut usize) -> c_int;
+    pub fn jtk_lc_session_destroy(s: *mut c_void) -> c_int;
     pub fn jtk_lc_trim_cache(device: c_int) -> c_int;          // hand pooled device workspaces back to the driver
     pub fn jtk_lc_strerror(status: c_int) -> *const c_char;
     pub fn jtk_lc_last_error() -> *const c_char;

@@ -50,6 +50,28 @@ pub(crate) fn clustering_on_pileups_gpu(
     // rc == -6 (JTK_ERR_CHUNK_FAILED): result[c].status names the chunks that hit a condition on which the reference itself
     // panics (e.g. misc.rs:335, pseudo_mcmc.rs:759) or a shape this build does not take; the others are complete.
     assert!(rc == 0 || rc == -6, "{}", unsafe { std::ffi::CStr::from_ptr(jtk_lc_last_error()) }.to_string_lossy());
+    // RUST_LOG=trace: the rows pseudo_mcmc.rs logs per chunk (TOTAL / CAND / PICK / DUMP / RANGE / LK / COUNTS) come from the
+    // device -- the batch once more as a resident session, jtk_lc_session_trace per clustered chunk (a debugging aid, like the
+    // log level; a batch that holds a chunk of copy number >= 8 gets no rows: JTK_ERR_UNSUPPORTED)
+    if log_enabled!(log::Level::Trace) {
+        let mut sess: *mut std::os::raw::c_void = std::ptr::null_mut();
+        if unsafe { jtk_lc_session_create(&params, chunks.len(), chunks.as_ptr(), tmpl.as_ptr(), reads.as_ptr(), read_off.as_ptr(),
+            ops.as_ptr(), ops_off.as_ptr(), strand.as_ptr(), stride, 0, &mut sess) } == 0 {
+            let run_rc = unsafe { jtk_lc_session_run(sess, 0) };
+            let mut text = vec![0u8; 1 << 16];
+            for c in (0..chunks.len()).filter(|&c| (run_rc == 0 || run_rc == -6) && result[c].status == 0) {
+                let mut len = 0usize;
+                let mut trc = unsafe { jtk_lc_session_trace(sess, c, text.as_mut_ptr() as *mut _, text.len(), &mut len) };
+                if trc != 0 && len > text.len() {
+                    text.resize(len, 0);
+                    trc = unsafe { jtk_lc_session_trace(sess, c, text.as_mut_ptr() as *mut _, text.len(), &mut len) };
+                }
+                if trc != 0 { break; }
+                for row in String::from_utf8_lossy(&text[..len]).lines() { trace!("{row}"); }
+            }
+            unsafe { jtk_lc_session_destroy(sess) };
+        }
+    }
     // update_by_clusterings (mod.rs:244-260) + the tuple clustering_on_pileup returns (mod.rs:122)
     let mut consensus_and_clusternum = HashMap::new();
     for (c, id) in order.iter().enumerate() {
