@@ -57,6 +57,17 @@ prob = helpers.correction_problem(3, n_chunks=5, n_reads=30, wrong=0.05)
 rc, *_ = O.correct_clustering(prob["read_id"], prob["node_off"], prob["nodes"], prob["posteriors"], prob["chunks"].copy(),
                               np.arange(5, dtype=np.uint64), 20.0, 1.0, 0)
 assert rc == 0
+# the trace! rows of a chunk (oracle/pseudo_mcmc.c: trace_row), into a buffer that holds them and into one that does not
+b, cfg, p = helpers.small_batch(n_chunks=1, tmpl_len=250, reads_per_hap=5)
+out, rows = O.trace_chunk(helpers.oracle_params(p), b, 0)
+assert out["rc"] == 0 and rows and rows[0].startswith("TOTAL")
+import ctypes as C
+buf = C.create_string_buffer(16)
+t = O.Trace(C.cast(buf, C.c_void_p), len(buf), 0)
+O.lib().jo_trace_set(C.byref(t))
+O._cluster_chunks_live(helpers.oracle_params(p), b, n_threads=1)
+O.lib().jo_trace_set(None)
+assert t.len == sum(len(r) + 1 for r in rows) > 16 and buf.raw[:6] == b"TOTAL\t"
 print("ok")
 '''
     assert "ok" in run_child(code, {})
